@@ -1,0 +1,339 @@
+"""CPU oracle for the PSI-GNN fixed-point inference path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain PyTorch-CPU restatement, operation for operation, of the reference's
+hot path.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import it; the product package (``psi-gnn_amd/``) never does.
+
+What it restates (reference file:line, all under /root/reference):
+
+* ``remove_self_loops`` + ``MessagePassing.propagate`` for ``Phi_to`` / ``Phi_from``
+  (``dirichlet/psignn/model.py:334-368``; PyG semantics in SURVEY.md §8a-a3),
+* ``MLP`` (``model.py:316-332``), ``Function.forward`` dirichlet (``model.py:279-300`` ≡
+  ``tests/model_psignn.py:269-290``) and mixed (``mixed/psignn/model.py:216-245``),
+* ``Encoder/Decoder`` (``model.py:370-392``), ``residual_loss`` (``model.py:157-167``),
+* ``ModelPSIGNN.forward`` glue (``tests/model_psignn.py:58-100``),
+* the solver library ``dirichlet/psignn/utilities/solver.py`` (broyden ``:116-207`` with
+  ``matvec/rmatvec :96-114`` and the ``ls=False`` branch of ``line_search :61-94``;
+  ``anderson :215-293``; ``forward_iteration :301-341``; ``newton :349-366``).
+
+Pinning status
+--------------
+* Solvers: PINNED.  ``oracle/make_golden.py`` runs the reference's own ``solver.py`` (importable
+  in the build container) and this restatement on identical inputs; traces, step counts and
+  results are compared bit-for-bit there and the vectors are committed under ``tests/golden/``.
+* ``Function.forward``: the arithmetic inside ``torch_geometric`` / ``torch_sparse`` (absent, unpinned
+  versions) cannot be executed here and the reference's tests hold no numeric vector for it →
+  **parity unpinned at bit level** for that boundary.  It is pinned semantically by (i) the PyG
+  contract restated in SURVEY §8a-a3, (ii) the reference's trained checkpoints, and (iii) the
+  reference's recorded statistics on in-distribution meshes, reproduced by this oracle on the real
+  gmsh mesh recovered from ``tests/special_geo/mesh_files/original`` (``tests/test_oracle_golden.py``).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------
+# weights
+# --------------------------------------------------------------------------------------
+def _mlp(sd, prefix, x):
+    """``MLP``: Linear, ReLU, Linear (model.py:316-332); keys ``<prefix>.mlp.{0,2}.{weight,bias}``."""
+    x = F.linear(x, sd[prefix + ".mlp.0.weight"], sd[prefix + ".mlp.0.bias"])
+    x = torch.relu(x)
+    return F.linear(x, sd[prefix + ".mlp.2.weight"], sd[prefix + ".mlp.2.bias"])
+
+
+def is_mixed_state_dict(sd) -> bool:
+    return any(k.startswith("deqdss.f.phi_neumann") for k in sd)
+
+
+def n_layers_of(sd) -> int:
+    ks = [k for k in sd if k.startswith("deqdss.f.update_list.")]
+    return 1 + max(int(k.split(".")[3]) for k in ks)
+
+
+# --------------------------------------------------------------------------------------
+# message passing
+# --------------------------------------------------------------------------------------
+def remove_self_loops(edge_index, edge_attr):
+    """torch_geometric.utils.remove_self_loops: keep edges with row != col (model.py:342,360)."""
+    keep = edge_index[0] != edge_index[1]
+    return edge_index[:, keep], edge_attr[keep]
+
+
+def phi(sd, prefix, h, edge_index, edge_attr, flow):
+    """One ``Phi_to`` (flow='source_to_target') / ``Phi_from`` ('target_to_source') pass.
+
+    PyG: (i, j) = (1, 0) for source_to_target else (0, 1); x_i = h[edge_index[i]],
+    x_j = h[edge_index[j]]; message = MLP([x_i, x_j, edge_attr]); summed at edge_index[i].
+    """
+    ei, ea = remove_self_loops(edge_index, edge_attr)
+    i, j = (1, 0) if flow == "source_to_target" else (0, 1)
+    x_i = h.index_select(0, ei[i])
+    x_j = h.index_select(0, ei[j])
+    msg = _mlp(sd, prefix + ".mlp", torch.cat([x_i, x_j, ea], dim=1))
+    out = torch.zeros_like(h)
+    out.index_add_(0, ei[i], msg)
+    return out
+
+
+def function_forward(sd, h, h_initial, batch):
+    """``Function.forward`` — dirichlet (model.py:279-300) or mixed (mixed/psignn/model.py:216-245),
+    chosen by the state dict."""
+    P = "deqdss.f."
+    nl = n_layers_of(sd)
+    if not is_mixed_state_dict(sd):
+        idx_d = torch.where(batch.tags == 1)[0]
+        for k in range(nl):
+            mp_to = phi(sd, f"{P}phi_to_list.{k}", h, batch.edge_index, batch.edge_attr, "source_to_target")
+            mp_from = phi(sd, f"{P}phi_from_list.{k}", h, batch.edge_index, batch.edge_attr, "target_to_source")
+            cat = torch.cat([h, mp_to, mp_from, batch.prb_data], dim=1)
+            alpha = torch.sigmoid(F.linear(cat, sd[P + "alpha.0.weight"], sd[P + "alpha.0.bias"]))
+            upd = alpha * _mlp(sd, f"{P}update_list.{k}", cat)
+            if k == nl - 1:
+                h = F.layer_norm(h + upd, (h.shape[1],), sd[P + "laynorm.weight"], sd[P + "laynorm.bias"], 1e-5)
+            else:
+                h = h + upd
+            h[idx_d, :] = h_initial[idx_d, :]
+        return h
+    # mixed: note the reference never reassigns h inside the loop
+    idx_d = torch.where(batch.tags[:, 1] == 1)[0]
+    idx_n = torch.where(batch.tags[:, 2] == 1)[0]
+    h_next = h
+    for k in range(nl):
+        mp_to = phi(sd, f"{P}phi_to_list.{k}", h, batch.edge_index, batch.edge_attr, "source_to_target")
+        mp_from = phi(sd, f"{P}phi_from_list.{k}", h, batch.edge_index, batch.edge_attr, "target_to_source")
+        mp_neu = phi(sd, f"{P}phi_neumann", h, batch.edge_index, batch.edge_attr, "target_to_source")
+        cat = torch.cat([h, mp_to, mp_from, batch.prb_data], dim=1)
+        alpha = torch.sigmoid(F.linear(cat, sd[P + "alpha.0.weight"], sd[P + "alpha.0.bias"]))
+        upd = alpha * _mlp(sd, f"{P}update_list.{k}", cat)
+        cat_n = torch.cat([h, mp_neu, batch.prb_data, batch.unit_normal_vector], dim=1)
+        upd_n = _mlp(sd, f"{P}update_neumann", cat_n)
+        h_next = h + upd
+        h_next[idx_n, :] = upd_n[idx_n, :]
+        if k == nl - 1:
+            h_next = F.layer_norm(h_next, (h.shape[1],), sd[P + "laynorm.weight"], sd[P + "laynorm.bias"], 1e-5)
+        h_next[idx_d, :] = h_initial[idx_d, :]
+    return h_next
+
+
+def encoder(sd, x):
+    return _mlp(sd, "autoencoder.encoder.mlp", x)
+
+
+def decoder(sd, h):
+    return _mlp(sd, "autoencoder.decoder.mlp", h)
+
+
+def residual_loss(u, batch):
+    """mean((A u - y)^2), A = COO(row=edge_index[0], col=edge_index[1], a_ij) incl. the diagonal
+    (model.py:157-167)."""
+    r, c = batch.edge_index[0], batch.edge_index[1]
+    Au = torch.zeros_like(u)
+    Au.index_add_(0, r, batch.a_ij.reshape(-1, 1) * u.index_select(0, c))
+    return torch.mean((Au - batch.y) ** 2)
+
+
+# --------------------------------------------------------------------------------------
+# solvers  (dirichlet/psignn/utilities/solver.py)
+# --------------------------------------------------------------------------------------
+def _rmatvec(Us, VTs, x):  # solver.py:96-104
+    if Us.nelement() == 0:
+        return -x
+    xTU = torch.einsum("bij, bijd -> bd", x, Us)
+    return -x + torch.einsum("bd, bdij -> bij", xTU, VTs)
+
+
+def _matvec(Us, VTs, x):  # solver.py:106-114
+    if Us.nelement() == 0:
+        return -x
+    VTx = torch.einsum("bdij, bij -> bd", VTs, x)
+    return -x + torch.einsum("bijd, bd -> bij", Us, VTx)
+
+
+def broyden(f, x0, threshold, eps=1e-3, stop_mode="rel", ls=False, name="unknown"):
+    """solver.py:116-207 with ls=False (the only mode any caller uses)."""
+    assert not ls, "line search is never enabled by the reference's callers"
+    x0 = x0[None, :]
+    bsz, total_hsize, seq_len = x0.size()
+    g = lambda y: f(y) - y
+    alt = "rel" if stop_mode == "abs" else "abs"
+    x_est = x0
+    gx = g(x_est[0, :]).view_as(x0)
+    Us = torch.zeros(bsz, total_hsize, seq_len, threshold).to(x0.device)
+    VTs = torch.zeros(bsz, threshold, total_hsize, seq_len).to(x0.device)
+    update = -_matvec(Us[:, :, :, :0], VTs[:, :0], gx)
+    prot_break = False
+    protect_thres = (1e6 if stop_mode == "abs" else 1e3) * seq_len
+    trace = {"abs": [], "rel": []}
+    lowest = {"abs": 1e8, "rel": 1e8}
+    lowest_step = {"abs": 0, "rel": 0}
+    nstep, lowest_xest = 0, x_est[0, :]
+    xest_trace = [x_est[0, :]]
+    while nstep < threshold:
+        x_new = x_est + 1.0 * update  # line_search(on=False): s = 1.0 (solver.py:85-94)
+        gx_new = g(x_new[0, :]).view_as(x_est)
+        delta_x, delta_gx = x_new - x_est, gx_new - gx
+        x_est, gx = x_new, gx_new
+        xest_trace.append(x_est[0, :])
+        nstep += 1
+        abs_diff = torch.norm(gx).item()
+        rel_diff = abs_diff / (torch.norm(gx + x_est).item() + 1e-9)
+        diff = {"abs": abs_diff, "rel": rel_diff}
+        trace["abs"].append(abs_diff)
+        trace["rel"].append(rel_diff)
+        for mode in ("rel", "abs"):
+            if diff[mode] < lowest[mode]:
+                if mode == stop_mode:
+                    lowest_xest = x_est[0, :].clone().detach()
+                lowest[mode] = diff[mode]
+                lowest_step[mode] = nstep
+        obj = diff[stop_mode]
+        if obj < eps:
+            break
+        if obj < 3 * eps and nstep > 30 and np.max(trace[stop_mode][-30:]) / np.min(trace[stop_mode][-30:]) < 1.3:
+            break
+        if obj > trace[stop_mode][0] * protect_thres:
+            prot_break = True
+            break
+        pU, pV = Us[:, :, :, :nstep - 1], VTs[:, :nstep - 1]
+        vT = _rmatvec(pU, pV, delta_x)
+        u = (delta_x - _matvec(pU, pV, delta_gx)) / torch.einsum("bij, bij -> b", vT, delta_gx)[:, None, None]
+        vT[vT != vT] = 0
+        u[u != u] = 0
+        VTs[:, nstep - 1] = vT
+        Us[:, :, :, nstep - 1] = u
+        update = -_matvec(Us[:, :, :, :nstep], VTs[:, :nstep], gx)
+    for _ in range(threshold + 1 - len(trace[stop_mode])):
+        trace[stop_mode].append(lowest[stop_mode])
+        trace[alt].append(lowest[alt])
+    return {"result": lowest_xest, "lowest": lowest[stop_mode], "nstep": lowest_step[stop_mode],
+            "prot_break": prot_break, "abs_trace": trace["abs"], "rel_trace": trace["rel"],
+            "xest_trace": xest_trace, "eps": eps, "threshold": threshold}
+
+
+def anderson(f, x0, m=2, lam=1e-4, threshold=50, eps=1e-3, stop_mode="rel", beta=1.0, **kwargs):
+    """solver.py:215-293."""
+    x0 = x0[None, :]
+    bsz, d, L = x0.shape
+    alt = "rel" if stop_mode == "abs" else "abs"
+    X = torch.zeros(bsz, m, d * L, dtype=x0.dtype, device=x0.device)
+    Fm = torch.zeros(bsz, m, d * L, dtype=x0.dtype, device=x0.device)
+    X[:, 0] = x0.reshape(bsz, -1)
+    Fm[:, 0] = f(x0[0, :]).view_as(x0).reshape(bsz, -1)
+    X[:, 1] = Fm[:, 0]
+    Fm[:, 1] = f(Fm[:, 0].reshape_as(x0)[0, :]).view_as(x0).reshape(bsz, -1)
+    H = torch.zeros(bsz, m + 1, m + 1, dtype=x0.dtype, device=x0.device)
+    H[:, 0, 1:] = H[:, 1:, 0] = 1
+    y = torch.zeros(bsz, m + 1, 1, dtype=x0.dtype, device=x0.device)
+    y[:, 0] = 1
+    trace = {"abs": [], "rel": []}
+    lowest = {"abs": 1e8, "rel": 1e8}
+    lowest_step = {"abs": 0, "rel": 0}
+    xest_trace = [x0[0, :]]
+    lowest_xest = None
+    for k in range(2, threshold):
+        n = min(k, m)
+        G = Fm[:, :n] - X[:, :n]
+        H[:, 1:n + 1, 1:n + 1] = torch.bmm(G, G.transpose(1, 2)) + lam * torch.eye(n, dtype=x0.dtype, device=x0.device)[None]
+        alpha = torch.linalg.solve(H[:, :n + 1, :n + 1], y[:, :n + 1])[:, 1:n + 1, 0]
+        X[:, k % m] = beta * (alpha[:, None] @ Fm[:, :n])[:, 0] + (1 - beta) * (alpha[:, None] @ X[:, :n])[:, 0]
+        Fm[:, k % m] = f(X[:, k % m].reshape_as(x0)[0, :]).view_as(x0).reshape(bsz, -1)
+        gx = (Fm[:, k % m] - X[:, k % m]).view_as(x0)
+        abs_diff = gx.norm().item()
+        rel_diff = abs_diff / (1e-5 + Fm[:, k % m].norm().item())
+        diff = {"abs": abs_diff, "rel": rel_diff}
+        trace["abs"].append(abs_diff)
+        trace["rel"].append(rel_diff)
+        for mode in ("rel", "abs"):
+            if diff[mode] < lowest[mode]:
+                if mode == stop_mode:
+                    lowest_xest = X[:, k % m].view_as(x0).clone().detach()
+                lowest[mode] = diff[mode]
+                lowest_step[mode] = k
+        xest_trace.append(lowest_xest[0, :])
+        if trace[stop_mode][-1] < eps:
+            for _ in range(threshold - 1 - k):
+                trace[stop_mode].append(lowest[stop_mode])
+                trace[alt].append(lowest[alt])
+            break
+    return {"result": lowest_xest[0, :], "lowest": lowest[stop_mode], "nstep": lowest_step[stop_mode],
+            "prot_break": False, "abs_trace": trace["abs"], "rel_trace": trace["rel"],
+            "xest_trace": xest_trace, "eps": eps, "threshold": threshold}
+
+
+def forward_iteration(f, z0, eps=1.e-5, threshold=50):
+    """solver.py:301-341."""
+    z_est = [z0]
+    z_prev = z0
+    z = f(z0)
+    trace = {"abs": [], "rel": []}
+    ite = 0
+    abs_res = torch.linalg.norm(z_prev - z)
+    rel_res = abs_res / torch.linalg.norm(z)
+    trace["abs"].append(abs_res.detach())
+    trace["rel"].append(rel_res.detach())
+    z_est.append(z)
+    while trace["rel"][-1] > eps and ite < threshold:
+        z_prev = z
+        z = f(z_prev)
+        ite += 1
+        abs_res = torch.linalg.norm(z_prev - z)
+        rel_res = abs_res / torch.linalg.norm(z)
+        trace["abs"].append(abs_res.detach())
+        trace["rel"].append(rel_res.detach())
+        z_est.append(z)
+    return {"result": z, "lowest": trace["rel"][-1], "abs_trace": trace["abs"], "rel_trace": trace["rel"],
+            "xest_trace": z_est, "nstep": ite, "eps": eps, "threshold": threshold}
+
+
+def newton(f, z0, eps=1.e-5, threshold=50):
+    """solver.py:349-366 — node-block-diagonal Newton wrapped in forward_iteration."""
+    f_root = lambda z: f(z) - z
+    g = lambda z: z - torch.linalg.solve(
+        torch.einsum("bibj->bij", torch.autograd.functional.jacobian(f_root, z)), f_root(z))
+    r = forward_iteration(g, z0, eps=eps, threshold=threshold)
+    return {"result": r["result"], "lowest": r["lowest"], "rel_trace": r["rel_trace"],
+            "abs_trace": r["abs_trace"], "xest_trace": r["xest_trace"], "nstep": r["nstep"],
+            "eps": eps, "threshold": threshold}
+
+
+# --------------------------------------------------------------------------------------
+# model glue (tests/model_psignn.py:58-100)
+# --------------------------------------------------------------------------------------
+def model_forward(sd, batch, solver=broyden, fw_tol=1e-5, fw_thres=500):
+    """``ModelPSIGNN.forward`` → (u_final, loss_dic, solver_out)."""
+    mixed = is_mixed_state_dict(sd)
+    with torch.no_grad():
+        h0 = encoder(sd, batch.x)
+        out = solver(lambda H: function_forward(sd, H, h0, batch), h0, threshold=fw_thres, eps=fw_tol)
+        h = out["result"]
+        u = decoder(sd, h)
+        mse = torch.nn.functional.mse_loss
+        idx_d = torch.where((batch.tags[:, 1] if mixed else batch.tags[:, 0]) == 1)[0]
+        loss = {
+            "residual_loss": residual_loss(u, batch),
+            "encoder_loss": mse(encoder(sd, u), h),
+            "autoencoder_loss": mse(decoder(sd, encoder(sd, u)), u),
+            "mse_loss": mse(u, batch.sol),
+            "mse_dirichlet_loss": mse(u[idx_d, :], batch.x[idx_d, :]),
+            "nsteps": out["nstep"],
+        }
+    return u, loss, out
+
+
+def function_jvp(sd, h, h_initial, batch, v):
+    """Directional derivative of ``Function.forward`` w.r.t. h along v (autograd forward-mode via
+    double-backward trick is avoided: torch.autograd.functional.jvp)."""
+    fn = lambda H: function_forward(sd, H, h_initial, batch)
+    _, jv = torch.autograd.functional.jvp(fn, (h,), (v,))
+    return jv
+
+
+def function_vjp(sd, h, h_initial, batch, v):
+    """vᵀ J of ``Function.forward`` (what ``autograd.grad(new_H, H, v)`` computes, model.py:214,432,449)."""
+    hh = h.detach().clone().requires_grad_(True)
+    out = function_forward(sd, hh, h_initial, batch)
+    return torch.autograd.grad(out, hh, v)[0]
