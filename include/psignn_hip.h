@@ -1,0 +1,180 @@
+/*
+ * psignn_hip.h — C ABI of libpsignn_hip.so, the MI355X (gfx950) implementation of the PSI-GNN
+ * fixed-point inference hot path.
+ *
+ * The reference (mnastorg/PSI-GNN) has no FFI layer: its hot path is Python calling
+ * torch_geometric / torch_sparse / ATen kernels.  Each entry point below replaces one such
+ * call site; the citation after "replaces:" is the reference file:line (relative to the
+ * reference repository root).  All pointers named d_* are DEVICE pointers (hipMalloc'ed or
+ * owned by any framework's allocator); h_* are host pointers.  `stream` is a hipStream_t
+ * passed as void* (NULL = default stream).  Every function returns 0 on success or a negative
+ * PSIGNN_E* code; psignn_last_error() returns a message for the calling thread.
+ *
+ * Unless stated otherwise calls are asynchronous on `stream` and perform no host sync.
+ * Tensors are dense row-major float32; node states are (N, 10) — the latent width d = 10 is
+ * the only value the reference ever trains (SURVEY.md "d") and is fixed at compile time.
+ */
+#ifndef PSIGNN_HIP_H
+#define PSIGNN_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSIGNN_D 10            /* latent_dim */
+#define PSIGNN_EDGE_F 3        /* edge_features_dim */
+
+#define PSIGNN_OK 0
+#define PSIGNN_EINVAL (-1)     /* bad argument / shape */
+#define PSIGNN_EHIP (-2)       /* HIP runtime error */
+#define PSIGNN_EINDEX (-3)     /* edge index out of range */
+#define PSIGNN_ENOMEM (-4)
+
+const char* psignn_last_error(void);
+int psignn_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Mesh plan: everything iteration-invariant, computed once per mesh on the device.
+ *
+ * replaces: torch_geometric.utils.remove_self_loops executed twice per f call
+ *           (dirichlet/psignn/model.py:342,360), torch.where(tags == 1) re-run every f call
+ *           (model.py:281; mixed/psignn/model.py:218-219), and the COO->CSR conversion inside
+ *           SparseTensor(...) (model.py:159-163).
+ *
+ * Layout built (all int32 / float32, device memory owned by the plan):
+ *   csr: non-self edges grouped by row  r = edge_index[0]  (aggregation side of Phi_from)
+ *   csc: non-self edges grouped by col  c = edge_index[1]  (aggregation side of Phi_to)
+ *   inside a group edges are ordered by (other endpoint, original edge id) — a canonical order
+ *   independent of the input edge order; edge_attr is stored once per ordering;
+ *   full CSR of A (self loops included, a_ij values) for the residual SpMV;
+ *   node flags: bit0 = Dirichlet, bit1 = Neumann.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct psignn_plan psignn_plan_t;
+
+/* tags: (N, tags_cols) float32 with tags_cols = 1 (dirichlet: tags[:,0]==1 -> Dirichlet) or
+ * 3 (mixed one-hot [interior, dirichlet, neumann]).  d_a_ij may be NULL (no residual SpMV).
+ * Synchronous: returns after the plan is complete (one device->host read of the edge count). */
+int psignn_plan_create(psignn_plan_t** out, int64_t n_nodes, int64_t n_edges,
+                       const int64_t* d_edge_index /* (2, E) */, const float* d_edge_attr /* (E,3) */,
+                       const float* d_a_ij /* (E) or NULL */, const float* d_tags, int tags_cols,
+                       void* stream);
+void psignn_plan_destroy(psignn_plan_t* plan);
+
+int64_t psignn_plan_num_nodes(const psignn_plan_t* plan);
+int64_t psignn_plan_num_edges(const psignn_plan_t* plan);          /* E, as given */
+int64_t psignn_plan_num_nonself_edges(const psignn_plan_t* plan);  /* E' */
+
+/* Copy one plan array to host memory (tests: bit-exact comparison with the numpy oracle).
+ * which: 0 csr_ptr(N+1 i32) 1 csr_nbr(E' i32) 2 csr_eid(E' i32) 3 csc_ptr 4 csc_nbr 5 csc_eid
+ *        6 node_flags (N u8) 7 csr_attr (E'*3 f32) 8 csc_attr 9 a_ptr (N+1 i32) 10 a_col (E i32)
+ *        11 a_val (E f32).  Synchronous. */
+int psignn_plan_export(const psignn_plan_t* plan, int which, void* h_dst, size_t dst_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Weights: one flat float32 device buffer in the order documented in DESIGN.md §weights
+ * (nn.Linear (out,in) row-major blocks, concatenated).  psignn_weights_size() gives its length.
+ * replaces: the nn.Module parameter tensors of Function / Phi_to / Phi_from / MLP
+ *           (dirichlet/psignn/model.py:265-277,316-368; mixed/psignn/model.py:198-214).
+ * ------------------------------------------------------------------------------------------ */
+int64_t psignn_weights_size(int mixed, int n_layers);
+
+/* ------------------------------------------------------------------------------------------
+ * f_theta: one application of the GNN block.
+ * replaces: Function.forward (dirichlet/psignn/model.py:279-300 == tests/model_psignn.py:269-290;
+ *           mixed/psignn/model.py:216-245) including both/all three MessagePassing.propagate
+ *           passes, the gated update MLP, LayerNorm and the Dirichlet/Neumann row handling.
+ * d_prb: (N,2) dirichlet / (N,3) mixed.  d_normals: (N,2) mixed only, else NULL.
+ * d_work: scratch of psignn_f_workspace_floats(plan) floats.  d_out must not alias d_h.
+ * ------------------------------------------------------------------------------------------ */
+int64_t psignn_f_workspace_floats(const psignn_plan_t* plan);
+int psignn_f_forward(const psignn_plan_t* plan, const float* d_weights, int n_layers,
+                     const float* d_h, const float* d_h_initial, const float* d_prb,
+                     const float* d_normals, float* d_out, float* d_work, void* stream);
+
+/* Single message-passing aggregation (tests / diagnostics): which = 0 Phi_to, 1 Phi_from,
+ * 2 Phi_neumann (mixed).  replaces: Phi_to.forward / Phi_from.forward (model.py:334-368). */
+int psignn_phi(const psignn_plan_t* plan, const float* d_weights, int n_layers, int layer, int which,
+               const float* d_h, float* d_out, float* d_work, void* stream);
+
+/* Jacobian-vector product of f at h along v (analytic, no finite differences).
+ * replaces: nothing executable in the reference (scipy.optimize.newton_krylov is imported at
+ *           utilities/solver.py:6 but never called); it is the transpose of the VJP that
+ *           autograd.grad(new_H, H, v) computes at model.py:214,432,449. */
+int psignn_f_jvp(const psignn_plan_t* plan, const float* d_weights, int n_layers,
+                 const float* d_h, const float* d_prb, const float* d_normals,
+                 const float* d_v, float* d_out, float* d_work, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small dense pieces around the solve.
+ * replaces: Encoder / Decoder MLPs (model.py:370-392), residual_loss SpMV (model.py:157-167).
+ * ------------------------------------------------------------------------------------------ */
+/* out (N, dout) = W2 relu(W1 x + b1) + b2 with W1 (hid,din), W2 (dout,hid); din,hid,dout <= 16 */
+int psignn_mlp2(const float* d_x, int64_t n, int din, int hid, int dout,
+                const float* d_w1, const float* d_b1, const float* d_w2, const float* d_b2,
+                float* d_out, void* stream);
+/* d_out (N) = A u - y  (A incl. diagonal). */
+int psignn_residual(const psignn_plan_t* plan, const float* d_u, const float* d_y, float* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * On-device Broyden root-find of g(x) = f(x) - x.
+ * replaces: broyden(f, x0, threshold, eps, stop_mode="rel", ls=False)
+ *           (dirichlet/psignn/utilities/solver.py:116-207) with matvec/rmatvec (:96-114) and the
+ *           two .item() syncs per iteration (:162-163).
+ * The inverse-Jacobian factors are stored U:(thr, N*d), V:(thr, N*d) row-contiguous.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct psignn_broyden psignn_broyden_t;
+
+typedef struct {
+  int32_t nstep;        /* index of the lowest-residual iterate ("nstep" of the reference dict) */
+  int32_t n_iter;       /* iterations executed (= len(xest_trace) - 1) */
+  int32_t prot_break;
+  int32_t stop_reason;  /* 0 threshold, 1 rel<eps, 2 plateau, 3 protective break */
+  double lowest;        /* lowest rel residual */
+  double lowest_abs;
+} psignn_solve_info_t;
+
+/* keep_trace != 0 stores every iterate ((thr+1) * N * d floats) for xest_trace. */
+int psignn_broyden_create(psignn_broyden_t** out, const psignn_plan_t* plan, int threshold, int keep_trace);
+void psignn_broyden_destroy(psignn_broyden_t* s);
+size_t psignn_broyden_bytes(const psignn_broyden_t* s);
+
+/* Solve; synchronous at the end (the result must be complete when it returns).  The host polls the
+ * device-side status every `poll_every` iterations (<=0: default 8).
+ * d_result: (N, d) lowest-residual iterate.  h_rel_trace / h_abs_trace: host arrays of
+ * `threshold` doubles (may be NULL). */
+int psignn_broyden_solve(psignn_broyden_t* s, const float* d_weights, int n_layers,
+                         const float* d_h_initial, const float* d_prb, const float* d_normals,
+                         double eps, int poll_every, float* d_result, psignn_solve_info_t* h_info,
+                         double* h_rel_trace, double* h_abs_trace, void* stream);
+/* Copy iterate i (0..n_iter) of the last solve to d_dst (needs keep_trace). */
+int psignn_broyden_get_iterate(const psignn_broyden_t* s, int i, float* d_dst, void* stream);
+
+/* Generic low-rank machinery for user-supplied f (Python callables): the solver-API drop-in
+ * `broyden(f, x0, threshold, eps)` drives these from the host with one f call per iteration.
+ *   step_begin: x_new = x + update                      -> returns pointer-free: writes d_x_new
+ *   step_end:   given fx = f(x_new): residual norms, stop test, rank-1 update, next update. */
+int psignn_broyden_ext_begin(psignn_broyden_t* s, const float* d_x0, const float* d_fx0, void* stream);
+int psignn_broyden_ext_next_x(psignn_broyden_t* s, float* d_x_new, void* stream);
+/* returns 1 in *h_done when the stop test fired (synchronous read of the status). */
+int psignn_broyden_ext_update(psignn_broyden_t* s, const float* d_fx_new, double eps, int* h_done, void* stream);
+int psignn_broyden_ext_finish(psignn_broyden_t* s, float* d_result, psignn_solve_info_t* h_info,
+                              double* h_rel_trace, double* h_abs_trace, void* stream);
+/* Same, for a problem that is not tied to a mesh plan (any vector length). */
+int psignn_broyden_create_n(psignn_broyden_t** out, int64_t n_elems, int seq_len, int threshold, int keep_trace);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline line;
+ * replaces: the reference's only instrumentation, time.time() around the model call,
+ * tests/special_geo/spec_geo_2.py:313-317).  Off by default.
+ * ------------------------------------------------------------------------------------------ */
+void psignn_prof_enable(int on);
+int psignn_prof_collect(void);   /* sync + aggregate per kernel name; returns the number of names */
+int psignn_prof_get(int i, char* name, int cap, int64_t* calls, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSIGNN_HIP_H */

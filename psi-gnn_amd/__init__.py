@@ -1,0 +1,33 @@
+"""MI355X-native PSI-GNN fixed-point inference.
+
+Import name: the directory is ``psi-gnn_amd``; ``import psignn_amd`` (alias module at the repo root) or
+``importlib.import_module("psi-gnn_amd")`` both load this package.
+"""
+import sys as _sys
+
+from . import data  # noqa: F401
+
+
+def install_reference_aliases():
+    """Register ``utilities`` / ``utilities.solver`` / ``model_psignn`` in ``sys.modules``.
+
+    Reference checkpoints pickle ``config["solver"]`` by its qualified name ``utilities.solver.broyden``
+    (training_class.py:60-66) and reference scripts do ``from utilities import solver`` /
+    ``import model_psignn``; with the aliases installed both resolve to this package.
+    """
+    from . import utilities, model_psignn
+    from .utilities import solver
+    _sys.modules.setdefault("utilities", utilities)
+    _sys.modules.setdefault("utilities.solver", solver)
+    _sys.modules.setdefault("model_psignn", model_psignn)
+
+
+def load_reference_checkpoint(path, map_location="cpu"):
+    """``torch.load(weights_only=True)`` of a reference ``*.pt`` checkpoint (no code from the file runs)."""
+    import torch
+    install_reference_aliases()
+    from .utilities import solver
+    # the pickle names the function by the reference's module path; map that path to our implementation
+    torch.serialization.add_safe_globals(
+        [(getattr(solver, n), f"utilities.solver.{n}") for n in ("broyden", "anderson", "forward_iteration", "newton")])
+    return torch.load(path, map_location=map_location, weights_only=True)

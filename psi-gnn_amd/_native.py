@@ -1,0 +1,124 @@
+"""ctypes binding of libpsignn_hip.so (C ABI declared in include/psignn_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, an exception is
+raised.  Tensors cross the boundary as raw device pointers (``tensor.data_ptr()``) on the
+current HIP stream; torch only supplies memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpsignn_hip.so")
+
+D = 10
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class SolveInfo(C.Structure):
+    _fields_ = [("nstep", C.c_int32), ("n_iter", C.c_int32), ("prot_break", C.c_int32),
+                ("stop_reason", C.c_int32), ("lowest", C.c_double), ("lowest_abs", C.c_double)]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_INT = C.c_int
+
+# name -> (restype, argtypes); mirrors include/psignn_hip.h one to one
+SIGNATURES = {
+    "psignn_last_error": (C.c_char_p, []),
+    "psignn_version": (_INT, []),
+    "psignn_plan_create": (_INT, [C.POINTER(_P), _I64, _I64, _P, _P, _P, _P, _INT, _P]),
+    "psignn_plan_destroy": (None, [_P]),
+    "psignn_plan_num_nodes": (_I64, [_P]),
+    "psignn_plan_num_edges": (_I64, [_P]),
+    "psignn_plan_num_nonself_edges": (_I64, [_P]),
+    "psignn_plan_export": (_INT, [_P, _INT, _P, C.c_size_t]),
+    "psignn_weights_size": (_I64, [_INT, _INT]),
+    "psignn_f_workspace_floats": (_I64, [_P]),
+    "psignn_f_forward": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P]),
+    "psignn_phi": (_INT, [_P, _P, _INT, _INT, _INT, _P, _P, _P, _P]),
+    "psignn_f_jvp": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P]),
+    "psignn_mlp2": (_INT, [_P, _I64, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P]),
+    "psignn_residual": (_INT, [_P, _P, _P, _P, _P]),
+    "psignn_broyden_create": (_INT, [C.POINTER(_P), _P, _INT, _INT]),
+    "psignn_broyden_create_n": (_INT, [C.POINTER(_P), _I64, _INT, _INT, _INT]),
+    "psignn_broyden_destroy": (None, [_P]),
+    "psignn_broyden_bytes": (C.c_size_t, [_P]),
+    "psignn_broyden_solve": (_INT, [_P, _P, _INT, _P, _P, _P, C.c_double, _INT, _P, C.POINTER(SolveInfo),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
+    "psignn_broyden_get_iterate": (_INT, [_P, _INT, _P, _P]),
+    "psignn_broyden_ext_begin": (_INT, [_P, _P, _P, _P]),
+    "psignn_broyden_ext_next_x": (_INT, [_P, _P, _P]),
+    "psignn_broyden_ext_update": (_INT, [_P, _P, C.c_double, C.POINTER(_INT), _P]),
+    "psignn_broyden_ext_finish": (_INT, [_P, _P, C.POINTER(SolveInfo), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_double), _P]),
+    "psignn_prof_enable": (None, [_INT]),
+    "psignn_prof_collect": (_INT, []),
+    "psignn_prof_get": (_INT, [_INT, C.c_char_p, _INT, C.POINTER(_I64), C.POINTER(C.c_double)]),
+}
+
+
+def prof_enable(on: bool):
+    lib().psignn_prof_enable(int(on))
+
+
+def prof_collect():
+    """{kernel name: (calls, total_ms)} of everything launched since the last collect (HIP events)."""
+    l = lib()
+    out = {}
+    for i in range(l.psignn_prof_collect()):
+        name = C.create_string_buffer(64)
+        calls, ms = _I64(0), C.c_double(0.0)
+        check(l.psignn_prof_get(i, name, 64, C.byref(calls), C.byref(ms)), "psignn_prof_get")
+        out[name.value.decode()] = (int(calls.value), float(ms.value))
+    return out
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises NativeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C psi-gnn_amd/csrc`.  There is no CPU fallback for the HIP path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().psignn_last_error().decode("utf-8", "replace")
+        raise NativeError(f"{what} failed (code {rc}): {msg}")
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t) -> int:
+    """Device pointer of a contiguous tensor (or NULL)."""
+    if t is None:
+        return 0
+    if not t.is_contiguous():
+        raise NativeError("tensor handed to the HIP path must be contiguous")
+    return t.data_ptr()
+
+
+def require_cuda(t, name="tensor"):
+    if not t.is_cuda:
+        raise NativeError(f"{name} is on {t.device}: the HIP path needs device tensors and has no CPU fallback")

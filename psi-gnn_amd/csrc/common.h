@@ -1,0 +1,92 @@
+// Shared declarations for libpsignn_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include "../../include/psignn_hip.h"
+
+#define D PSIGNN_D
+
+void psignn_set_error(const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      psignn_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return PSIGNN_EHIP;                                                               \
+    }                                                                                   \
+  } while (0)
+
+#define ARG_CHECK(cond, msg)                                   \
+  do {                                                         \
+    if (!(cond)) {                                             \
+      psignn_set_error("%s: %s", __func__, msg);               \
+      return PSIGNN_EINVAL;                                    \
+    }                                                          \
+  } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// Weight pack layout (floats).  All blocks are nn.Linear (out,in) row-major.
+//   shared : ln_gamma[10] ln_beta[10] alpha_w[30+P] alpha_b[1]            (padded to SHARED_SZ)
+//   layer l: phi_to{W1[10x23] b1[10] W2[10x10] b2[10]}  phi_from{...}  update{U1[10x(30+P)] c1[10] U2[10x10] c2[10]}
+//   mixed  : phi_neu{...350}  upd_neu{N1[10x25] n1[10] N2[10x10] n2[10]}
+// P = second_member_dim = 2 (dirichlet) / 3 (mixed).
+// ---------------------------------------------------------------------------------------------
+template <int P>
+struct WLayout {
+  static constexpr int CAT = 3 * D + P;       // 32 / 33
+  static constexpr int EIN = 2 * D + 3;       // 23
+  static constexpr int LN_G = 0, LN_B = 10, AL_W = 20, AL_B = 20 + CAT;
+  static constexpr int SHARED_SZ = 64;
+  static constexpr int PHI_SZ = D * EIN + D + D * D + D;  // 350
+  static constexpr int PHI_W1 = 0, PHI_B1 = D * EIN, PHI_W2 = D * EIN + D, PHI_B2 = D * EIN + D + D * D;
+  static constexpr int UPD_SZ = D * CAT + D + D * D + D;
+  static constexpr int UPD_W1 = 0, UPD_B1 = D * CAT, UPD_W2 = D * CAT + D, UPD_B2 = D * CAT + D + D * D;
+  static constexpr int LAYER_SZ = 2 * PHI_SZ + UPD_SZ;
+  static constexpr int L_TO = 0, L_FROM = PHI_SZ, L_UPD = 2 * PHI_SZ;
+  static constexpr int NEU_CAT = 2 * D + P + 2;  // 25 (mixed only)
+  static constexpr int NEU_SZ = D * NEU_CAT + D + D * D + D;
+  static constexpr int NEU_W1 = 0, NEU_B1 = D * NEU_CAT, NEU_W2 = D * NEU_CAT + D, NEU_B2 = D * NEU_CAT + D + D * D;
+  __host__ __device__ static constexpr int layer(int l) { return SHARED_SZ + l * LAYER_SZ; }
+  __host__ __device__ static constexpr int phi_neu(int nl) { return SHARED_SZ + nl * LAYER_SZ; }
+  __host__ __device__ static constexpr int upd_neu(int nl) { return SHARED_SZ + nl * LAYER_SZ + PHI_SZ; }
+  __host__ __device__ static constexpr int total(int nl, bool mixed) {
+    return SHARED_SZ + nl * LAYER_SZ + (mixed ? PHI_SZ + NEU_SZ : 0);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Mesh plan (device memory owned here).
+// ---------------------------------------------------------------------------------------------
+struct psignn_plan {
+  int64_t N = 0, E = 0, Ep = 0;
+  int mixed = 0;
+  int32_t *csr_ptr = nullptr, *csr_nbr = nullptr, *csr_eid = nullptr;
+  int32_t *csc_ptr = nullptr, *csc_nbr = nullptr, *csc_eid = nullptr;
+  float *csr_attr = nullptr, *csc_attr = nullptr;  // (E',3)
+  uint8_t* flags = nullptr;                        // (N)
+  int32_t *a_ptr = nullptr, *a_col = nullptr;      // full CSR of A (self loops included)
+  float* a_val = nullptr;
+  int max_deg = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline numbers).
+// Off by default: LAUNCH() is then a plain launch.
+// ---------------------------------------------------------------------------------------------
+extern int g_prof_on;
+void prof_begin(const char* name, hipStream_t st);
+void prof_end(hipStream_t st);
+#define LAUNCH(name, st, ...)            \
+  do {                                   \
+    if (g_prof_on) prof_begin(name, st); \
+    __VA_ARGS__;                         \
+    if (g_prof_on) prof_end(st);         \
+  } while (0)
+
+#define FLAG_DIRICHLET 1
+#define FLAG_NEUMANN 2

@@ -1,0 +1,659 @@
+// On-device Broyden root-find of g(x) = f(x) - x, plus the small dense pieces around a solve (gfx950).
+//
+// Reference: broyden() in dirichlet/psignn/utilities/solver.py:116-207 ("good" Broyden with the
+// inverse Jacobian kept as  B = -I + U V^T,  matvec/rmatvec at :96-114, ls=False so the step is 1).
+//
+// Storage: U, V are (thr, M) row-contiguous, M = N*d (the reference keeps U as (1,N,d,thr) with the
+// rank index innermost, i.e. strided sweeps, and zero-fills 2*thr*M floats up front).
+// Per iteration, with k stored pairs, dx = previous update, dg = g_new - g_old:
+//   dots  pass : a_j = dx.U_j, c_j = V_j.dg, b_j = V_j.g_new            (U and V read once)
+//   axpy  pass : vT = -dx + sum a_j V_j ;  D1 = dx + dg - sum c_j U_j ;  D2 = g_new - sum b_j U_j
+//                                                                        (U and V read once more)
+//   final      : u = D1 / (vT.dg), NaN->0 ;  update = D2 - u (vT.g_new)
+// = 4 k M floats of compulsory traffic (the reference sweeps 6 k M).  All convergence bookkeeping
+// (norms, traces, lowest iterate, the three stop tests of solver.py:176-183) lives in a device-side
+// status block; the host only polls a done flag.  Reductions use fixed-shape partial sums ->
+// bitwise reproducible run to run.
+#include "common.h"
+#include <math.h>
+#include <vector>
+
+#define VEC 16           // elements per thread in the vector kernels
+#define TB 256           // threads per block
+#define CHUNK (VEC * TB) // 4096 elements per block
+
+struct Status {
+  int32_t n_iter;       // iterations done
+  int32_t done;
+  int32_t prot_break;
+  int32_t stop_reason;
+  int32_t lowest_step;
+  int32_t cur;          // buffer index of x_est
+  int32_t low;          // buffer index of the lowest-residual iterate
+  int32_t nxt;          // buffer index the next iterate is written to
+  double lowest_rel, lowest_abs_at;  // lowest rel, and lowest abs (tracked independently, solver.py:170-175)
+  double rel0;
+  double s, beta;       // vT.dg, vT.g
+};
+
+struct psignn_broyden {
+  const psignn_plan* plan = nullptr;
+  int64_t M = 0;
+  int seq_len = D;
+  int thr = 0;
+  int keep_trace = 0;
+  int nblk = 0, npart = 0;
+  float *U = nullptr, *V = nullptr;
+  float* xbuf = nullptr;    // (thr+2, M) with trace, else (3, M)
+  float *gx = nullptr, *dg = nullptr, *upd = nullptr, *fx = nullptr, *fwork = nullptr;
+  float* part = nullptr;    // (3, thr, npart) dot partials; reused for the norm / s,beta partials
+  float* coef = nullptr;    // (3, thr)
+  Status* st = nullptr;     // device
+  double *rel_trace = nullptr, *abs_trace = nullptr;  // device, thr entries
+  Status* h_st = nullptr;   // pinned host mirror
+  size_t bytes = 0;
+  int ext_iter = 0;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ void ld16(const float* __restrict__ p, float* r) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float4 t = q[i];
+    r[4 * i] = t.x; r[4 * i + 1] = t.y; r[4 * i + 2] = t.z; r[4 * i + 3] = t.w;
+  }
+}
+__device__ __forceinline__ void st16(float* __restrict__ p, const float* r) {
+  float4* q = reinterpret_cast<float4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+}
+// Tail-safe vector access: each thread owns VEC consecutive elements starting at e0.
+__device__ __forceinline__ void ldv(const float* __restrict__ p, int64_t e0, int64_t M, float* r) {
+  if (e0 + VEC <= M) {
+    ld16(p + e0, r);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r[i] = (e0 + i < M) ? p[e0 + i] : 0.f;
+  }
+}
+__device__ __forceinline__ void stv(float* __restrict__ p, int64_t e0, int64_t M, const float* r) {
+  if (e0 + VEC <= M) {
+    st16(p + e0, r);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+      if (e0 + i < M) p[e0 + i] = r[i];
+  }
+}
+
+__global__ void k_init_status(Status* st, double* rel_trace, double* abs_trace, int thr) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    st->n_iter = 0; st->done = 0; st->prot_break = 0; st->stop_reason = 0; st->lowest_step = 0;
+    st->cur = 0; st->low = 0; st->nxt = 1;
+    st->lowest_rel = 1e8; st->lowest_abs_at = 1e8; st->rel0 = 0.0; st->s = 0.0; st->beta = 0.0;
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < thr; i += gridDim.x * blockDim.x) {
+    rel_trace[i] = 0.0;
+    abs_trace[i] = 0.0;
+  }
+}
+
+// gx = fx0 - x0 ; upd = gx ; xbuf[0] = x0
+__global__ __launch_bounds__(TB) void k_begin(int64_t M, const float* __restrict__ x0, const float* __restrict__ fx0,
+                                              float* __restrict__ xb, float* __restrict__ gx, float* __restrict__ upd) {
+  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  if (e0 >= M) return;
+  float a[VEC], b[VEC];
+  ldv(x0, e0, M, a);
+  ldv(fx0, e0, M, b);
+  stv(xb, e0, M, a);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) b[i] -= a[i];
+  stv(gx, e0, M, b);
+  stv(upd, e0, M, b);
+}
+
+// x_next = x_cur + upd   (line_search with on=False: s = 1, solver.py:85-94)
+__global__ __launch_bounds__(TB) void k_xnext(int64_t M, const Status* __restrict__ st, float* __restrict__ xb,
+                                              const float* __restrict__ upd, float* __restrict__ copy_out) {
+  if (st->done) return;
+  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  if (e0 >= M) return;
+  const float* xc = xb + (int64_t)st->cur * M;
+  float* xn = xb + (int64_t)st->nxt * M;
+  float a[VEC], b[VEC];
+  ldv(xc, e0, M, a);
+  ldv(upd, e0, M, b);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) a[i] += b[i];
+  stv(xn, e0, M, a);
+  if (copy_out) stv(copy_out, e0, M, a);
+}
+
+// g_new = fx - x_next ; dg = g_new - g ; g = g_new ; per-wave partials of |g_new|^2 and |fx|^2
+__global__ __launch_bounds__(TB) void k_resid(int64_t M, const Status* __restrict__ st, const float* __restrict__ xb,
+                                              const float* __restrict__ fx, float* __restrict__ gx,
+                                              float* __restrict__ dg, float* __restrict__ part, int npart) {
+  if (st->done) return;
+  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  float sg = 0.f, sf = 0.f;
+  if (e0 < M) {
+    const float* xn = xb + (int64_t)st->nxt * M;
+    float x[VEC], f[VEC], g[VEC];
+    ldv(xn, e0, M, x);
+    ldv(fx, e0, M, f);
+    ldv(gx, e0, M, g);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float gn = f[i] - x[i];
+      sg = fmaf(gn, gn, sg);
+      sf = fmaf(f[i], f[i], sf);
+      g[i] = gn - g[i];
+      x[i] = gn;
+    }
+    stv(gx, e0, M, x);
+    stv(dg, e0, M, g);
+  }
+  sg = wave_sum(sg);
+  sf = wave_sum(sf);
+  if ((threadIdx.x & 63) == 0) {
+    int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+    part[w] = sg;
+    part[npart + w] = sf;
+  }
+}
+
+__device__ double block_sum_partials(const float* __restrict__ p, int n, double* sh) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += TB) s += (double)p[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = TB / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+// One block: finish the norms, append to the traces, track the lowest iterate, run the stop tests
+// (solver.py:160-183) and rotate the iterate buffers.
+__global__ __launch_bounds__(TB) void k_check(Status* st, const float* __restrict__ part, int npart,
+                                              double* __restrict__ rel_trace, double* __restrict__ abs_trace,
+                                              double eps, int thr, int seq_len, int keep_trace) {
+  __shared__ double sh[TB];
+  if (st->done) return;
+  double sg = block_sum_partials(part, npart, sh);
+  double sf = block_sum_partials(part + npart, npart, sh);
+  if (threadIdx.x != 0) return;
+  // torch.norm(...) is an fp32 value read back with .item(); the division is done in Python doubles
+  double abs_diff = (double)(float)sqrt(sg);
+  double rel_diff = abs_diff / ((double)(float)sqrt(sf) + 1e-9);
+  int n = st->n_iter + 1;
+  st->n_iter = n;
+  rel_trace[n - 1] = rel_diff;
+  abs_trace[n - 1] = abs_diff;
+  if (n == 1) st->rel0 = rel_diff;
+  bool new_low = rel_diff < st->lowest_rel;
+  if (new_low) {
+    st->lowest_rel = rel_diff;
+    st->lowest_step = n;
+  }
+  if (abs_diff < st->lowest_abs_at) st->lowest_abs_at = abs_diff;
+  // buffer rotation: the iterate just evaluated lives in nxt
+  int cur = st->nxt;
+  int low = new_low ? cur : st->low;
+  int nxt;
+  if (keep_trace) {
+    nxt = cur + 1;
+  } else {
+    nxt = 0;
+    while (nxt == cur || nxt == low) ++nxt;
+  }
+  st->cur = cur;
+  st->low = low;
+  st->nxt = nxt;
+  // stop tests
+  int reason = -1;
+  if (rel_diff < eps) {
+    reason = 1;
+  } else if (rel_diff < 3 * eps && n > 30) {
+    double mx = -1e300, mn = 1e300;
+    for (int i = n - 30; i < n; ++i) {
+      double r = rel_trace[i];
+      mx = r > mx ? r : mx;
+      mn = r < mn ? r : mn;
+    }
+    if (mx / mn < 1.3) reason = 2;
+  }
+  if (reason < 0 && rel_diff > st->rel0 * 1e3 * seq_len) {
+    reason = 3;
+    st->prot_break = 1;
+  }
+  if (reason < 0 && n >= thr) reason = 0;
+  if (reason >= 0) {
+    st->done = 1;
+    st->stop_reason = reason;
+  }
+}
+
+// dots pass: per-wave partials of a_j = dx.U_j, c_j = V_j.dg, b_j = V_j.g   for j < k
+__global__ __launch_bounds__(TB) void k_dots(int64_t M, int k, const Status* __restrict__ st,
+                                             const float* __restrict__ U, const float* __restrict__ V,
+                                             const float* __restrict__ dxv, const float* __restrict__ dgv,
+                                             const float* __restrict__ gv, float* __restrict__ part, int npart, int thr) {
+  if (st->done) return;
+  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  float dx[VEC], dg[VEC], g[VEC];
+  bool act = e0 < M;
+  if (act) {
+    ldv(dxv, e0, M, dx);
+    ldv(dgv, e0, M, dg);
+    ldv(gv, e0, M, g);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) dx[i] = dg[i] = g[i] = 0.f;
+  }
+  int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+  bool lead = (threadIdx.x & 63) == 0;
+  for (int j = 0; j < k; ++j) {
+    float u[VEC], v[VEC];
+    float sa = 0.f, sc = 0.f, sb = 0.f;
+    if (act) {
+      ldv(U + (int64_t)j * M, e0, M, u);
+      ldv(V + (int64_t)j * M, e0, M, v);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        sa = fmaf(dx[i], u[i], sa);
+        sc = fmaf(v[i], dg[i], sc);
+        sb = fmaf(v[i], g[i], sb);
+      }
+    }
+    sa = wave_sum(sa);
+    sc = wave_sum(sc);
+    sb = wave_sum(sb);
+    if (lead) {
+      part[((int64_t)0 * thr + j) * npart + w] = sa;
+      part[((int64_t)1 * thr + j) * npart + w] = sc;
+      part[((int64_t)2 * thr + j) * npart + w] = sb;
+    }
+  }
+}
+
+// coef[c][j] = sum of partials; grid = (k, 3)
+__global__ __launch_bounds__(TB) void k_reduce(const Status* __restrict__ st, const float* __restrict__ part, int npart,
+                                               int thr, float* __restrict__ coef) {
+  __shared__ double sh[TB];
+  if (st->done) return;
+  int j = blockIdx.x, c = blockIdx.y;
+  double s = block_sum_partials(part + ((int64_t)c * thr + j) * npart, npart, sh);
+  if (threadIdx.x == 0) coef[c * thr + j] = (float)s;
+}
+
+// axpy pass.  Writes vT (NaN->0) to V[k], D1 to U[k] (unscaled), D2 to upd, partials of vT.dg, vT.g
+__global__ __launch_bounds__(TB) void k_axpy(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
+                                             float* __restrict__ V, float* __restrict__ upd /* in: dx, out: D2 */,
+                                             const float* __restrict__ dgv, const float* __restrict__ gv,
+                                             const float* __restrict__ coef, int thr, float* __restrict__ part, int npart) {
+  if (st->done) return;
+  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  float p1 = 0.f, p2 = 0.f;
+  if (e0 < M) {
+    float av[VEC], a1[VEC], a2[VEC], dg[VEC], g[VEC];
+    ldv(upd, e0, M, av);
+    ldv(dgv, e0, M, dg);
+    ldv(gv, e0, M, g);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      a1[i] = av[i] + dg[i];
+      a2[i] = g[i];
+      av[i] = -av[i];
+    }
+    for (int j = 0; j < k; ++j) {
+      float u[VEC], v[VEC];
+      float ca = coef[j], cc = coef[thr + j], cb = coef[2 * thr + j];
+      ldv(U + (int64_t)j * M, e0, M, u);
+      ldv(V + (int64_t)j * M, e0, M, v);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        av[i] = fmaf(ca, v[i], av[i]);
+        a1[i] = fmaf(-cc, u[i], a1[i]);
+        a2[i] = fmaf(-cb, u[i], a2[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      p1 = fmaf(av[i], dg[i], p1);       // with the raw vT, as the reference divides before scrubbing
+      av[i] = (av[i] != av[i]) ? 0.f : av[i];
+      p2 = fmaf(av[i], g[i], p2);
+    }
+    stv(V + (int64_t)k * M, e0, M, av);
+    stv(U + (int64_t)k * M, e0, M, a1);
+    stv(upd, e0, M, a2);
+  }
+  p1 = wave_sum(p1);
+  p2 = wave_sum(p2);
+  if ((threadIdx.x & 63) == 0) {
+    int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+    part[w] = p1;
+    part[npart + w] = p2;
+  }
+}
+
+__global__ __launch_bounds__(TB) void k_reduce2(Status* st, const float* __restrict__ part, int npart) {
+  __shared__ double sh[TB];
+  if (st->done) return;
+  double s = block_sum_partials(part, npart, sh);
+  double b = block_sum_partials(part + npart, npart, sh);
+  if (threadIdx.x == 0) {
+    st->s = (double)(float)s;
+    st->beta = (double)(float)b;
+  }
+}
+
+// u = D1 / s (NaN -> 0) -> U[k] ;  update = D2 - u * beta
+__global__ __launch_bounds__(TB) void k_final(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
+                                              float* __restrict__ upd) {
+  if (st->done) return;
+  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  if (e0 >= M) return;
+  float s = (float)st->s, beta = (float)st->beta;
+  float u[VEC], d2[VEC];
+  float* Uk = U + (int64_t)k * M;
+  ldv(Uk, e0, M, u);
+  ldv(upd, e0, M, d2);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    float q = u[i] / s;
+    q = (q != q) ? 0.f : q;
+    u[i] = q;
+    d2[i] = fmaf(-q, beta, d2[i]);
+  }
+  stv(Uk, e0, M, u);
+  stv(upd, e0, M, d2);
+}
+
+__global__ __launch_bounds__(TB) void k_copy_sel(int64_t M, const float* __restrict__ xb, const int32_t* __restrict__ sel,
+                                                 int fixed, float* __restrict__ dst) {
+  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  if (e0 >= M) return;
+  int idx = sel ? *sel : fixed;
+  float a[VEC];
+  ldv(xb + (int64_t)idx * M, e0, M, a);
+  stv(dst, e0, M, a);
+}
+
+// ------------------------------------------------------------------------------------------ host
+// f kernels with a device-selected input buffer (fgnn.hip)
+int psignn_f_forward_sel(const psignn_plan_t* p, const float* W, int nl, const float* hbase, const int32_t* d_sel,
+                         int64_t stride, const float* h0, const float* prb, const float* nrm, float* out, float* work,
+                         hipStream_t st);
+
+static int broyden_alloc(psignn_broyden* s) {
+  size_t M = (size_t)s->M, thr = (size_t)s->thr;
+  s->nblk = (int)cdiv(s->M, CHUNK);
+  s->npart = s->nblk * (TB / 64);
+  size_t nx = s->keep_trace ? thr + 2 : 3;
+  struct { void** p; size_t n; } allocs[] = {
+      {(void**)&s->U, thr * M * 4},   {(void**)&s->V, thr * M * 4},   {(void**)&s->xbuf, nx * M * 4},
+      {(void**)&s->gx, M * 4},        {(void**)&s->dg, M * 4},        {(void**)&s->upd, M * 4},
+      {(void**)&s->fx, M * 4},        {(void**)&s->part, 3 * thr * (size_t)s->npart * 4 + 16},
+      {(void**)&s->coef, 3 * thr * 4 + 16}, {(void**)&s->st, sizeof(Status)},
+      {(void**)&s->rel_trace, thr * 8 + 8}, {(void**)&s->abs_trace, thr * 8 + 8}};
+  for (auto& a : allocs) {
+    if (hipMalloc(a.p, a.n ? a.n : 16) != hipSuccess) {
+      psignn_set_error("broyden: hipMalloc of %zu bytes failed (U+V need 2*thr*N*d*4 bytes)", a.n);
+      return PSIGNN_ENOMEM;
+    }
+    s->bytes += a.n;
+  }
+  if (s->plan) {
+    size_t wf = (size_t)psignn_f_workspace_floats(s->plan) * 4;
+    if (hipMalloc((void**)&s->fwork, wf) != hipSuccess) {
+      psignn_set_error("broyden: hipMalloc of f workspace failed");
+      return PSIGNN_ENOMEM;
+    }
+    s->bytes += wf;
+  }
+  if (hipHostMalloc((void**)&s->h_st, sizeof(Status)) != hipSuccess) {
+    psignn_set_error("broyden: hipHostMalloc failed");
+    return PSIGNN_ENOMEM;
+  }
+  return 0;
+}
+
+extern "C" void psignn_broyden_destroy(psignn_broyden_t* s) {
+  if (!s) return;
+  void* ptrs[] = {s->U, s->V, s->xbuf, s->gx, s->dg, s->upd, s->fx, s->fwork, s->part, s->coef, s->st,
+                  s->rel_trace, s->abs_trace};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  if (s->h_st) (void)hipHostFree(s->h_st);
+  delete s;
+}
+
+extern "C" int psignn_broyden_create_n(psignn_broyden_t** out, int64_t n_elems, int seq_len, int threshold, int keep_trace) {
+  ARG_CHECK(out, "out is NULL");
+  *out = nullptr;
+  ARG_CHECK(n_elems > 0 && threshold > 0 && seq_len > 0, "bad sizes");
+  ARG_CHECK(cdiv(n_elems, CHUNK) * (TB / 64) < (int64_t)INT32_MAX, "vector too long");
+  psignn_broyden* s = new psignn_broyden();
+  s->M = n_elems;
+  s->seq_len = seq_len;
+  s->thr = threshold;
+  s->keep_trace = keep_trace;
+  int rc = broyden_alloc(s);
+  if (rc) {
+    psignn_broyden_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return PSIGNN_OK;
+}
+
+extern "C" int psignn_broyden_create(psignn_broyden_t** out, const psignn_plan_t* plan, int threshold, int keep_trace) {
+  ARG_CHECK(out, "out is NULL");
+  *out = nullptr;
+  ARG_CHECK(plan && threshold > 0, "bad arguments");
+  psignn_broyden* s = new psignn_broyden();
+  s->plan = plan;
+  s->M = plan->N * D;
+  s->seq_len = D;
+  s->thr = threshold;
+  s->keep_trace = keep_trace;
+  int rc = broyden_alloc(s);
+  if (rc) {
+    psignn_broyden_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return PSIGNN_OK;
+}
+
+extern "C" size_t psignn_broyden_bytes(const psignn_broyden_t* s) { return s ? s->bytes : 0; }
+
+static inline int sel_off_cur() { return offsetof(Status, cur) / 4; }
+static inline int sel_off_low() { return offsetof(Status, low) / 4; }
+static inline int sel_off_nxt() { return offsetof(Status, nxt) / 4; }
+
+// everything of one iteration after fx = f(x_next) is available; k = pairs stored so far
+static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st) {
+  unsigned g = (unsigned)s->nblk;
+  LAUNCH("k_resid", st, (k_resid<<<g, TB, 0, st>>>(s->M, s->st, s->xbuf, s->fx, s->gx, s->dg, s->part, s->npart)));
+  LAUNCH("k_check", st, (k_check<<<1, TB, 0, st>>>(s->st, s->part, s->npart, s->rel_trace, s->abs_trace, eps, s->thr, s->seq_len, s->keep_trace)));
+  if (k >= s->thr) return;  // the threshold stop has fired; no slot left for another pair
+  if (k > 0) {
+    LAUNCH("k_dots", st, (k_dots<<<g, TB, 0, st>>>(s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->npart, s->thr)));
+    LAUNCH("k_reduce", st, (k_reduce<<<dim3(k, 3), TB, 0, st>>>(s->st, s->part, s->npart, s->thr, s->coef)));
+  }
+  LAUNCH("k_axpy", st, (k_axpy<<<g, TB, 0, st>>>(s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->npart)));
+  LAUNCH("k_reduce2", st, (k_reduce2<<<1, TB, 0, st>>>(s->st, s->part, s->npart)));
+  LAUNCH("k_final", st, (k_final<<<g, TB, 0, st>>>(s->M, k, s->st, s->U, s->upd)));
+}
+
+static int read_status(psignn_broyden* s, hipStream_t st) {
+  HIP_TRY(hipMemcpyAsync(s->h_st, s->st, sizeof(Status), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return 0;
+}
+
+static int finish(psignn_broyden* s, float* d_result, psignn_solve_info_t* info, double* h_rel, double* h_abs,
+                  hipStream_t st) {
+  unsigned g = (unsigned)s->nblk;
+  if (d_result)
+    k_copy_sel<<<g, TB, 0, st>>>(s->M, s->xbuf, reinterpret_cast<const int32_t*>(s->st) + sel_off_low(), 0, d_result);
+  int rc = read_status(s, st);
+  if (rc) return rc;
+  const Status& h = *s->h_st;
+  if (info) {
+    info->nstep = h.lowest_step;
+    info->n_iter = h.n_iter;
+    info->prot_break = h.prot_break;
+    info->stop_reason = h.stop_reason;
+    info->lowest = h.lowest_rel;
+    info->lowest_abs = h.lowest_abs_at;
+  }
+  int n = h.n_iter;
+  if (h_rel && n > 0) HIP_TRY(hipMemcpy(h_rel, s->rel_trace, (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (h_abs && n > 0) HIP_TRY(hipMemcpy(h_abs, s->abs_trace, (size_t)n * 8, hipMemcpyDeviceToHost));
+  // pad to `threshold` entries with the lowest values, as the reference pads its lists (solver.py:195-197)
+  for (int i = n; i < s->thr; ++i) {
+    if (h_rel) h_rel[i] = h.lowest_rel;
+    if (h_abs) h_abs[i] = h.lowest_abs_at;
+  }
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+
+extern "C" int psignn_broyden_solve(psignn_broyden_t* s, const float* W, int nl, const float* h0, const float* prb,
+                                    const float* nrm, double eps, int poll_every, float* d_result,
+                                    psignn_solve_info_t* info, double* h_rel, double* h_abs, void* stream) {
+  ARG_CHECK(s && s->plan, "solver was not created from a mesh plan");
+  ARG_CHECK(W && h0 && prb, "NULL argument");
+  ARG_CHECK(!s->plan->mixed || nrm, "mixed plan needs unit normals");
+  hipStream_t st = (hipStream_t)stream;
+  if (poll_every <= 0) poll_every = 8;
+  unsigned g = (unsigned)s->nblk;
+  const int32_t* sel_nxt = reinterpret_cast<const int32_t*>(s->st) + sel_off_nxt();
+  k_init_status<<<4, TB, 0, st>>>(s->st, s->rel_trace, s->abs_trace, s->thr);
+  // gx0 = f(x0) - x0, update = gx0 (solver.py:131-136)
+  int rc = psignn_f_forward(s->plan, W, nl, h0, h0, prb, nrm, s->fx, s->fwork, st);
+  if (rc) return rc;
+  k_begin<<<g, TB, 0, st>>>(s->M, h0, s->fx, s->xbuf, s->gx, s->upd);
+  for (int it = 0; it < s->thr; ++it) {
+    LAUNCH("k_xnext", st, (k_xnext<<<g, TB, 0, st>>>(s->M, s->st, s->xbuf, s->upd, nullptr)));
+    rc = psignn_f_forward_sel(s->plan, W, nl, s->xbuf, sel_nxt, s->M, h0, prb, nrm, s->fx, s->fwork, st);
+    if (rc) return rc;
+    launch_update(s, it, eps, st);
+    if ((it + 1) % poll_every == 0 || it + 1 == s->thr) {
+      rc = read_status(s, st);
+      if (rc) return rc;
+      if (s->h_st->done) break;
+    }
+  }
+  return finish(s, d_result, info, h_rel, h_abs, st);
+}
+
+extern "C" int psignn_broyden_get_iterate(const psignn_broyden_t* s, int i, float* d_dst, void* stream) {
+  ARG_CHECK(s && d_dst, "NULL argument");
+  ARG_CHECK(s->keep_trace, "solver was created without keep_trace");
+  ARG_CHECK(i >= 0 && i <= s->thr, "iterate index out of range");
+  k_copy_sel<<<(unsigned)s->nblk, TB, 0, (hipStream_t)stream>>>(s->M, s->xbuf, nullptr, i, d_dst);
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+
+// ---- externally driven variant (user-supplied f) ------------------------------------------
+extern "C" int psignn_broyden_ext_begin(psignn_broyden_t* s, const float* d_x0, const float* d_fx0, void* stream) {
+  ARG_CHECK(s && d_x0 && d_fx0, "NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  k_init_status<<<4, TB, 0, st>>>(s->st, s->rel_trace, s->abs_trace, s->thr);
+  k_begin<<<(unsigned)s->nblk, TB, 0, st>>>(s->M, d_x0, d_fx0, s->xbuf, s->gx, s->upd);
+  s->ext_iter = 0;
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+extern "C" int psignn_broyden_ext_next_x(psignn_broyden_t* s, float* d_x_new, void* stream) {
+  ARG_CHECK(s && d_x_new, "NULL argument");
+  k_xnext<<<(unsigned)s->nblk, TB, 0, (hipStream_t)stream>>>(s->M, s->st, s->xbuf, s->upd, d_x_new);
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+extern "C" int psignn_broyden_ext_update(psignn_broyden_t* s, const float* d_fx_new, double eps, int* h_done, void* stream) {
+  ARG_CHECK(s && d_fx_new, "NULL argument");
+  ARG_CHECK(s->ext_iter < s->thr, "more updates than threshold");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(s->fx, d_fx_new, (size_t)s->M * 4, hipMemcpyDeviceToDevice, st));
+  launch_update(s, s->ext_iter, eps, st);
+  s->ext_iter++;
+  if (h_done) {
+    int rc = read_status(s, st);
+    if (rc) return rc;
+    *h_done = s->h_st->done;
+  }
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+extern "C" int psignn_broyden_ext_finish(psignn_broyden_t* s, float* d_result, psignn_solve_info_t* info,
+                                         double* h_rel, double* h_abs, void* stream) {
+  ARG_CHECK(s, "NULL argument");
+  return finish(s, d_result, info, h_rel, h_abs, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// Small MLP (Encoder / Decoder, model.py:370-392) and the residual SpMV (model.py:157-167)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TB) void k_mlp2(int64_t n, int din, int hid, int dout, const float* __restrict__ x,
+                                             const float* __restrict__ w1, const float* __restrict__ b1,
+                                             const float* __restrict__ w2, const float* __restrict__ b2,
+                                             float* __restrict__ out) {
+  int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
+  if (r >= n) return;
+  float xi[16], hv[16];
+  for (int i = 0; i < din; ++i) xi[i] = x[r * din + i];
+  for (int o = 0; o < hid; ++o) {
+    float s = b1[o];
+    for (int i = 0; i < din; ++i) s = fmaf(w1[o * din + i], xi[i], s);
+    hv[o] = fmaxf(s, 0.f);
+  }
+  for (int o = 0; o < dout; ++o) {
+    float s = b2[o];
+    for (int i = 0; i < hid; ++i) s = fmaf(w2[o * hid + i], hv[i], s);
+    out[r * dout + o] = s;
+  }
+}
+
+extern "C" int psignn_mlp2(const float* x, int64_t n, int din, int hid, int dout, const float* w1, const float* b1,
+                           const float* w2, const float* b2, float* out, void* stream) {
+  ARG_CHECK(x && w1 && b1 && w2 && b2 && out, "NULL argument");
+  ARG_CHECK(n >= 0 && din >= 1 && din <= 16 && hid >= 1 && hid <= 16 && dout >= 1 && dout <= 16, "bad sizes");
+  if (n == 0) return PSIGNN_OK;
+  k_mlp2<<<(unsigned)cdiv(n, TB), TB, 0, (hipStream_t)stream>>>(n, din, hid, dout, x, w1, b1, w2, b2, out);
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+
+__global__ __launch_bounds__(TB) void k_residual(int64_t N, const int32_t* __restrict__ ptr, const int32_t* __restrict__ col,
+                                                 const float* __restrict__ val, const float* __restrict__ u,
+                                                 const float* __restrict__ y, float* __restrict__ out) {
+  int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
+  if (r >= N) return;
+  float s = 0.f;
+  for (int32_t i = ptr[r]; i < ptr[r + 1]; ++i) s = fmaf(val[i], u[col[i]], s);
+  out[r] = s - y[r];
+}
+
+extern "C" int psignn_residual(const psignn_plan_t* p, const float* u, const float* y, float* out, void* stream) {
+  ARG_CHECK(p && u && y && out, "NULL argument");
+  k_residual<<<(unsigned)cdiv(p->N, TB), TB, 0, (hipStream_t)stream>>>(p->N, p->a_ptr, p->a_col, p->a_val, u, y, out);
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}

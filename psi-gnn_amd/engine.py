@@ -1,0 +1,318 @@
+"""Host-side handles of the HIP hot path: mesh plan, packed weights, f / JVP, device Broyden.
+
+Everything numerical happens in libpsignn_hip.so; this module only owns lifetimes, packs the
+reference ``state_dict`` into the flat weight buffer (layout: csrc/common.h ``WLayout``) and passes
+device pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+D = nat.D
+
+
+# ---------------------------------------------------------------------------------------------
+# weights
+# ---------------------------------------------------------------------------------------------
+def is_mixed_state_dict(sd) -> bool:
+    return any(k.startswith("deqdss.f.phi_neumann") for k in sd)
+
+
+def n_layers_of(sd) -> int:
+    return 1 + max(int(k.split(".")[3]) for k in sd if k.startswith("deqdss.f.update_list."))
+
+
+def pack_weights(sd, device=None) -> torch.Tensor:
+    """Flatten the ``deqdss.f.*`` tensors of a reference state_dict into the kernel layout.
+
+    Key layout of the reference: dirichlet/psignn/model.py:265-277 (mixed/psignn/model.py:198-214),
+    SURVEY §8b.  Order (csrc/common.h): shared{ln_gamma, ln_beta, alpha_w, alpha_b} padded to 64;
+    per layer phi_to{W1,b1,W2,b2} phi_from{..} update{U1,c1,U2,c2}; mixed tail phi_neumann, update_neumann.
+    """
+    mixed = is_mixed_state_dict(sd)
+    nl = n_layers_of(sd)
+    P = "deqdss.f."
+    g = lambda k: sd[P + k].detach().to("cpu", torch.float32).reshape(-1)
+    p = 3 if mixed else 2
+    if sd[P + "laynorm.weight"].numel() != D:
+        raise nat.NativeError(f"latent_dim {sd[P + 'laynorm.weight'].numel()} != {D}: the HIP kernels are built for d = {D}")
+    if sd[P + "alpha.0.weight"].numel() != 3 * D + p:
+        raise nat.NativeError("alpha gate width does not match the boundary-condition family")
+    shared = torch.cat([g("laynorm.weight"), g("laynorm.bias"), g("alpha.0.weight"), g("alpha.0.bias")])
+    parts = [torch.nn.functional.pad(shared, (0, 64 - shared.numel()))]
+    for l in range(nl):
+        for phi in ("phi_to_list", "phi_from_list"):
+            parts += [g(f"{phi}.{l}.mlp.mlp.0.weight"), g(f"{phi}.{l}.mlp.mlp.0.bias"),
+                      g(f"{phi}.{l}.mlp.mlp.2.weight"), g(f"{phi}.{l}.mlp.mlp.2.bias")]
+        parts += [g(f"update_list.{l}.mlp.0.weight"), g(f"update_list.{l}.mlp.0.bias"),
+                  g(f"update_list.{l}.mlp.2.weight"), g(f"update_list.{l}.mlp.2.bias")]
+    if mixed:
+        parts += [g("phi_neumann.mlp.mlp.0.weight"), g("phi_neumann.mlp.mlp.0.bias"),
+                  g("phi_neumann.mlp.mlp.2.weight"), g("phi_neumann.mlp.mlp.2.bias"),
+                  g("update_neumann.mlp.0.weight"), g("update_neumann.mlp.0.bias"),
+                  g("update_neumann.mlp.2.weight"), g("update_neumann.mlp.2.bias")]
+    flat = torch.cat(parts).contiguous()
+    return flat if device is None else flat.to(device)
+
+
+class PackedWeights:
+    def __init__(self, sd, device):
+        self.mixed = is_mixed_state_dict(sd)
+        self.n_layers = n_layers_of(sd)
+        self.flat = pack_weights(sd, device)
+        expect = nat.lib().psignn_weights_size(int(self.mixed), self.n_layers)
+        if self.flat.numel() != expect:
+            raise nat.NativeError(f"packed weight length {self.flat.numel()} != native layout {expect}")
+
+
+# ---------------------------------------------------------------------------------------------
+# mesh plan
+# ---------------------------------------------------------------------------------------------
+_EXPORT = {"csr_ptr": (0, np.int32), "csr_nbr": (1, np.int32), "csr_eid": (2, np.int32),
+           "csc_ptr": (3, np.int32), "csc_nbr": (4, np.int32), "csc_eid": (5, np.int32),
+           "node_flags": (6, np.uint8), "csr_attr": (7, np.float32), "csc_attr": (8, np.float32),
+           "a_ptr": (9, np.int32), "a_col": (10, np.int32), "a_val": (11, np.float32)}
+
+
+class MeshPlan:
+    """Iteration-invariant device data of one mesh (or a disjoint union).  See csrc/plan.hip."""
+
+    def __init__(self, batch):
+        ei = batch.edge_index
+        nat.require_cuda(ei, "batch.edge_index")
+        self.device = ei.device
+        N = int(batch.x.shape[0])
+        tags = batch.tags.to(torch.float32).contiguous()
+        if tags.dim() == 1:
+            tags = tags[:, None]
+        ea = batch.edge_attr.to(torch.float32).contiguous()
+        aij = getattr(batch, "a_ij", None)
+        aij = None if aij is None else aij.to(torch.float32).reshape(-1).contiguous()
+        eic = ei.to(torch.int64).contiguous()
+        if ea.shape[0] != eic.shape[1] or ea.shape[1] != 3:
+            raise nat.NativeError(f"edge_attr shape {tuple(ea.shape)} does not match edge_index {tuple(eic.shape)}")
+        if tags.shape[0] != N:
+            raise nat.NativeError("tags and x disagree on the node count")
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().psignn_plan_create(C.byref(h), N, eic.shape[1], nat.ptr(eic), nat.ptr(ea),
+                                                   nat.ptr(aij), nat.ptr(tags), tags.shape[1],
+                                                   nat.stream_ptr(self.device)), "psignn_plan_create")
+        self.handle = h
+        self._fin = weakref.finalize(self, nat.lib().psignn_plan_destroy, h)
+        self.N = N
+        self.E = int(eic.shape[1])
+        self.Ep = int(nat.lib().psignn_plan_num_nonself_edges(h))
+        self.mixed = tags.shape[1] == 3
+        self._work = None
+
+    def export(self, name):
+        which, dt = _EXPORT[name]
+        n = {"csr_ptr": self.N + 1, "csc_ptr": self.N + 1, "a_ptr": self.N + 1, "node_flags": self.N,
+             "csr_attr": 3 * self.Ep, "csc_attr": 3 * self.Ep, "a_col": self.E, "a_val": self.E}.get(name, self.Ep)
+        out = np.empty(n, dtype=dt)
+        nat.check(nat.lib().psignn_plan_export(self.handle, which, out.ctypes.data_as(C.c_void_p), out.nbytes),
+                  "psignn_plan_export")
+        return out
+
+    def workspace(self):
+        if self._work is None:
+            n = int(nat.lib().psignn_f_workspace_floats(self.handle))
+            self._work = torch.empty(n, dtype=torch.float32, device=self.device)
+        return self._work
+
+
+def plan_for(batch) -> MeshPlan:
+    """Plan cached on the batch object (rebuilt if edge_index/tags storage changed)."""
+    key = (batch.edge_index.data_ptr(), tuple(batch.edge_index.shape), batch.tags.data_ptr(),
+           batch.edge_attr.data_ptr(), str(batch.edge_index.device))
+    cached = getattr(batch, "_psignn_plan", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    plan = MeshPlan(batch)
+    try:
+        batch._psignn_plan = (key, plan)
+    except Exception:
+        pass
+    return plan
+
+
+def _f32c(t):
+    return t.to(torch.float32).contiguous()
+
+
+class FixedPointMap:
+    """``H -> f(H, H_init, batch)`` bound to a plan and packed weights.
+
+    Stands where the reference passes ``lambda H: self.f(H, H_init, batch)`` to the solver
+    (dirichlet/psignn/model.py:189, tests/model_psignn.py:226).  Being an object instead of a lambda lets
+    ``utilities.solver.broyden`` recognise it and run the whole root-find on the device.
+    """
+
+    def __init__(self, plan: MeshPlan, weights: PackedWeights, h_initial, prb_data, normals=None):
+        if plan.mixed != weights.mixed:
+            raise nat.NativeError("boundary-condition family of the weights and of the batch differ "
+                                  f"(weights mixed={weights.mixed}, batch mixed={plan.mixed})")
+        self.plan, self.weights = plan, weights
+        self.h0 = _f32c(h_initial)
+        self.prb = _f32c(prb_data)
+        self.nrm = None if normals is None else _f32c(normals)
+        if plan.mixed and self.nrm is None:
+            raise nat.NativeError("mixed problems need batch.unit_normal_vector")
+        exp_p = 3 if plan.mixed else 2
+        if self.prb.shape != (plan.N, exp_p) or self.h0.shape != (plan.N, D):
+            raise nat.NativeError(f"shape mismatch: prb_data {tuple(self.prb.shape)}, h_initial {tuple(self.h0.shape)}")
+
+    def __call__(self, H):
+        nat.require_cuda(H, "H")
+        Hc = _f32c(H)
+        if Hc.shape != (self.plan.N, D):
+            raise nat.NativeError(f"H has shape {tuple(Hc.shape)}, expected {(self.plan.N, D)}")
+        out = torch.empty_like(Hc)
+        with torch.cuda.device(Hc.device):
+            nat.check(nat.lib().psignn_f_forward(self.plan.handle, nat.ptr(self.weights.flat), self.weights.n_layers,
+                                                 nat.ptr(Hc), nat.ptr(self.h0), nat.ptr(self.prb), nat.ptr(self.nrm),
+                                                 nat.ptr(out), nat.ptr(self.plan.workspace()),
+                                                 nat.stream_ptr(Hc.device)), "psignn_f_forward")
+        return out
+
+    def jvp(self, H, V):
+        """Analytic J_f(H) V."""
+        Hc, Vc = _f32c(H), _f32c(V)
+        out = torch.empty_like(Hc)
+        with torch.cuda.device(Hc.device):
+            nat.check(nat.lib().psignn_f_jvp(self.plan.handle, nat.ptr(self.weights.flat), self.weights.n_layers,
+                                             nat.ptr(Hc), nat.ptr(self.prb), nat.ptr(self.nrm), nat.ptr(Vc),
+                                             nat.ptr(out), nat.ptr(self.plan.workspace()),
+                                             nat.stream_ptr(Hc.device)), "psignn_f_jvp")
+        return out
+
+    def phi(self, H, which: int, layer: int = 0):
+        """One aggregation: 0 Phi_to, 1 Phi_from, 2 Phi_neumann."""
+        Hc = _f32c(H)
+        out = torch.empty_like(Hc)
+        with torch.cuda.device(Hc.device):
+            nat.check(nat.lib().psignn_phi(self.plan.handle, nat.ptr(self.weights.flat), self.weights.n_layers,
+                                           layer, which, nat.ptr(Hc), nat.ptr(out), nat.ptr(self.plan.workspace()),
+                                           nat.stream_ptr(Hc.device)), "psignn_phi")
+        return out
+
+
+def mlp2(x, w1, b1, w2, b2):
+    """relu(x W1^T + b1) W2^T + b2 for the tiny encoder/decoder MLPs (model.py:370-392)."""
+    nat.require_cuda(x, "x")
+    xc = _f32c(x)
+    n, din = xc.shape
+    hid, dout = w1.shape[0], w2.shape[0]
+    out = torch.empty((n, dout), dtype=torch.float32, device=xc.device)
+    with torch.cuda.device(xc.device):
+        nat.check(nat.lib().psignn_mlp2(nat.ptr(xc), n, din, hid, dout, nat.ptr(_f32c(w1)), nat.ptr(_f32c(b1)),
+                                        nat.ptr(_f32c(w2)), nat.ptr(_f32c(b2)), nat.ptr(out),
+                                        nat.stream_ptr(xc.device)), "psignn_mlp2")
+    return out
+
+
+def residual(plan: MeshPlan, u, y):
+    """A u - y with A = COO(edge_index, a_ij) including the diagonal (model.py:157-167)."""
+    uc, yc = _f32c(u).reshape(-1), _f32c(y).reshape(-1)
+    out = torch.empty_like(uc)
+    with torch.cuda.device(uc.device):
+        nat.check(nat.lib().psignn_residual(plan.handle, nat.ptr(uc), nat.ptr(yc), nat.ptr(out),
+                                            nat.stream_ptr(uc.device)), "psignn_residual")
+    return out.reshape(-1, 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# device Broyden
+# ---------------------------------------------------------------------------------------------
+TRACE_BUDGET_BYTES = 8 << 30  # keep every iterate only while (thr+2)*N*d*4 stays under this
+
+
+class DeviceBroyden:
+    def __init__(self, plan=None, threshold=50, keep_trace=False, n_elems=None, seq_len=D, device=None):
+        h = C.c_void_p()
+        self.plan = plan
+        self.threshold = int(threshold)
+        self.keep_trace = bool(keep_trace)
+        self.device = plan.device if plan is not None else device
+        with torch.cuda.device(self.device):
+            if plan is not None:
+                nat.check(nat.lib().psignn_broyden_create(C.byref(h), plan.handle, self.threshold, int(keep_trace)),
+                          "psignn_broyden_create")
+                self.M = plan.N * D
+            else:
+                nat.check(nat.lib().psignn_broyden_create_n(C.byref(h), int(n_elems), int(seq_len), self.threshold,
+                                                            int(keep_trace)), "psignn_broyden_create_n")
+                self.M = int(n_elems)
+        self.handle = h
+        self._fin = weakref.finalize(self, nat.lib().psignn_broyden_destroy, h)
+
+    def close(self):
+        self._fin()
+
+    @property
+    def nbytes(self):
+        return int(nat.lib().psignn_broyden_bytes(self.handle))
+
+    def _collect(self, info, rel, abs_, shape, dev):
+        n_it = info.n_iter
+        out = {"nstep": int(info.nstep), "n_iter": int(n_it), "lowest": float(info.lowest),
+               "prot_break": bool(info.prot_break), "stop_reason": int(info.stop_reason)}
+        # reference pads both traces to threshold+1 entries with the lowest values (solver.py:195-197)
+        rel_l = list(rel[:n_it]) + [float(info.lowest)] * (self.threshold + 1 - n_it)
+        abs_l = list(abs_[:n_it]) + [float(info.lowest_abs)] * (self.threshold + 1 - n_it)
+        out["rel_trace"], out["abs_trace"] = rel_l, abs_l
+        return out
+
+    def solve(self, fmap: FixedPointMap, eps, poll_every=8):
+        result = torch.empty_like(fmap.h0)
+        info = nat.SolveInfo()
+        rel = (C.c_double * self.threshold)()
+        abs_ = (C.c_double * self.threshold)()
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().psignn_broyden_solve(
+                self.handle, nat.ptr(fmap.weights.flat), fmap.weights.n_layers, nat.ptr(fmap.h0), nat.ptr(fmap.prb),
+                nat.ptr(fmap.nrm), float(eps), int(poll_every), nat.ptr(result), C.byref(info), rel, abs_,
+                nat.stream_ptr(self.device)), "psignn_broyden_solve")
+        out = self._collect(info, rel, abs_, result.shape, result.device)
+        out["result"] = result
+        return out
+
+    def iterate(self, i, like):
+        dst = torch.empty_like(like)
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().psignn_broyden_get_iterate(self.handle, int(i), nat.ptr(dst),
+                                                           nat.stream_ptr(self.device)), "psignn_broyden_get_iterate")
+        return dst
+
+    def solve_callable(self, f, x0, eps):
+        """Generic f (any Python callable on device tensors): one f call per iteration from the host."""
+        x0c = _f32c(x0)
+        lib, sp = nat.lib(), nat.stream_ptr(self.device)
+        with torch.cuda.device(self.device):
+            fx = _f32c(f(x0c))
+            nat.check(lib.psignn_broyden_ext_begin(self.handle, nat.ptr(x0c), nat.ptr(fx), sp), "ext_begin")
+            done = C.c_int(0)
+            xn = torch.empty_like(x0c)
+            for _ in range(self.threshold):
+                nat.check(lib.psignn_broyden_ext_next_x(self.handle, nat.ptr(xn), sp), "ext_next_x")
+                fx = _f32c(f(xn.clone()))
+                nat.check(lib.psignn_broyden_ext_update(self.handle, nat.ptr(fx), float(eps), C.byref(done), sp),
+                          "ext_update")
+                if done.value:
+                    break
+            result = torch.empty_like(x0c)
+            info = nat.SolveInfo()
+            rel = (C.c_double * self.threshold)()
+            abs_ = (C.c_double * self.threshold)()
+            nat.check(lib.psignn_broyden_ext_finish(self.handle, nat.ptr(result), C.byref(info), rel, abs_, sp),
+                      "ext_finish")
+        out = self._collect(info, rel, abs_, result.shape, result.device)
+        out["result"] = result
+        return out

@@ -1,0 +1,270 @@
+"""PSI-GNN inference models with the reference's constructor, ``forward()`` and ``state_dict`` layout.
+
+Drop-in for ``tests/model_psignn.py`` (``ModelPSIGNN``, ``ModelPSIGNNIterative``),
+``dirichlet/psignn/model.py`` (``ModelDEQDSS``: ``forward`` diagnostics / ``inference`` /
+``iterative_inference``) and their mixed (Dirichlet + Neumann) counterparts
+``mixed/psignn/test/model_test.py`` / ``mixed/psignn/model.py``.
+
+* ``Model(config)`` takes the reference's config dict (``latent_dim, n_layers, solver, fw_tol, fw_thres,
+  bw_tol, bw_thres, path_logs``; ``hidden_dim`` ignored as in the reference).  An optional key
+  ``"bc"`` = ``"dirichlet"`` | ``"mixed"`` selects the family (the reference uses two copies of the file).
+* ``load_state_dict(ckpt["state_dict"])`` of a reference checkpoint works unchanged: parameter names
+  and shapes are identical.
+* ``batch`` is any object with the PyG ``Data`` attributes (see ``data/meshdata.py``), already on the GPU.
+
+The numerical work — encoder/decoder MLPs, the GNN block f, the Broyden root-find, the residual
+SpMV — runs in libpsignn_hip.so.  No torch_geometric / torch_sparse.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _native as nat
+from . import engine
+from .utilities import solver as _solver
+
+# ----------------------------------------------------------------------------------------------
+# parameter containers (names = the reference's module tree; arithmetic is NOT done by these)
+# ----------------------------------------------------------------------------------------------
+
+
+def initialize_weights_xavier(m, gain=1.0):  # model.py:310-314
+    if isinstance(m, nn.Linear):
+        nn.init.xavier_uniform_(m.weight, gain=gain)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+
+
+class MLP(nn.Module):
+    """Linear, ReLU, Linear (model.py:316-332).  Two-layer only, like every instance in the reference."""
+
+    def __init__(self, hidden_channels=None, activation=None):
+        super().__init__()
+        if len(hidden_channels) != 3:
+            raise nat.NativeError("the HIP path implements the reference's two-layer MLPs only")
+        a, b, c = hidden_channels
+        self.mlp = nn.Sequential(nn.Linear(a, b), nn.ReLU(), nn.Linear(b, c)).apply(initialize_weights_xavier)
+
+    def forward(self, x):
+        l0, l2 = self.mlp[0], self.mlp[2]
+        return engine.mlp2(x, l0.weight, l0.bias, l2.weight, l2.bias)
+
+
+class _Phi(nn.Module):
+    """Parameter holder of ``Phi_to`` / ``Phi_from`` (model.py:334-368)."""
+
+    def __init__(self, hidden_channels=None, activation=None):
+        super().__init__()
+        self.mlp = MLP(hidden_channels, activation)
+
+
+class Phi_to(_Phi):
+    pass
+
+
+class Phi_from(_Phi):
+    pass
+
+
+class Encoder(nn.Module):
+    def __init__(self, hidden_channels=None, activation=None):
+        super().__init__()
+        self.mlp = MLP(hidden_channels, activation)
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+class Decoder(Encoder):
+    pass
+
+
+class Autoencoder(nn.Module):  # model.py:394-406
+    def __init__(self, hidden_channels=None, activation=None):
+        super().__init__()
+        self.encoder = Encoder(hidden_channels, activation)
+        self.decoder = Decoder(list(reversed(hidden_channels)), activation)
+
+    def forward(self, x, sens):
+        if sens == "latent":
+            return self.encoder(self.decoder(x))
+        if sens == "physics":
+            return self.decoder(self.encoder(x))
+        print("Specify autoencoder direction")
+
+
+class Function(nn.Module):
+    """The GNN block f_theta (dirichlet: model.py:263-300; mixed: mixed/psignn/model.py:196-245)."""
+
+    def __init__(self, n_layers=None, latent_dim=None, edge_features_dim=None, second_member_dim=None,
+                 activation=None, mixed=False):
+        super().__init__()
+        if latent_dim != engine.D or edge_features_dim != 3:
+            raise nat.NativeError(f"HIP kernels are built for latent_dim={engine.D}, edge_features_dim=3")
+        self.n_layers, self.mixed = n_layers, mixed
+        d, p = latent_dim, second_member_dim
+        self.laynorm = nn.LayerNorm(d)
+        self.phi_to_list = nn.ModuleList([Phi_to([2 * d + 3, d, d], activation) for _ in range(n_layers)])
+        self.phi_from_list = nn.ModuleList([Phi_from([2 * d + 3, d, d], activation) for _ in range(n_layers)])
+        self.alpha = nn.Sequential(nn.Linear(3 * d + p, 1), nn.Sigmoid()).apply(initialize_weights_xavier)
+        self.update_list = nn.ModuleList([MLP([3 * d + p, d, d], activation) for _ in range(n_layers)])
+        if mixed:
+            self.phi_neumann = Phi_from([2 * d + 3, d, d], activation)
+            self.update_neumann = MLP([2 * d + p + 2, d, d], activation)
+        self._packed = None
+        self._packed_key = None
+
+    def packed(self, device) -> engine.PackedWeights:
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed_key != key:
+            sd = {"deqdss.f." + k: v for k, v in self.state_dict().items()}
+            self._packed = engine.PackedWeights(sd, device)
+            self._packed_key = key
+        return self._packed
+
+    def bind(self, h_initial, batch) -> engine.FixedPointMap:
+        """The map H -> f(H, h_initial, batch) as a device object the solvers understand."""
+        plan = engine.plan_for(batch)
+        nrm = getattr(batch, "unit_normal_vector", None) if self.mixed else None
+        return engine.FixedPointMap(plan, self.packed(h_initial.device), h_initial, batch.prb_data, nrm)
+
+    def forward(self, h, h_initial, batch):
+        return self.bind(h_initial, batch)(h)
+
+
+class DeepEquilibrium(nn.Module):
+    """Inference variant (tests/model_psignn.py:216-243): one solver call, returns the solver dict."""
+
+    def __init__(self, function=None, config_deq=None):
+        super().__init__()
+        self.f = function
+        self.config_deq = config_deq
+        self.path_logs = self.config_deq.get("path_logs")
+
+    def forward(self, H_init, batch):
+        return self.config_deq["solver"](self.f.bind(H_init, batch), H_init,
+                                         threshold=self.config_deq["fw_thres"], eps=self.config_deq["fw_tol"])
+
+    inference = forward  # dirichlet/psignn/model.py:245-253
+
+
+# ----------------------------------------------------------------------------------------------
+# models
+# ----------------------------------------------------------------------------------------------
+class _Base(nn.Module):
+    MIXED = False
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = dict(config)
+        bc = self.config.get("bc")
+        self.mixed = self.MIXED if bc is None else (bc == "mixed")
+        self.config.setdefault("solver", _solver.broyden)
+        for k, v in (("fw_tol", 1e-5), ("fw_thres", 300), ("bw_tol", 1e-8), ("bw_thres", 300), ("path_logs", None)):
+            self.config.setdefault(k, v)
+        d = self.config["latent_dim"]
+        self.autoencoder = Autoencoder(hidden_channels=[1, d, d], activation=nn.ReLU())
+        self.config_deq = {k: self.config[k] for k in ("solver", "fw_tol", "fw_thres", "bw_tol", "bw_thres", "path_logs")}
+        self.deqdss = DeepEquilibrium(
+            function=Function(n_layers=self.config["n_layers"], latent_dim=d, edge_features_dim=3,
+                              second_member_dim=3 if self.mixed else 2, activation=nn.ReLU(), mixed=self.mixed),
+            config_deq=self.config_deq)
+        self.mse_loss = nn.MSELoss()
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _dirichlet_index(self, batch):
+        t = batch.tags[:, 1] if self.mixed else batch.tags.reshape(batch.tags.shape[0], -1)[:, 0]
+        return torch.where(t == 1)[0]
+
+    def residual_loss(self, u, batch):
+        """mean((A u - y)^2), A incl. the diagonal (model.py:157-167)."""
+        r = engine.residual(engine.plan_for(batch), u, batch.y)
+        return torch.mean(r ** 2)
+
+    @torch.no_grad()
+    def _solve(self, batch):
+        nat.require_cuda(batch.x, "batch.x")
+        h_initial = self.autoencoder.encoder(batch.x)
+        out = self.deqdss(h_initial, batch)
+        return h_initial, out
+
+    @torch.no_grad()
+    def _diagnostics(self, u_final, h_final, batch, key_dir):
+        enc = self.autoencoder.encoder(u_final)
+        idx = self._dirichlet_index(batch)
+        return {
+            "residual_loss": self.residual_loss(u_final, batch),
+            "encoder_loss": self.mse_loss(enc, h_final),
+            "autoencoder_loss": self.mse_loss(self.autoencoder.decoder(enc), u_final),
+            "mse_loss": self.mse_loss(u_final, batch.sol),
+            key_dir: self.mse_loss(u_final[idx, :], batch.x[idx, :]),
+        }
+
+    @torch.no_grad()
+    def inference(self, batch):
+        """u_final only (dirichlet/psignn/model.py:99-107)."""
+        _, out = self._solve(batch)
+        return self.autoencoder.decoder(out["result"])
+
+    @torch.no_grad()
+    def _iterative(self, batch):
+        """tests/model_psignn.py:145-194 ≡ dirichlet/psignn/model.py:109-155."""
+        out_dic = {"sol_dic": [], "res_dic": [], "mse_dic": [], "bound_mse_dic": [], "inter_mse_dic": [], "nstep": []}
+        if self.mixed:
+            ib = torch.where(batch.tags[:, 1] == 1)[0]
+            ii = torch.where(batch.tags[:, 0] == 1)[0]
+        else:
+            ib = torch.where(batch.tags == 1)[0]
+            ii = torch.where(batch.tags == 0)[0]
+
+        def record(u):
+            out_dic["sol_dic"].append(u.cpu())
+            out_dic["res_dic"].append(self.residual_loss(u, batch).cpu().item())
+            out_dic["mse_dic"].append(torch.mean((u - batch.sol) ** 2).cpu().item())
+            out_dic["bound_mse_dic"].append(torch.mean((u[ib, :] - batch.sol[ib, :]) ** 2).cpu().item())
+            out_dic["inter_mse_dic"].append(torch.mean((u[ii, :] - batch.sol[ii, :]) ** 2).cpu().item())
+
+        record(batch.x)
+        _, out_fw = self._solve(batch)
+        for h_star in out_fw["xest_trace"]:
+            record(self.autoencoder.decoder(h_star))
+        out_dic["nstep"] = out_fw["nstep"]
+        return out_dic
+
+
+class ModelPSIGNN(_Base):
+    """tests/model_psignn.py:28-112: ``forward(batch) -> (u_final, loss_dic incl. 'nsteps')``."""
+
+    @torch.no_grad()
+    def forward(self, batch):
+        _, out = self._solve(batch)
+        h_final = out["result"]
+        u_final = self.autoencoder.decoder(h_final)
+        loss_dic = self._diagnostics(u_final, h_final, batch, "mse_dirichlet_loss")
+        loss_dic["nsteps"] = out["nstep"]
+        return u_final, loss_dic
+
+
+class ModelPSIGNNIterative(_Base):
+    """tests/model_psignn.py:114-206: per-iterate diagnostics dictionary."""
+
+    def forward(self, batch):
+        return self._iterative(batch)
+
+
+class ModelDEQDSS(_Base):
+    """Inference surface of dirichlet/psignn/model.py:28-167 (``forward`` diagnostics without the training-only
+    Jacobian regulariser / backward hook, ``inference``, ``iterative_inference``)."""
+
+    @torch.no_grad()
+    def forward(self, batch):
+        _, out = self._solve(batch)
+        h_final = out["result"]
+        u_final = self.autoencoder.decoder(h_final)
+        loss_dic = self._diagnostics(u_final, h_final, batch, "mse_dirichlet")
+        loss_dic["jacobian_loss"] = torch.zeros((), device=u_final.device)  # training-only term (model.py:207)
+        return u_final, loss_dic
+
+    def iterative_inference(self, batch):
+        return self._iterative(batch)

@@ -1,0 +1,176 @@
+"""Fixed-point solver library with the reference's signatures and return dictionaries.
+
+Mirror of ``dirichlet/psignn/utilities/solver.py`` (≡ ``mixed/psignn/utilities/solver.py``):
+
+    solver(f, x0, threshold=int, eps=float) -> dict(result, lowest, nstep, prot_break,
+                                                   abs_trace, rel_trace, xest_trace, eps, threshold)
+
+``f`` maps an (N, d) device tensor to an (N, d) device tensor.  The arithmetic runs in
+libpsignn_hip.so: when ``f`` is an ``engine.FixedPointMap`` (what the models pass) the whole
+Broyden root-find — f, norms, stop tests, low-rank updates — stays on the device and the host
+only polls a done flag; for any other callable the low-rank machinery is still native and
+``f`` is called once per iteration.  CPU tensors are rejected: there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _native as nat
+from ..engine import D, TRACE_BUDGET_BYTES, DeviceBroyden, FixedPointMap
+
+
+class _LazyTrace:
+    """``xest_trace`` of a device solve: list-like, iterates are copied out on demand."""
+
+    def __init__(self, solver, n_iter, like, x0, result, nstep):
+        self._s, self._n, self._like = solver, n_iter, like
+        self._x0, self._res, self._nstep = x0, result, nstep
+
+    def __len__(self):
+        return self._n + 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        if self._s.keep_trace:
+            return self._s.iterate(i, self._like)
+        if i == 0:
+            return self._x0
+        if i == self._nstep:
+            return self._res
+        raise RuntimeError("iterates were not kept (trace would exceed the memory budget); "
+                           "call broyden(..., keep_trace=True)")
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+def broyden(f, x0, threshold, eps=1e-3, stop_mode="rel", ls=False, name="unknown", keep_trace=None,
+            poll_every=8):
+    """Broyden's method on g(x) = f(x) - x  (reference: utilities/solver.py:116-207).
+
+    Same contract as the reference: ``result`` is the lowest-``rel`` iterate x (not f(x)), ``nstep`` its
+    index, ``rel = |f(x)-x| / (|f(x)| + 1e-9)``, stops on ``rel < eps``, the 30-step plateau rule, the
+    protective break (``rel > rel_0 * 1e3 * d``) or ``threshold`` iterations.
+    """
+    if stop_mode != "rel" or ls:
+        raise NotImplementedError("the reference only ever calls broyden with stop_mode='rel', ls=False")
+    nat.require_cuda(x0, "x0")
+    if x0.dim() != 2:
+        raise nat.NativeError(f"x0 must be (N, d), got {tuple(x0.shape)}")
+    M = x0.numel()
+    if keep_trace is None:
+        keep_trace = (threshold + 2) * M * 4 <= TRACE_BUDGET_BYTES
+    if isinstance(f, FixedPointMap):
+        solver = DeviceBroyden(plan=f.plan, threshold=threshold, keep_trace=keep_trace)
+        out = solver.solve(f, eps, poll_every=poll_every)
+        x_init = f.h0
+    else:
+        solver = DeviceBroyden(threshold=threshold, keep_trace=keep_trace, n_elems=M, seq_len=x0.shape[1],
+                               device=x0.device)
+        out = solver.solve_callable(f, x0, eps)
+        x_init = x0
+    res = out["result"].reshape(x0.shape)
+    trace = _LazyTrace(solver, out["n_iter"], res, x_init, res, out["nstep"])
+    return {"result": res, "lowest": out["lowest"], "nstep": out["nstep"], "prot_break": out["prot_break"],
+            "abs_trace": out["abs_trace"], "rel_trace": out["rel_trace"], "xest_trace": trace,
+            "eps": eps, "threshold": threshold, "n_iter": out["n_iter"], "stop_reason": out["stop_reason"]}
+
+
+def forward_iteration(f, z0, eps=1.e-5, threshold=50):
+    """Picard iteration (reference: utilities/solver.py:301-341): returns the last iterate."""
+    nat.require_cuda(z0, "z0")
+    z_est = [z0]
+    z_prev, z = z0, f(z0)
+    trace = {"abs": [], "rel": []}
+    ite = 0
+    a = torch.linalg.norm(z_prev - z)
+    r = a / torch.linalg.norm(z)
+    trace["abs"].append(a.detach())
+    trace["rel"].append(r.detach())
+    z_est.append(z)
+    while trace["rel"][-1] > eps and ite < threshold:
+        z_prev = z
+        z = f(z_prev)
+        ite += 1
+        a = torch.linalg.norm(z_prev - z)
+        r = a / torch.linalg.norm(z)
+        trace["abs"].append(a.detach())
+        trace["rel"].append(r.detach())
+        z_est.append(z)
+    return {"result": z, "lowest": trace["rel"][-1], "abs_trace": trace["abs"], "rel_trace": trace["rel"],
+            "xest_trace": z_est, "nstep": ite, "eps": eps, "threshold": threshold}
+
+
+def anderson(f, x0, m=2, lam=1e-4, threshold=50, eps=1e-3, stop_mode="rel", beta=1.0, **kwargs):
+    """Anderson acceleration (reference: utilities/solver.py:215-293; m=2, lam=1e-4, beta=1;
+    ``rel = |f(x)-x| / (1e-5 + |f(x)|)``)."""
+    nat.require_cuda(x0, "x0")
+    shape = x0.shape
+    n = x0.numel()
+    alt = "rel" if stop_mode == "abs" else "abs"
+    kw = dict(dtype=x0.dtype, device=x0.device)
+    X = torch.zeros(m, n, **kw)
+    Fm = torch.zeros(m, n, **kw)
+    X[0] = x0.reshape(-1)
+    Fm[0] = f(x0).reshape(-1)
+    X[1] = Fm[0]
+    Fm[1] = f(Fm[0].reshape(shape)).reshape(-1)
+    H = torch.zeros(m + 1, m + 1, **kw)
+    H[0, 1:] = H[1:, 0] = 1
+    y = torch.zeros(m + 1, 1, **kw)
+    y[0] = 1
+    trace = {"abs": [], "rel": []}
+    lowest = {"abs": 1e8, "rel": 1e8}
+    lowest_step = {"abs": 0, "rel": 0}
+    xest_trace = [x0]
+    lowest_x = None
+    for k in range(2, threshold):
+        nn = min(k, m)
+        G = Fm[:nn] - X[:nn]
+        H[1:nn + 1, 1:nn + 1] = G @ G.t() + lam * torch.eye(nn, **kw)
+        alpha = torch.linalg.solve(H[:nn + 1, :nn + 1], y[:nn + 1])[1:nn + 1, 0]
+        X[k % m] = beta * (alpha[None] @ Fm[:nn])[0] + (1 - beta) * (alpha[None] @ X[:nn])[0]
+        Fm[k % m] = f(X[k % m].reshape(shape)).reshape(-1)
+        gx = Fm[k % m] - X[k % m]
+        abs_diff = gx.norm().item()
+        rel_diff = abs_diff / (1e-5 + Fm[k % m].norm().item())
+        diff = {"abs": abs_diff, "rel": rel_diff}
+        trace["abs"].append(abs_diff)
+        trace["rel"].append(rel_diff)
+        for mode in ("rel", "abs"):
+            if diff[mode] < lowest[mode]:
+                if mode == stop_mode:
+                    lowest_x = X[k % m].reshape(shape).clone()
+                lowest[mode] = diff[mode]
+                lowest_step[mode] = k
+        xest_trace.append(lowest_x)
+        if trace[stop_mode][-1] < eps:
+            for _ in range(threshold - 1 - k):
+                trace[stop_mode].append(lowest[stop_mode])
+                trace[alt].append(lowest[alt])
+            break
+    return {"result": lowest_x, "lowest": lowest[stop_mode], "nstep": lowest_step[stop_mode], "prot_break": False,
+            "abs_trace": trace["abs"], "rel_trace": trace["rel"], "xest_trace": xest_trace,
+            "eps": eps, "threshold": threshold}
+
+
+def newton(f, z0, eps=1.e-5, threshold=50):
+    """Node-block-diagonal Newton wrapped in forward_iteration (reference: utilities/solver.py:349-366).
+
+    The reference builds the dense (N,d,N,d) Jacobian with autograd and keeps its per-node d x d blocks
+    (``einsum('bibj->bij')``).  Here the same blocks come from analytic JVPs: block column j of node n is
+    (J v)[n] for v = e_j on the nodes of one colour class of the mesh graph (no two adjacent nodes share a
+    colour, so the neighbours' contributions vanish) — O(N d^2) memory instead of O((N d)^2).
+    """
+    if not isinstance(f, FixedPointMap):
+        raise nat.NativeError("newton needs the analytic JVP of a FixedPointMap")
+    from .newton_blocks import block_newton_map
+    g = block_newton_map(f)
+    r = forward_iteration(g, z0, eps=eps, threshold=threshold)
+    return {"result": r["result"], "lowest": r["lowest"], "rel_trace": r["rel_trace"], "abs_trace": r["abs_trace"],
+            "xest_trace": r["xest_trace"], "nstep": r["nstep"], "eps": eps, "threshold": threshold}

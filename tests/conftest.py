@@ -1,0 +1,55 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pkg(name=""):
+    return importlib.import_module("psi-gnn_amd" + ("." + name if name else ""))
+
+
+def load_weights(kind):
+    w = np.load(os.path.join(GOLDEN, f"weights_{kind}.npz"))
+    return {k: torch.from_numpy(w[k]) for k in w.files}
+
+
+def load_case(name):
+    """(golden dict, MeshData built from the stored input tensors)."""
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    MeshData = pkg("data").MeshData
+    fields = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("in_")}
+    return g, MeshData(**fields)
+
+
+CASES = {
+    "original_dirichlet_s0": "dirichlet",
+    "original_dirichlet_s1": "dirichlet",
+    "hex13_dirichlet_s0": "dirichlet",
+    "hex13_mixed_s1": "mixed",
+    "hex26_dirichlet_s0": "dirichlet",
+}
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64).reshape(-1)
+    b = torch.as_tensor(b, dtype=torch.float64).reshape(-1)
+    return float((a.cpu() - b.cpu()).norm() / b.cpu().norm())
+
+
+@pytest.fixture(scope="session")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

@@ -1,0 +1,121 @@
+"""CPU: host-side logic and the C ABI surface (no compute calls — there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_weights, pkg
+
+
+def test_library_exports_every_declared_symbol():
+    nat = pkg("_native")
+    hdr = open(os.path.join(ROOT, "include", "psignn_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(psignn_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(nat.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    # the ctypes table binds exactly the declared functions
+    assert set(nat.SIGNATURES) == declared
+
+
+def test_pure_host_entry_points():
+    nat = pkg("_native")
+    lib = nat.lib()
+    assert lib.psignn_version() >= 100
+    assert lib.psignn_weights_size(0, 1) == 64 + 2 * 350 + (10 * 32 + 120)
+    assert lib.psignn_weights_size(1, 1) == 64 + 2 * 350 + (10 * 33 + 120) + 350 + (10 * 25 + 120)
+    assert lib.psignn_weights_size(0, 0) == -1
+    assert lib.psignn_plan_num_nodes(None) == -1
+
+
+def test_weight_packing_layout():
+    eng = pkg("engine")
+    sd = load_weights("dirichlet")
+    flat = eng.pack_weights(sd)
+    assert flat.numel() == 1204
+    P = "deqdss.f."
+    assert torch.equal(flat[0:10], sd[P + "laynorm.weight"])
+    assert torch.equal(flat[20:52], sd[P + "alpha.0.weight"].reshape(-1))
+    assert torch.equal(flat[64:64 + 230], sd[P + "phi_to_list.0.mlp.mlp.0.weight"].reshape(-1))
+    assert torch.equal(flat[64 + 350:64 + 350 + 230], sd[P + "phi_from_list.0.mlp.mlp.0.weight"].reshape(-1))
+    assert torch.equal(flat[64 + 700:64 + 700 + 320], sd[P + "update_list.0.mlp.0.weight"].reshape(-1))
+    sdm = load_weights("mixed")
+    flatm = eng.pack_weights(sdm)
+    assert flatm.numel() == 1934
+    assert torch.equal(flatm[-370:-120], sdm[P + "update_neumann.mlp.0.weight"].reshape(-1))
+    assert eng.is_mixed_state_dict(sdm) and not eng.is_mixed_state_dict(sd)
+
+
+@pytest.mark.parametrize("kind,mod", [("dirichlet", "model_psignn"), ("mixed", "mixed")])
+def test_reference_state_dict_loads(kind, mod):
+    m = pkg(mod)
+    net = m.ModelPSIGNN(dict(latent_dim=10, n_layers=1, fw_tol=1e-5, fw_thres=500))
+    sd = load_weights(kind)
+    assert set(net.state_dict()) == set(sd)
+    net.load_state_dict(sd, strict=True)
+    n_params = sum(p.numel() for p in net.parameters())
+    assert n_params == (1444 if kind == "dirichlet" else 2175)  # model_config.csv:88 / :96
+
+
+def test_no_cpu_fallback():
+    """CPU tensors are rejected loudly; nothing silently routes around the HIP library."""
+    nat = pkg("_native")
+    solver = pkg("utilities.solver")
+    with pytest.raises(nat.NativeError):
+        solver.broyden(lambda x: 0.5 * x, torch.zeros(4, 10), threshold=5, eps=1e-3)
+    data = pkg("data")
+    mesh = data.make_hex_problem(3, seed=0)
+    net = pkg("model_psignn").ModelPSIGNN(dict(latent_dim=10, n_layers=1))
+    with pytest.raises(nat.NativeError):
+        net(mesh)
+    src = open(os.path.join(ROOT, "psi-gnn_amd", "engine.py")).read() + open(os.path.join(ROOT, "psi-gnn_amd", "model_psignn.py")).read()
+    assert "oracle" not in src
+
+
+def test_hex_mesh_schema_and_sizes():
+    data = pkg("data")
+    for n, N in ((13, 547), (26, 2107)):
+        m = data.make_hex_problem(n, seed=0)
+        assert m.num_nodes == N == 3 * n * n + 3 * n + 1
+        assert int((m.tags == 1).sum()) == 6 * n
+        r, c = m.edge_index
+        assert bool(((r[1:] > r[:-1]) | ((r[1:] == r[:-1]) & (c[1:] > c[:-1]))).all())  # row-major, unique
+        assert int((r == c).sum()) == N  # full diagonal
+        bd = (m.tags[:, 0] == 1).nonzero()[:, 0]
+        assert bool(torch.isin(r, bd).logical_and(r != c).sum() == 0)  # Dirichlet rows are identity rows
+        A = torch.sparse_coo_tensor(m.edge_index, m.a_ij[:, 0].double(), (N, N))
+        assert float((torch.sparse.mm(A, m.sol.double()) - m.y.double()).abs().max()) < 1e-4
+    assert data.make_hex_problem(13, seed=0).edge_index.shape[1] == 3361
+    mm = data.make_hex_problem(13, seed=1, mixed=True)
+    assert mm.tags.shape == (547, 3) and bool((mm.tags.sum(1) == 1).all())
+    assert mm.tags.sum(0).tolist() == [469.0, 42.0, 36.0]
+    assert mm.prb_data.shape == (547, 3) and mm.unit_normal_vector.shape == (547, 2)
+    assert data.hex_n_for_nodes(1_000_000) == 577 and data.hex_n_for_nodes(100_000) == 183
+
+
+def test_collate_disjoint_union():
+    data = pkg("data")
+    a, b = data.make_hex_problem(3, seed=0), data.make_hex_problem(4, seed=1)
+    u = data.collate([a, b])
+    assert u.num_nodes == a.num_nodes + b.num_nodes
+    assert u.edge_index.shape[1] == a.num_edges + b.num_edges
+    assert int(u.edge_index[:, a.num_edges:].min()) == a.num_nodes
+    assert u.batch.tolist() == [0] * a.num_nodes + [1] * b.num_nodes
+    assert u.ptr.tolist() == [0, a.num_nodes, u.num_nodes]
+
+
+def test_plan_reference_numpy():
+    """The numpy statement of the plan's canonical CSR/CSC order used by the GPU bit-exact test."""
+    from plan_ref import plan_reference
+    ei = np.array([[0, 1, 2, 2, 1, 0, 2], [1, 0, 2, 0, 2, 0, 1]])
+    ref = plan_reference(ei, 3)
+    assert ref["csr_ptr"].tolist() == [0, 1, 3, 5]
+    assert ref["csr_nbr"].tolist() == [1, 0, 2, 0, 1]
+    assert ref["csr_eid"].tolist() == [0, 1, 4, 3, 6]
+    assert ref["csc_ptr"].tolist() == [0, 2, 4, 5]
+    assert ref["csc_nbr"].tolist() == [1, 2, 0, 2, 1]
