@@ -56,12 +56,25 @@ typedef struct psignn_plan psignn_plan_t;
 
 /* tags: (N, tags_cols) float32 with tags_cols = 1 (dirichlet: tags[:,0]==1 -> Dirichlet) or
  * 3 (mixed one-hot [interior, dirichlet, neumann]).  d_a_ij may be NULL (no residual SpMV).
- * Synchronous: returns after the plan is complete (one device->host read of the edge count). */
+ * d_pos: (N,2) node coordinates (batch.pos) or NULL; used only to renumber nodes into spatially
+ * compact tiles (speed, never results).  tile_target: nodes per tile (0 = default, < 0 = no tiles).
+ * Synchronous: returns after the plan is complete (a few small device->host reads). */
 int psignn_plan_create(psignn_plan_t** out, int64_t n_nodes, int64_t n_edges,
                        const int64_t* d_edge_index /* (2, E) */, const float* d_edge_attr /* (E,3) */,
                        const float* d_a_ij /* (E) or NULL */, const float* d_tags, int tags_cols,
-                       void* stream);
+                       const float* d_pos, int tile_target, void* stream);
 void psignn_plan_destroy(psignn_plan_t* plan);
+
+/* Tile structures: when present, solver state is kept in "plan order"
+ * (nodes renumbered tile by tile).  psignn_plan_permute moves (N, cols) float rows between the
+ * caller's numbering and plan order: to_plan = 1: dst[new] = src[perm[new]]; 0: dst[old] = src[inv[old]].
+ * On an untiled plan it is a copy. */
+int psignn_plan_is_tiled(const psignn_plan_t* plan);
+int64_t psignn_plan_num_tiles(const psignn_plan_t* plan);
+int64_t psignn_plan_ell_rows(const psignn_plan_t* plan);      /* 64-lane ELL slot-rows (padding included) */
+int psignn_plan_max_tile_rows(const psignn_plan_t* plan);     /* max tile + halo rows staged in LDS */
+int psignn_plan_permute(const psignn_plan_t* plan, const float* d_src, int cols, float* d_dst, int to_plan,
+                        void* stream);
 
 int64_t psignn_plan_num_nodes(const psignn_plan_t* plan);
 int64_t psignn_plan_num_edges(const psignn_plan_t* plan);          /* E, as given */
@@ -70,7 +83,9 @@ int64_t psignn_plan_num_nonself_edges(const psignn_plan_t* plan);  /* E' */
 /* Copy one plan array to host memory (tests: bit-exact comparison with the numpy oracle).
  * which: 0 csr_ptr(N+1 i32) 1 csr_nbr(E' i32) 2 csr_eid(E' i32) 3 csc_ptr 4 csc_nbr 5 csc_eid
  *        6 node_flags (N u8) 7 csr_attr (E'*3 f32) 8 csc_attr 9 a_ptr (N+1 i32) 10 a_col (E i32)
- *        11 a_val (E f32).  Synchronous. */
+ *        11 a_val (E f32); tiled plans only: 12 perm (N i32, perm[new] = old) 13 tile_ptr (T+1 i32)
+ *        14 halo_cnt (T i32) 15 halo (T*512 i32) 16 slice_off (S+1 i32) 17 slice_deg (S*2 u8)
+ *        18 ell_idx (rows*64 u16) 19 ell_attr (rows*3*64 f32) 20 tile_slice (T+1 i32).  Synchronous. */
 int psignn_plan_export(const psignn_plan_t* plan, int which, void* h_dst, size_t dst_bytes);
 
 /* ------------------------------------------------------------------------------------------
@@ -93,6 +108,12 @@ int64_t psignn_f_workspace_floats(const psignn_plan_t* plan);
 int psignn_f_forward(const psignn_plan_t* plan, const float* d_weights, int n_layers,
                      const float* d_h, const float* d_h_initial, const float* d_prb,
                      const float* d_normals, float* d_out, float* d_work, void* stream);
+
+/* Same, with h, h_initial, prb, normals and out already in plan order (no permutation passes):
+ * the form iterative callers use after one psignn_plan_permute per tensor. */
+int psignn_f_forward_p(const psignn_plan_t* plan, const float* d_weights, int n_layers,
+                       const float* d_h, const float* d_h_initial, const float* d_prb,
+                       const float* d_normals, float* d_out, float* d_work, void* stream);
 
 /* Single message-passing aggregation (tests / diagnostics): which = 0 Phi_to, 1 Phi_from,
  * 2 Phi_neumann (mixed).  replaces: Phi_to.forward / Phi_from.forward (model.py:334-368). */

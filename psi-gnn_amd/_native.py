@@ -34,7 +34,13 @@ _INT = C.c_int
 SIGNATURES = {
     "psignn_last_error": (C.c_char_p, []),
     "psignn_version": (_INT, []),
-    "psignn_plan_create": (_INT, [C.POINTER(_P), _I64, _I64, _P, _P, _P, _P, _INT, _P]),
+    "psignn_plan_create": (_INT, [C.POINTER(_P), _I64, _I64, _P, _P, _P, _P, _INT, _P, _INT, _P]),
+    "psignn_plan_is_tiled": (_INT, [_P]),
+    "psignn_plan_num_tiles": (_I64, [_P]),
+    "psignn_plan_ell_rows": (_I64, [_P]),
+    "psignn_plan_max_tile_rows": (_INT, [_P]),
+    "psignn_plan_permute": (_INT, [_P, _P, _INT, _P, _INT, _P]),
+    "psignn_f_forward_p": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P]),
     "psignn_plan_destroy": (None, [_P]),
     "psignn_plan_num_nodes": (_I64, [_P]),
     "psignn_plan_num_edges": (_I64, [_P]),

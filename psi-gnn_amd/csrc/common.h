@@ -72,7 +72,32 @@ struct psignn_plan {
   int32_t *a_ptr = nullptr, *a_col = nullptr;      // full CSR of A (self loops included)
   float* a_val = nullptr;
   int max_deg = 0;
+
+  // ---- tile structures (tiles.hip); valid when tiled != 0 -------------------------------------
+  // Nodes are renumbered so that a tile (<= TILE_MAX consecutive new ids) is spatially compact; a tile's
+  // out-of-tile neighbours form its halo.  Solver state lives in the new ("plan") order.
+  int tiled = 0;
+  int64_t n_tiles = 0, n_slices = 0, ell_rows = 0;
+  int max_rows = 0;                            // max over tiles of n_t + n_halo (LDS rows)
+  int32_t *perm = nullptr, *inv = nullptr;     // perm[new] = old ; inv[old] = new
+  int32_t* tile_ptr = nullptr;                 // (n_tiles+1) new-id ranges
+  int32_t* tile_slice = nullptr;               // (n_tiles+1) first 64-lane slice of each tile
+  int32_t *halo = nullptr, *halo_cnt = nullptr;  // (n_tiles, HALO_CAP) sorted new ids ; (n_tiles)
+  int32_t* slice_off = nullptr;                // (n_slices+1) first ELL slot-row of each slice
+  uint8_t* slice_deg = nullptr;                // (n_slices, 2) max in-degree, max out-degree of the slice
+  uint16_t* ell_idx = nullptr;                 // (ell_rows, 64) LDS row of the neighbour, 0xFFFF = empty
+  float* ell_attr = nullptr;                   // (ell_rows, 3, 64) edge_attr, SoA per slot-row
+  uint8_t* flags_p = nullptr;                  // node flags in plan order
+  float cell_size = 0.f, xmin = 0.f, ymin = 0.f;
+  int nx = 0, ny = 0;
 };
+
+#define TILE_MAX 256      // nodes per tile = threads per block of the tile kernel
+#define HALO_CAP 512      // halo entries stored per tile
+#define ELL_EMPTY 0xFFFFu
+
+int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipStream_t st);
+void psignn_tiles_free(psignn_plan* p);
 
 // ---------------------------------------------------------------------------------------------
 // Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline numbers).

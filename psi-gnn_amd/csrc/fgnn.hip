@@ -12,36 +12,7 @@
 // bitwise reproducible — then gate, update MLP, LayerNorm and Dirichlet/Neumann row handling.
 #include "common.h"
 
-struct F2 {
-  float x, y;
-};
-
-__device__ __forceinline__ void load10(const float* __restrict__ p, float* __restrict__ r) {
-  const float2* q = reinterpret_cast<const float2*>(p);
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    float2 t = q[i];
-    r[2 * i] = t.x;
-    r[2 * i + 1] = t.y;
-  }
-}
-__device__ __forceinline__ void store10(float* __restrict__ p, const float* __restrict__ r) {
-  float2* q = reinterpret_cast<float2*>(p);
-#pragma unroll
-  for (int i = 0; i < 5; ++i) q[i] = make_float2(r[2 * i], r[2 * i + 1]);
-}
-
-// out[o] (+)= sum_k W[o*ld + off + k] * x[k],  o < 10, k < K   (W wave-uniform -> scalar loads)
-template <int K, bool ACC>
-__device__ __forceinline__ void matvec10(const float* __restrict__ W, int ld, int off, const float* x, float* out) {
-#pragma unroll
-  for (int o = 0; o < D; ++o) {
-    float s = ACC ? out[o] : 0.f;
-#pragma unroll
-    for (int k = 0; k < K; ++k) s = fmaf(W[o * ld + off + k], x[k], s);
-    out[o] = s;
-  }
-}
+#include "fgnn_common.h"
 
 // ------------------------------------------------------------------------------------------
 // Kernel 1: neighbour-side projections.  NPH = number of Phi modules (2 dirichlet, 3 mixed).
@@ -381,9 +352,50 @@ int psignn_f_forward_sel(const psignn_plan_t* p, const float* W, int nl, const f
   return PSIGNN_OK;
 }
 
+int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const float* h, const int32_t* hsel,
+                          int64_t hstride, const float* h0, const float* prb, const float* nrm, float* out,
+                          float* work, hipStream_t st);
+
+// Evaluation with every node tensor in PLAN order (the solver's internal numbering): tiled kernel when the
+// plan has tile structures, global-gather kernels otherwise (then plan order == caller order).
+int psignn_f_eval_p(const psignn_plan_t* p, const float* W, int nl, const float* h, const int32_t* hsel,
+                    int64_t hstride, const float* h0, const float* prb, const float* nrm, float* out, float* work,
+                    hipStream_t st) {
+  ARG_CHECK(p != nullptr, "plan is NULL");
+  if (p->tiled) return psignn_f_tile_forward(p, W, nl, h, hsel, hstride, h0, prb, nrm, out, work, st);
+  return psignn_f_forward_sel(p, W, nl, h, hsel, hstride, h0, prb, nrm, out, work, st);
+}
+
+extern "C" int psignn_f_forward_p(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* h0,
+                                  const float* prb, const float* nrm, float* out, float* work, void* stream) {
+  ARG_CHECK(out != h, "out must not alias h");
+  return psignn_f_eval_p(p, W, nl, h, nullptr, 0, h0, prb, nrm, out, work, (hipStream_t)stream);
+}
+
 extern "C" int psignn_f_forward(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* h0,
                                 const float* prb, const float* nrm, float* out, float* work, void* stream) {
-  return psignn_f_forward_sel(p, W, nl, h, nullptr, 0, h0, prb, nrm, out, work, (hipStream_t)stream);
+  ARG_CHECK(p != nullptr, "plan is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  if (!p->tiled) return psignn_f_forward_sel(p, W, nl, h, nullptr, 0, h0, prb, nrm, out, work, st);
+  // caller numbering -> plan order -> tile kernel -> caller numbering (convenience path; callers that
+  // iterate should permute once with psignn_plan_permute and use psignn_f_forward_p)
+  int rc = f_args_ok(p, W, nl, h, prb, nrm, out, work);
+  if (rc) return rc;
+  ARG_CHECK(h0 != nullptr, "h_initial is NULL");
+  const int64_t N = p->N;
+  const int P = p->mixed ? 3 : 2;
+  float* hp = work;
+  float* h0p = hp + N * D;
+  float* outp = h0p + N * D;
+  float* prbp = outp + N * D;
+  float* nrmp = prbp + N * 3;
+  float* rest = nrmp + N * 2;
+  if ((rc = psignn_plan_permute(p, h, D, hp, 1, stream))) return rc;
+  if ((rc = psignn_plan_permute(p, h0, D, h0p, 1, stream))) return rc;
+  if ((rc = psignn_plan_permute(p, prb, P, prbp, 1, stream))) return rc;
+  if (p->mixed && (rc = psignn_plan_permute(p, nrm, 2, nrmp, 1, stream))) return rc;
+  if ((rc = psignn_f_tile_forward(p, W, nl, hp, nullptr, 0, h0p, prbp, p->mixed ? nrmp : nullptr, outp, rest, st))) return rc;
+  return psignn_plan_permute(p, outp, D, out, 0, stream);
 }
 
 extern "C" int psignn_phi(const psignn_plan_t* p, const float* W, int nl, int layer, int which, const float* h,

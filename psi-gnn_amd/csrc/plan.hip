@@ -233,7 +233,7 @@ __global__ void k_flags(int64_t N, const float* __restrict__ tags, int cols, uin
 }
 
 // ------------------------------------------------------------------ host
-static int exclusive_scan(const int32_t* in, int64_t n, int32_t* out, int32_t* bsum, hipStream_t st) {
+int psignn_exclusive_scan(const int32_t* in, int64_t n, int32_t* out, int32_t* bsum, hipStream_t st) {
   int64_t nb = cdiv(n, SCAN_ITEMS);
   k_scan_block_sums<<<dim3((unsigned)nb), 256, 0, st>>>(in, n, bsum);
   k_scan_sums<<<1, 256, 0, st>>>(bsum, nb);
@@ -255,12 +255,13 @@ extern "C" void psignn_plan_destroy(psignn_plan_t* p) {
                   p->csc_attr, p->flags,   p->a_ptr,   p->a_col,   p->a_val};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
+  psignn_tiles_free(p);
   delete p;
 }
 
 extern "C" int psignn_plan_create(psignn_plan_t** out, int64_t N, int64_t E, const int64_t* d_ei,
                                   const float* d_attr, const float* d_aij, const float* d_tags, int tags_cols,
-                                  void* stream) {
+                                  const float* d_pos, int tile_target, void* stream) {
   ARG_CHECK(out != nullptr, "out is NULL");
   *out = nullptr;
   ARG_CHECK(N > 0 && N < (int64_t)INT32_MAX, "n_nodes out of range");
@@ -300,9 +301,9 @@ extern "C" int psignn_plan_create(psignn_plan_t** out, int64_t N, int64_t E, con
     return fail(PSIGNN_EHIP);
   }
   if (E > 0) k_count_edges<<<dim3((unsigned)cdiv(E, TB)), TB, 0, st>>>(E, N, d_ei, deg, deg + N, deg + 2 * N, misc);
-  TRY(exclusive_scan(deg, N, p->csr_ptr, bsum, st));
-  TRY(exclusive_scan(deg + N, N, p->csc_ptr, bsum, st));
-  TRY(exclusive_scan(deg + 2 * N, N, p->a_ptr, bsum, st));
+  TRY(psignn_exclusive_scan(deg, N, p->csr_ptr, bsum, st));
+  TRY(psignn_exclusive_scan(deg + N, N, p->csc_ptr, bsum, st));
+  TRY(psignn_exclusive_scan(deg + 2 * N, N, p->a_ptr, bsum, st));
   k_flags<<<dim3((unsigned)cdiv(N, TB)), TB, 0, st>>>(N, d_tags, tags_cols, p->flags);
   int32_t h_misc[2] = {0, 0}, h_ep = 0, h_ea = 0;
   if (hipMemcpyAsync(h_misc, misc, sizeof(h_misc), hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -361,9 +362,21 @@ extern "C" int psignn_plan_create(psignn_plan_t** out, int64_t N, int64_t E, con
   (void)hipFree(a_eid);
   (void)hipFree(misc);
 #undef TRY
+  if (tile_target >= 0 && Ep > 0) {
+    rc = psignn_tiles_build(p, d_pos, tile_target, st);
+    if (rc) {
+      psignn_plan_destroy(p);
+      return rc;
+    }
+  }
   *out = p;
   return PSIGNN_OK;
 }
+
+extern "C" int psignn_plan_is_tiled(const psignn_plan_t* p) { return p ? p->tiled : 0; }
+extern "C" int64_t psignn_plan_num_tiles(const psignn_plan_t* p) { return p && p->tiled ? p->n_tiles : 0; }
+extern "C" int64_t psignn_plan_ell_rows(const psignn_plan_t* p) { return p && p->tiled ? p->ell_rows : 0; }
+extern "C" int psignn_plan_max_tile_rows(const psignn_plan_t* p) { return p && p->tiled ? p->max_rows : 0; }
 
 extern "C" int64_t psignn_plan_num_nodes(const psignn_plan_t* p) { return p ? p->N : -1; }
 extern "C" int64_t psignn_plan_num_edges(const psignn_plan_t* p) { return p ? p->E : -1; }
@@ -387,6 +400,15 @@ extern "C" int psignn_plan_export(const psignn_plan_t* p, int which, void* h_dst
     case 9: src = p->a_ptr; bytes = (N + 1) * 4; break;
     case 10: src = p->a_col; bytes = E * 4; break;
     case 11: src = p->a_val; bytes = E * 4; break;
+    case 12: src = p->perm; bytes = p->tiled ? N * 4 : 0; break;
+    case 13: src = p->tile_ptr; bytes = p->tiled ? (size_t)(p->n_tiles + 1) * 4 : 0; break;
+    case 14: src = p->halo_cnt; bytes = p->tiled ? (size_t)p->n_tiles * 4 : 0; break;
+    case 15: src = p->halo; bytes = p->tiled ? (size_t)p->n_tiles * HALO_CAP * 4 : 0; break;
+    case 16: src = p->slice_off; bytes = p->tiled ? (size_t)(p->n_slices + 1) * 4 : 0; break;
+    case 17: src = p->slice_deg; bytes = p->tiled ? (size_t)p->n_slices * 2 : 0; break;
+    case 18: src = p->ell_idx; bytes = p->tiled ? (size_t)p->ell_rows * 64 * 2 : 0; break;
+    case 19: src = p->ell_attr; bytes = p->tiled ? (size_t)p->ell_rows * 3 * 64 * 4 : 0; break;
+    case 20: src = p->tile_slice; bytes = p->tiled ? (size_t)(p->n_tiles + 1) * 4 : 0; break;
     default: ARG_CHECK(false, "unknown array id");
   }
   ARG_CHECK(dst_bytes >= bytes, "destination too small");

@@ -46,6 +46,7 @@ struct psignn_broyden {
   float *U = nullptr, *V = nullptr;
   float* xbuf = nullptr;    // (thr+2, M) with trace, else (3, M)
   float *gx = nullptr, *dg = nullptr, *upd = nullptr, *fx = nullptr, *fwork = nullptr;
+  float *h0p = nullptr, *prbp = nullptr, *nrmp = nullptr;  // plan-order copies of h_initial, prb_data, normals
   float* part = nullptr;    // (3, thr, npart) dot partials; reused for the norm / s,beta partials
   float* coef = nullptr;    // (3, thr)
   Status* st = nullptr;     // device
@@ -393,9 +394,9 @@ __global__ __launch_bounds__(TB) void k_copy_sel(int64_t M, const float* __restr
 
 // ------------------------------------------------------------------------------------------ host
 // f kernels with a device-selected input buffer (fgnn.hip)
-int psignn_f_forward_sel(const psignn_plan_t* p, const float* W, int nl, const float* hbase, const int32_t* d_sel,
-                         int64_t stride, const float* h0, const float* prb, const float* nrm, float* out, float* work,
-                         hipStream_t st);
+int psignn_f_eval_p(const psignn_plan_t* p, const float* W, int nl, const float* hbase, const int32_t* d_sel,
+                    int64_t stride, const float* h0, const float* prb, const float* nrm, float* out, float* work,
+                    hipStream_t st);
 
 static int broyden_alloc(psignn_broyden* s) {
   size_t M = (size_t)s->M, thr = (size_t)s->thr;
@@ -422,6 +423,13 @@ static int broyden_alloc(psignn_broyden* s) {
       return PSIGNN_ENOMEM;
     }
     s->bytes += wf;
+    size_t N = (size_t)s->plan->N;
+    if (hipMalloc((void**)&s->h0p, M * 4) != hipSuccess || hipMalloc((void**)&s->prbp, N * 3 * 4) != hipSuccess ||
+        hipMalloc((void**)&s->nrmp, N * 2 * 4) != hipSuccess) {
+      psignn_set_error("broyden: hipMalloc of plan-order inputs failed");
+      return PSIGNN_ENOMEM;
+    }
+    s->bytes += M * 4 + N * 20;
   }
   if (hipHostMalloc((void**)&s->h_st, sizeof(Status)) != hipSuccess) {
     psignn_set_error("broyden: hipHostMalloc failed");
@@ -433,7 +441,7 @@ static int broyden_alloc(psignn_broyden* s) {
 extern "C" void psignn_broyden_destroy(psignn_broyden_t* s) {
   if (!s) return;
   void* ptrs[] = {s->U, s->V, s->xbuf, s->gx, s->dg, s->upd, s->fx, s->fwork, s->part, s->coef, s->st,
-                  s->rel_trace, s->abs_trace};
+                  s->rel_trace, s->abs_trace, s->h0p, s->prbp, s->nrmp};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (s->h_st) (void)hipHostFree(s->h_st);
@@ -508,10 +516,17 @@ static int read_status(psignn_broyden* s, hipStream_t st) {
 static int finish(psignn_broyden* s, float* d_result, psignn_solve_info_t* info, double* h_rel, double* h_abs,
                   hipStream_t st) {
   unsigned g = (unsigned)s->nblk;
-  if (d_result)
-    k_copy_sel<<<g, TB, 0, st>>>(s->M, s->xbuf, reinterpret_cast<const int32_t*>(s->st) + sel_off_low(), 0, d_result);
-  int rc = read_status(s, st);
-  if (rc) return rc;
+  int rc = 0;
+  if (d_result) {
+    const int32_t* sel_low = reinterpret_cast<const int32_t*>(s->st) + sel_off_low();
+    if (s->plan) {  // iterates live in plan order: select into fx, then back to the caller's numbering
+      k_copy_sel<<<g, TB, 0, st>>>(s->M, s->xbuf, sel_low, 0, s->fx);
+      if ((rc = psignn_plan_permute(s->plan, s->fx, D, d_result, 0, st))) return rc;
+    } else {
+      k_copy_sel<<<g, TB, 0, st>>>(s->M, s->xbuf, sel_low, 0, d_result);
+    }
+  }
+  if ((rc = read_status(s, st))) return rc;
   const Status& h = *s->h_st;
   if (info) {
     info->nstep = h.lowest_step;
@@ -544,13 +559,19 @@ extern "C" int psignn_broyden_solve(psignn_broyden_t* s, const float* W, int nl,
   unsigned g = (unsigned)s->nblk;
   const int32_t* sel_nxt = reinterpret_cast<const int32_t*>(s->st) + sel_off_nxt();
   k_init_status<<<4, TB, 0, st>>>(s->st, s->rel_trace, s->abs_trace, s->thr);
+  // node tensors into plan order once per solve (identity copy on an untiled plan)
+  int rc;
+  const psignn_plan* p = s->plan;
+  if ((rc = psignn_plan_permute(p, h0, D, s->h0p, 1, st))) return rc;
+  if ((rc = psignn_plan_permute(p, prb, p->mixed ? 3 : 2, s->prbp, 1, st))) return rc;
+  if (p->mixed && (rc = psignn_plan_permute(p, nrm, 2, s->nrmp, 1, st))) return rc;
+  const float* nrmp = p->mixed ? s->nrmp : nullptr;
   // gx0 = f(x0) - x0, update = gx0 (solver.py:131-136)
-  int rc = psignn_f_forward(s->plan, W, nl, h0, h0, prb, nrm, s->fx, s->fwork, st);
-  if (rc) return rc;
-  k_begin<<<g, TB, 0, st>>>(s->M, h0, s->fx, s->xbuf, s->gx, s->upd);
+  if ((rc = psignn_f_eval_p(p, W, nl, s->h0p, nullptr, 0, s->h0p, s->prbp, nrmp, s->fx, s->fwork, st))) return rc;
+  k_begin<<<g, TB, 0, st>>>(s->M, s->h0p, s->fx, s->xbuf, s->gx, s->upd);
   for (int it = 0; it < s->thr; ++it) {
     LAUNCH("k_xnext", st, (k_xnext<<<g, TB, 0, st>>>(s->M, s->st, s->xbuf, s->upd, nullptr)));
-    rc = psignn_f_forward_sel(s->plan, W, nl, s->xbuf, sel_nxt, s->M, h0, prb, nrm, s->fx, s->fwork, st);
+    rc = psignn_f_eval_p(p, W, nl, s->xbuf, sel_nxt, s->M, s->h0p, s->prbp, nrmp, s->fx, s->fwork, st);
     if (rc) return rc;
     launch_update(s, it, eps, st);
     if ((it + 1) % poll_every == 0 || it + 1 == s->thr) {
@@ -566,6 +587,10 @@ extern "C" int psignn_broyden_get_iterate(const psignn_broyden_t* s, int i, floa
   ARG_CHECK(s && d_dst, "NULL argument");
   ARG_CHECK(s->keep_trace, "solver was created without keep_trace");
   ARG_CHECK(i >= 0 && i <= s->thr, "iterate index out of range");
+  if (s->plan) {
+    k_copy_sel<<<(unsigned)s->nblk, TB, 0, (hipStream_t)stream>>>(s->M, s->xbuf, nullptr, i, s->fx);
+    return psignn_plan_permute(s->plan, s->fx, D, d_dst, 0, stream);
+  }
   k_copy_sel<<<(unsigned)s->nblk, TB, 0, (hipStream_t)stream>>>(s->M, s->xbuf, nullptr, i, d_dst);
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;

@@ -1,0 +1,415 @@
+// Tile structures of the mesh plan (gfx950): spatial node renumbering, tiles with halos, sliced-ELL
+// neighbour lists with LDS-local indices.  One-time, on the device; integer / index work only.
+//
+// Why: the GNN block gathers a projected 40-byte row per edge endpoint.  From global memory those gathers
+// are uncoalesced (one cache line per lane) and the texture-address path, not HBM, bounds the kernel.
+// With nodes renumbered so that <= 256 consecutive ids form a compact patch of the mesh, a workgroup
+// stages the rows of its patch + halo in LDS once and every gather becomes a ds_read.
+//
+//   1. bin nodes into square cells of ~tile_target nodes (pos, bounding box, one refinement of the cell
+//      size from the occupied-cell count); counting sort by cell, node id ascending inside a cell
+//   2. cells -> tiles (cells above TILE_MAX nodes are split evenly); tiles -> 64-lane slices
+//   3. per tile: halo = sorted distinct out-of-tile neighbours (both directions)
+//   4. per slice: ELL slot-rows [max in-degree | max out-degree] x 64 lanes holding the LDS row of each
+//      neighbour (uint16) and edge_attr (SoA), in the canonical neighbour order of the CSR/CSC plan
+// If a structure limit is exceeded (cell > SORT_CAP nodes, halo > HALO_CAP, degree > 255) the plan
+// stays untiled and the global-gather kernels (fgnn.hip) are used.
+#include "common.h"
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+#define SORT_CAP 4096
+#define CAND_CAP 4096
+
+// ---------------------------------------------------------------- bounding box
+__device__ __forceinline__ uint32_t f2o(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+static float o2f(uint32_t o) {
+  uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+__global__ void k_bbox(int64_t N, const float* __restrict__ pos, uint32_t* __restrict__ box /* xmin ymin xmax ymax */) {
+  float xmn = INFINITY, ymn = INFINITY, xmx = -INFINITY, ymx = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    float x = pos[2 * i], y = pos[2 * i + 1];
+    xmn = fminf(xmn, x); xmx = fmaxf(xmx, x);
+    ymn = fminf(ymn, y); ymx = fmaxf(ymx, y);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    xmn = fminf(xmn, __shfl_xor(xmn, o)); xmx = fmaxf(xmx, __shfl_xor(xmx, o));
+    ymn = fminf(ymn, __shfl_xor(ymn, o)); ymx = fmaxf(ymx, __shfl_xor(ymx, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&box[0], f2o(xmn)); atomicMin(&box[1], f2o(ymn));
+    atomicMax(&box[2], f2o(xmx)); atomicMax(&box[3], f2o(ymx));
+  }
+}
+
+__device__ __forceinline__ int cell_of(float x, float y, float xmin, float ymin, float inv_cs, int nx, int ny) {
+  int cx = (int)floorf((x - xmin) * inv_cs);
+  int cy = (int)floorf((y - ymin) * inv_cs);
+  cx = min(max(cx, 0), nx - 1);
+  cy = min(max(cy, 0), ny - 1);
+  return cy * nx + cx;
+}
+
+__global__ void k_cell_count(int64_t N, const float* __restrict__ pos, float xmin, float ymin, float inv_cs, int nx,
+                             int ny, int32_t* __restrict__ cnt) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  atomicAdd(&cnt[cell_of(pos[2 * i], pos[2 * i + 1], xmin, ymin, inv_cs, nx, ny)], 1);
+}
+__global__ void k_count_nonempty(int64_t n, const int32_t* __restrict__ cnt, int32_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int v = (i < n && cnt[i] > 0) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+__global__ void k_cell_fill(int64_t N, const float* __restrict__ pos, float xmin, float ymin, float inv_cs, int nx,
+                            int ny, const int32_t* __restrict__ cptr, int32_t* __restrict__ cur,
+                            int32_t* __restrict__ list) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int c = cell_of(pos[2 * i], pos[2 * i + 1], xmin, ymin, inv_cs, nx, ny);
+  list[cptr[c] + atomicAdd(&cur[c], 1)] = (int32_t)i;
+}
+// One block per cell: rank sort of the (unique) node ids held by the cell.
+__global__ __launch_bounds__(256) void k_cell_sort(const int32_t* __restrict__ cptr, int32_t* __restrict__ list,
+                                                   int32_t* __restrict__ err) {
+  __shared__ int32_t ids[SORT_CAP];
+  int32_t s = cptr[blockIdx.x], n = cptr[blockIdx.x + 1] - s;
+  if (n <= 1) return;
+  if (n > SORT_CAP) {
+    if (threadIdx.x == 0) atomicOr(err, 1);
+    return;
+  }
+  for (int i = threadIdx.x; i < n; i += 256) ids[i] = list[s + i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    int32_t x = ids[i];
+    int r = 0;
+    for (int j = 0; j < n; ++j) r += ids[j] < x;
+    list[s + r] = x;
+  }
+}
+
+__global__ void k_inverse_perm(int64_t N, const int32_t* __restrict__ perm, int32_t* __restrict__ inv,
+                               const uint8_t* __restrict__ flags, uint8_t* __restrict__ flags_p) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int32_t o = perm[i];
+  inv[o] = (int32_t)i;
+  flags_p[i] = flags[o];
+}
+__global__ void k_iota(int64_t N, int32_t* __restrict__ a) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) a[i] = (int32_t)i;
+}
+
+// ---------------------------------------------------------------- halo
+// One block per tile: distinct out-of-tile neighbours (new ids), ascending.
+__global__ __launch_bounds__(256) void k_halo(const int32_t* __restrict__ tile_ptr, const int32_t* __restrict__ perm,
+                                              const int32_t* __restrict__ inv, const int32_t* __restrict__ csr_ptr,
+                                              const int32_t* __restrict__ csr_nbr, const int32_t* __restrict__ csc_ptr,
+                                              const int32_t* __restrict__ csc_nbr, int32_t* __restrict__ halo,
+                                              int32_t* __restrict__ halo_cnt, int32_t* __restrict__ misc /* [0] err [1] max rows */) {
+  __shared__ int32_t cand[CAND_CAP];
+  __shared__ uint8_t keep[CAND_CAP];
+  __shared__ int32_t n_cand, n_keep;
+  const int tile = blockIdx.x;
+  const int32_t t0 = tile_ptr[tile], t1 = tile_ptr[tile + 1];
+  if (threadIdx.x == 0) { n_cand = 0; n_keep = 0; }
+  __syncthreads();
+  if ((int)threadIdx.x < t1 - t0) {
+    int32_t old = perm[t0 + threadIdx.x];
+    for (int pass = 0; pass < 2; ++pass) {
+      const int32_t* ptr = pass ? csr_ptr : csc_ptr;
+      const int32_t* nbr = pass ? csr_nbr : csc_nbr;
+      for (int32_t e = ptr[old]; e < ptr[old + 1]; ++e) {
+        int32_t nb = inv[nbr[e]];
+        if (nb < t0 || nb >= t1) {
+          int p = atomicAdd(&n_cand, 1);
+          if (p < CAND_CAP) cand[p] = nb;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  int n = n_cand;
+  if (n > CAND_CAP) {
+    if (threadIdx.x == 0) atomicOr(&misc[0], 2);
+    n = CAND_CAP;
+  }
+  for (int i = threadIdx.x; i < n; i += 256) {
+    int32_t x = cand[i];
+    bool first = true;
+    for (int j = 0; j < i; ++j) first = first && (cand[j] != x);
+    keep[i] = first;
+    if (first) atomicAdd(&n_keep, 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    if (!keep[i]) continue;
+    int32_t x = cand[i];
+    int r = 0;
+    for (int j = 0; j < n; ++j) r += (keep[j] && cand[j] < x);
+    if (r < HALO_CAP) halo[(int64_t)tile * HALO_CAP + r] = x;
+  }
+  if (threadIdx.x == 0) {
+    halo_cnt[tile] = n_keep;
+    if (n_keep > HALO_CAP) atomicOr(&misc[0], 4);
+    atomicMax(&misc[1], (t1 - t0) + n_keep);
+  }
+}
+
+// ---------------------------------------------------------------- slices / ELL
+// One wave per slice: max in-/out-degree of its (up to) 64 nodes.
+__global__ __launch_bounds__(256) void k_slice_deg(int64_t n_slices, const int32_t* __restrict__ slice_tile,
+                                                   const int32_t* __restrict__ tile_slice,
+                                                   const int32_t* __restrict__ tile_ptr, const int32_t* __restrict__ perm,
+                                                   const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csc_ptr,
+                                                   uint8_t* __restrict__ slice_deg, int32_t* __restrict__ misc) {
+  int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= n_slices) return;
+  int lane = threadIdx.x & 63;
+  int tile = slice_tile[s];
+  int32_t node = tile_ptr[tile] + 64 * (int32_t)(s - tile_slice[tile]) + lane;
+  int din = 0, dout = 0;
+  if (node < tile_ptr[tile + 1]) {
+    int32_t old = perm[node];
+    din = csc_ptr[old + 1] - csc_ptr[old];
+    dout = csr_ptr[old + 1] - csr_ptr[old];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    din = max(din, __shfl_xor(din, o));
+    dout = max(dout, __shfl_xor(dout, o));
+  }
+  if (lane == 0) {
+    if (din > 255 || dout > 255) atomicOr(&misc[0], 8);
+    slice_deg[2 * s] = (uint8_t)min(din, 255);
+    slice_deg[2 * s + 1] = (uint8_t)min(dout, 255);
+  }
+}
+
+__device__ __forceinline__ int lower_bound_i32(const int32_t* __restrict__ a, int n, int32_t x) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (a[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void k_ell_fill(int64_t n_slices, const int32_t* __restrict__ slice_tile,
+                                                  const int32_t* __restrict__ tile_slice,
+                                                  const int32_t* __restrict__ tile_ptr, const int32_t* __restrict__ perm,
+                                                  const int32_t* __restrict__ inv, const int32_t* __restrict__ halo,
+                                                  const int32_t* __restrict__ halo_cnt,
+                                                  const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_nbr,
+                                                  const float* __restrict__ csr_attr, const int32_t* __restrict__ csc_ptr,
+                                                  const int32_t* __restrict__ csc_nbr, const float* __restrict__ csc_attr,
+                                                  const int32_t* __restrict__ slice_off, const uint8_t* __restrict__ slice_deg,
+                                                  uint16_t* __restrict__ ell_idx, float* __restrict__ ell_attr) {
+  int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= n_slices) return;
+  int lane = threadIdx.x & 63;
+  int tile = slice_tile[s];
+  const int32_t t0 = tile_ptr[tile], t1 = tile_ptr[tile + 1];
+  const int32_t n_t = t1 - t0;
+  int32_t node = t0 + 64 * (int32_t)(s - tile_slice[tile]) + lane;
+  bool valid = node < t1;
+  int32_t old = valid ? perm[node] : 0;
+  const int32_t* hl = halo + (int64_t)tile * HALO_CAP;
+  const int hc = min(halo_cnt[tile], HALO_CAP);
+  int64_t row = slice_off[s];
+  for (int pass = 0; pass < 2; ++pass) {
+    const int32_t* ptr = pass ? csr_ptr : csc_ptr;
+    const int32_t* nbr = pass ? csr_nbr : csc_nbr;
+    const float* attr = pass ? csr_attr : csc_attr;
+    int dmax = slice_deg[2 * s + pass];
+    int32_t b = valid ? ptr[old] : 0, e = valid ? ptr[old + 1] : 0;
+    for (int r = 0; r < dmax; ++r, ++row) {
+      uint16_t li = ELL_EMPTY;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      if (b + r < e) {
+        int32_t nb = inv[nbr[b + r]];
+        li = (nb >= t0 && nb < t1) ? (uint16_t)(nb - t0) : (uint16_t)(n_t + lower_bound_i32(hl, hc, nb));
+        a0 = attr[3 * (int64_t)(b + r)];
+        a1 = attr[3 * (int64_t)(b + r) + 1];
+        a2 = attr[3 * (int64_t)(b + r) + 2];
+      }
+      ell_idx[row * 64 + lane] = li;
+      ell_attr[(row * 3 + 0) * 64 + lane] = a0;
+      ell_attr[(row * 3 + 1) * 64 + lane] = a1;
+      ell_attr[(row * 3 + 2) * 64 + lane] = a2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- host
+int psignn_exclusive_scan(const int32_t* in, int64_t n, int32_t* out, int32_t* bsum, hipStream_t st);
+
+void psignn_tiles_free(psignn_plan* p) {
+  void* ptrs[] = {p->perm, p->inv, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt,
+                  p->slice_off, p->slice_deg, p->ell_idx, p->ell_attr, p->flags_p};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  p->perm = p->inv = p->tile_ptr = p->tile_slice = p->halo = p->halo_cnt = p->slice_off = nullptr;
+  p->slice_deg = nullptr; p->ell_idx = nullptr; p->ell_attr = nullptr; p->flags_p = nullptr;
+  p->tiled = 0;
+}
+
+#define HT(expr)                                                                        \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      psignn_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      rc = PSIGNN_EHIP;                                                                 \
+      goto done;                                                                        \
+    }                                                                                   \
+  } while (0)
+
+// Builds the tile structures.  Returns 0 and sets p->tiled = 1 on success; returns 0 with p->tiled = 0
+// when a structural limit was hit (the caller keeps the untiled plan); negative on HIP errors.
+int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipStream_t st) {
+  const int64_t N = p->N;
+  const unsigned TB = 256;
+  int rc = 0;
+  if (tile_target <= 0) tile_target = 160;
+  if (tile_target > TILE_MAX) tile_target = TILE_MAX;
+  int32_t *cnt = nullptr, *cptr = nullptr, *cur = nullptr, *bsum = nullptr, *misc = nullptr, *slice_tile = nullptr;
+  uint32_t* box = nullptr;
+  std::vector<int32_t> h_cptr, h_tile_ptr, h_tile_slice, h_slice_tile, h_slice_off;
+  std::vector<uint8_t> h_deg;
+  int64_t ncell = 0;
+  int32_t h_misc[2] = {0, 0};
+  const unsigned gn = (unsigned)cdiv(N, TB);
+
+  HT(hipMalloc((void**)&p->perm, N * 4));
+  HT(hipMalloc((void**)&p->inv, N * 4));
+  HT(hipMalloc((void**)&p->flags_p, N));
+  HT(hipMalloc((void**)&misc, 8));
+  HT(hipMemsetAsync(misc, 0, 8, st));
+
+  if (d_pos) {
+    // ---- 1. cells
+    uint32_t h_box[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
+    HT(hipMalloc((void**)&box, 16));
+    HT(hipMemcpyAsync(box, h_box, 16, hipMemcpyHostToDevice, st));
+    k_bbox<<<1024, TB, 0, st>>>(N, d_pos, box);
+    HT(hipMemcpyAsync(h_box, box, 16, hipMemcpyDeviceToHost, st));
+    HT(hipStreamSynchronize(st));
+    float xmin = o2f(h_box[0]), ymin = o2f(h_box[1]), xmax = o2f(h_box[2]), ymax = o2f(h_box[3]);
+    if (!(isfinite(xmin) && isfinite(ymin) && isfinite(xmax) && isfinite(ymax))) goto done;  // NaN/inf positions: stay untiled
+    double w = fmax((double)xmax - xmin, 1e-30), hgt = fmax((double)ymax - ymin, 1e-30);
+    double cs = sqrt((double)tile_target * w * hgt / (double)N);
+    int nx = 1, ny = 1;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      nx = (int)fmin(fmax(ceil(w / cs), 1.0), 32768.0);
+      ny = (int)fmin(fmax(ceil(hgt / cs), 1.0), 32768.0);
+      ncell = (int64_t)nx * ny;
+      if (cnt) { (void)hipFree(cnt); cnt = nullptr; }
+      HT(hipMalloc((void**)&cnt, (ncell + 1) * 4));
+      HT(hipMemsetAsync(cnt, 0, (ncell + 1) * 4, st));
+      k_cell_count<<<gn, TB, 0, st>>>(N, d_pos, xmin, ymin, (float)(1.0 / cs), nx, ny, cnt);
+      if (attempt == 1) break;
+      // refine the cell size once so that OCCUPIED cells hold ~tile_target nodes (domains do not fill their box)
+      k_count_nonempty<<<(unsigned)cdiv(ncell, TB), TB, 0, st>>>(ncell, cnt, cnt + ncell);
+      int32_t nonempty = 0;
+      HT(hipMemcpyAsync(&nonempty, cnt + ncell, 4, hipMemcpyDeviceToHost, st));
+      HT(hipStreamSynchronize(st));
+      double avg = (double)N / fmax(1.0, (double)nonempty);
+      if (avg < 1.12 * tile_target && avg > 0.88 * tile_target) break;
+      cs *= sqrt((double)tile_target / avg);
+    }
+    p->cell_size = (float)cs; p->xmin = xmin; p->ymin = ymin; p->nx = nx; p->ny = ny;
+    HT(hipMalloc((void**)&cptr, (ncell + 1) * 4));
+    HT(hipMalloc((void**)&cur, ncell * 4));
+    HT(hipMalloc((void**)&bsum, (cdiv(ncell, 1024) + 2) * 4));
+    HT(hipMemsetAsync(cur, 0, ncell * 4, st));
+    if ((rc = psignn_exclusive_scan(cnt, ncell, cptr, bsum, st)) != 0) goto done;
+    k_cell_fill<<<gn, TB, 0, st>>>(N, d_pos, xmin, ymin, (float)(1.0 / cs), nx, ny, cptr, cur, p->perm);
+    k_cell_sort<<<(unsigned)ncell, TB, 0, st>>>(cptr, p->perm, misc);
+    h_cptr.resize(ncell + 1);
+    HT(hipMemcpyAsync(h_cptr.data(), cptr, (ncell + 1) * 4, hipMemcpyDeviceToHost, st));
+    HT(hipMemcpyAsync(h_misc, misc, 8, hipMemcpyDeviceToHost, st));
+    HT(hipStreamSynchronize(st));
+    if (h_misc[0]) goto done;  // a cell above SORT_CAP nodes: stay untiled
+  } else {
+    // no coordinates: keep the given numbering, tiles = consecutive chunks
+    k_iota<<<gn, TB, 0, st>>>(N, p->perm);
+    ncell = cdiv(N, tile_target);
+    h_cptr.resize(ncell + 1);
+    for (int64_t c = 0; c <= ncell; ++c) h_cptr[c] = (int32_t)((c * (int64_t)tile_target < N) ? c * tile_target : N);
+  }
+  // ---- 2. tiles and slices (host: a few thousand entries)
+  h_tile_ptr.push_back(0);
+  for (int64_t c = 0; c < ncell; ++c) {
+    int32_t n = h_cptr[c + 1] - h_cptr[c];
+    if (n <= 0) continue;
+    int nt = (n + TILE_MAX - 1) / TILE_MAX;
+    int chunk = (n + nt - 1) / nt;
+    for (int j = 0; j < nt; ++j) h_tile_ptr.push_back(h_cptr[c] + (int32_t)fmin((double)n, (double)(j + 1) * chunk));
+  }
+  p->n_tiles = (int64_t)h_tile_ptr.size() - 1;
+  h_tile_slice.resize(p->n_tiles + 1);
+  h_tile_slice[0] = 0;
+  for (int64_t t = 0; t < p->n_tiles; ++t) {
+    int ns = (h_tile_ptr[t + 1] - h_tile_ptr[t] + 63) / 64;
+    h_tile_slice[t + 1] = h_tile_slice[t] + ns;
+    for (int j = 0; j < ns; ++j) h_slice_tile.push_back((int32_t)t);
+  }
+  p->n_slices = h_tile_slice[p->n_tiles];
+  HT(hipMalloc((void**)&p->tile_ptr, (p->n_tiles + 1) * 4));
+  HT(hipMalloc((void**)&p->tile_slice, (p->n_tiles + 1) * 4));
+  HT(hipMalloc((void**)&slice_tile, p->n_slices * 4 + 4));
+  HT(hipMalloc((void**)&p->halo, p->n_tiles * HALO_CAP * 4));
+  HT(hipMalloc((void**)&p->halo_cnt, p->n_tiles * 4));
+  HT(hipMalloc((void**)&p->slice_deg, p->n_slices * 2 + 2));
+  HT(hipMalloc((void**)&p->slice_off, (p->n_slices + 1) * 4));
+  HT(hipMemcpyAsync(p->tile_ptr, h_tile_ptr.data(), (p->n_tiles + 1) * 4, hipMemcpyHostToDevice, st));
+  HT(hipMemcpyAsync(p->tile_slice, h_tile_slice.data(), (p->n_tiles + 1) * 4, hipMemcpyHostToDevice, st));
+  HT(hipMemcpyAsync(slice_tile, h_slice_tile.data(), p->n_slices * 4, hipMemcpyHostToDevice, st));
+  k_inverse_perm<<<gn, TB, 0, st>>>(N, p->perm, p->inv, p->flags, p->flags_p);
+  // ---- 3. halos
+  k_halo<<<(unsigned)p->n_tiles, TB, 0, st>>>(p->tile_ptr, p->perm, p->inv, p->csr_ptr, p->csr_nbr, p->csc_ptr,
+                                               p->csc_nbr, p->halo, p->halo_cnt, misc);
+  // ---- 4. slices / ELL
+  k_slice_deg<<<(unsigned)cdiv(p->n_slices, 4), TB, 0, st>>>(p->n_slices, slice_tile, p->tile_slice, p->tile_ptr,
+                                                              p->perm, p->csr_ptr, p->csc_ptr, p->slice_deg, misc);
+  h_deg.resize(p->n_slices * 2);
+  HT(hipMemcpyAsync(h_deg.data(), p->slice_deg, p->n_slices * 2, hipMemcpyDeviceToHost, st));
+  HT(hipMemcpyAsync(h_misc, misc, 8, hipMemcpyDeviceToHost, st));
+  HT(hipStreamSynchronize(st));
+  if (h_misc[0]) goto done;  // halo or degree limit exceeded: stay untiled
+  p->max_rows = h_misc[1];
+  h_slice_off.resize(p->n_slices + 1);
+  h_slice_off[0] = 0;
+  for (int64_t s = 0; s < p->n_slices; ++s) {
+    int64_t nxt = (int64_t)h_slice_off[s] + h_deg[2 * s] + h_deg[2 * s + 1];
+    if (nxt > (int64_t)INT32_MAX / 256) goto done;
+    h_slice_off[s + 1] = (int32_t)nxt;
+  }
+  p->ell_rows = h_slice_off[p->n_slices];
+  HT(hipMemcpyAsync(p->slice_off, h_slice_off.data(), (p->n_slices + 1) * 4, hipMemcpyHostToDevice, st));
+  HT(hipMalloc((void**)&p->ell_idx, (size_t)(p->ell_rows + 1) * 64 * 2));
+  HT(hipMalloc((void**)&p->ell_attr, (size_t)(p->ell_rows + 1) * 3 * 64 * 4));
+  k_ell_fill<<<(unsigned)cdiv(p->n_slices, 4), TB, 0, st>>>(p->n_slices, slice_tile, p->tile_slice, p->tile_ptr, p->perm,
+                                                             p->inv, p->halo, p->halo_cnt, p->csr_ptr, p->csr_nbr,
+                                                             p->csr_attr, p->csc_ptr, p->csc_nbr, p->csc_attr,
+                                                             p->slice_off, p->slice_deg, p->ell_idx, p->ell_attr);
+  HT(hipStreamSynchronize(st));
+  HT(hipGetLastError());
+  p->tiled = 1;
+done:
+  for (void* q : {(void*)cnt, (void*)cptr, (void*)cur, (void*)bsum, (void*)misc, (void*)slice_tile, (void*)box})
+    if (q) (void)hipFree(q);
+  if (!p->tiled) psignn_tiles_free(p);
+  return rc;
+}

@@ -77,13 +77,19 @@ class PackedWeights:
 _EXPORT = {"csr_ptr": (0, np.int32), "csr_nbr": (1, np.int32), "csr_eid": (2, np.int32),
            "csc_ptr": (3, np.int32), "csc_nbr": (4, np.int32), "csc_eid": (5, np.int32),
            "node_flags": (6, np.uint8), "csr_attr": (7, np.float32), "csc_attr": (8, np.float32),
-           "a_ptr": (9, np.int32), "a_col": (10, np.int32), "a_val": (11, np.float32)}
+           "a_ptr": (9, np.int32), "a_col": (10, np.int32), "a_val": (11, np.float32),
+           "perm": (12, np.int32), "tile_ptr": (13, np.int32), "halo_cnt": (14, np.int32), "halo": (15, np.int32),
+           "slice_off": (16, np.int32), "slice_deg": (17, np.uint8), "ell_idx": (18, np.uint16),
+           "ell_attr": (19, np.float32), "tile_slice": (20, np.int32)}
+
+HALO_CAP = 512
 
 
 class MeshPlan:
     """Iteration-invariant device data of one mesh (or a disjoint union).  See csrc/plan.hip."""
 
-    def __init__(self, batch):
+    def __init__(self, batch, tile_target=0):
+        """tile_target: nodes per tile (0 = library default, < 0 = untiled global-gather kernels)."""
         ei = batch.edge_index
         nat.require_cuda(ei, "batch.edge_index")
         self.device = ei.device
@@ -99,23 +105,41 @@ class MeshPlan:
             raise nat.NativeError(f"edge_attr shape {tuple(ea.shape)} does not match edge_index {tuple(eic.shape)}")
         if tags.shape[0] != N:
             raise nat.NativeError("tags and x disagree on the node count")
+        pos = getattr(batch, "pos", None)
+        if pos is not None:
+            pos = pos.to(torch.float32).contiguous()
+            if pos.shape != (N, 2) or pos.device != self.device:
+                pos = None  # coordinates only steer the tiling; without them the given numbering is kept
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             nat.check(nat.lib().psignn_plan_create(C.byref(h), N, eic.shape[1], nat.ptr(eic), nat.ptr(ea),
-                                                   nat.ptr(aij), nat.ptr(tags), tags.shape[1],
-                                                   nat.stream_ptr(self.device)), "psignn_plan_create")
+                                                   nat.ptr(aij), nat.ptr(tags), tags.shape[1], nat.ptr(pos),
+                                                   int(tile_target), nat.stream_ptr(self.device)),
+                      "psignn_plan_create")
         self.handle = h
         self._fin = weakref.finalize(self, nat.lib().psignn_plan_destroy, h)
         self.N = N
         self.E = int(eic.shape[1])
         self.Ep = int(nat.lib().psignn_plan_num_nonself_edges(h))
         self.mixed = tags.shape[1] == 3
+        self.tiled = bool(nat.lib().psignn_plan_is_tiled(h))
+        self.n_tiles = int(nat.lib().psignn_plan_num_tiles(h))
+        self.ell_rows = int(nat.lib().psignn_plan_ell_rows(h))
+        self.max_tile_rows = int(nat.lib().psignn_plan_max_tile_rows(h))
         self._work = None
 
     def export(self, name):
         which, dt = _EXPORT[name]
+        if which >= 12 and not self.tiled:
+            raise nat.NativeError("plan has no tile structures")
+        n_slices = None
+        if name in ("slice_off", "slice_deg"):
+            n_slices = int(self.export("tile_slice")[-1])
         n = {"csr_ptr": self.N + 1, "csc_ptr": self.N + 1, "a_ptr": self.N + 1, "node_flags": self.N,
-             "csr_attr": 3 * self.Ep, "csc_attr": 3 * self.Ep, "a_col": self.E, "a_val": self.E}.get(name, self.Ep)
+             "csr_attr": 3 * self.Ep, "csc_attr": 3 * self.Ep, "a_col": self.E, "a_val": self.E,
+             "perm": self.N, "tile_ptr": self.n_tiles + 1, "tile_slice": self.n_tiles + 1, "halo_cnt": self.n_tiles,
+             "halo": self.n_tiles * HALO_CAP, "slice_off": (n_slices or 0) + 1, "slice_deg": 2 * (n_slices or 0),
+             "ell_idx": self.ell_rows * 64, "ell_attr": self.ell_rows * 192}.get(name, self.Ep)
         out = np.empty(n, dtype=dt)
         nat.check(nat.lib().psignn_plan_export(self.handle, which, out.ctypes.data_as(C.c_void_p), out.nbytes),
                   "psignn_plan_export")
@@ -127,15 +151,24 @@ class MeshPlan:
             self._work = torch.empty(n, dtype=torch.float32, device=self.device)
         return self._work
 
+    def permute(self, t, to_plan=True):
+        """Rows of an (N, cols) float tensor between the caller's numbering and plan order."""
+        tc = _f32c(t)
+        out = torch.empty_like(tc)
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().psignn_plan_permute(self.handle, nat.ptr(tc), tc.shape[1], nat.ptr(out), int(to_plan),
+                                                    nat.stream_ptr(self.device)), "psignn_plan_permute")
+        return out
 
-def plan_for(batch) -> MeshPlan:
+
+def plan_for(batch, tile_target=0) -> MeshPlan:
     """Plan cached on the batch object (rebuilt if edge_index/tags storage changed)."""
     key = (batch.edge_index.data_ptr(), tuple(batch.edge_index.shape), batch.tags.data_ptr(),
-           batch.edge_attr.data_ptr(), str(batch.edge_index.device))
+           batch.edge_attr.data_ptr(), str(batch.edge_index.device), tile_target)
     cached = getattr(batch, "_psignn_plan", None)
     if cached is not None and cached[0] == key:
         return cached[1]
-    plan = MeshPlan(batch)
+    plan = MeshPlan(batch, tile_target)
     try:
         batch._psignn_plan = (key, plan)
     except Exception:
@@ -168,6 +201,28 @@ class FixedPointMap:
         exp_p = 3 if plan.mixed else 2
         if self.prb.shape != (plan.N, exp_p) or self.h0.shape != (plan.N, D):
             raise nat.NativeError(f"shape mismatch: prb_data {tuple(self.prb.shape)}, h_initial {tuple(self.h0.shape)}")
+        self._p = None  # plan-order copies of h0 / prb / normals, made on first use
+
+    # -- plan-order fast path (no permutation passes per call) -------------------------------------
+    def to_plan(self, H):
+        return self.plan.permute(H, True)
+
+    def from_plan(self, Hp):
+        return self.plan.permute(Hp, False)
+
+    def fp(self, Hp):
+        """f in plan order: Hp and the result are numbered like the plan's tiles (see MeshPlan.permute)."""
+        if self._p is None:
+            self._p = (self.to_plan(self.h0), self.to_plan(self.prb), None if self.nrm is None else self.to_plan(self.nrm))
+        h0p, prbp, nrmp = self._p
+        Hc = _f32c(Hp)
+        out = torch.empty_like(Hc)
+        with torch.cuda.device(Hc.device):
+            nat.check(nat.lib().psignn_f_forward_p(self.plan.handle, nat.ptr(self.weights.flat), self.weights.n_layers,
+                                                   nat.ptr(Hc), nat.ptr(h0p), nat.ptr(prbp), nat.ptr(nrmp),
+                                                   nat.ptr(out), nat.ptr(self.plan.workspace()),
+                                                   nat.stream_ptr(Hc.device)), "psignn_f_forward_p")
+        return out
 
     def __call__(self, H):
         nat.require_cuda(H, "H")

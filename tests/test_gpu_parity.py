@@ -374,3 +374,89 @@ def test_full_size_properties(dev):
     out = solver.broyden(fm, fm.h0, threshold=40, eps=1e-5, keep_trace=False)
     assert out["n_iter"] == 40 and np.all(np.isfinite(out["rel_trace"]))
     assert out["rel_trace"][39] < out["rel_trace"][0]
+
+
+# ------------------------------------------------------------------------------------------ tiled plan
+@pytest.mark.parametrize("name,target", [("original_dirichlet_s0", 0), ("hex13_mixed_s1", 64), ("hex26_dirichlet_s0", 0),
+                                         ("hex26_dirichlet_s0", 256)])
+def test_tile_structures_bit_exact(name, target, dev):
+    """Renumbering, halos and sliced-ELL lists of csrc/tiles.hip against the numpy statement (tests/plan_ref.py)."""
+    from plan_ref import tile_reference
+    g, mesh = load_case(name)
+    eng = pkg("engine")
+    plan = eng.MeshPlan(mesh.to(dev), tile_target=target)
+    assert plan.tiled
+    perm, tile_ptr = plan.export("perm"), plan.export("tile_ptr")
+    assert np.array_equal(np.sort(perm), np.arange(mesh.num_nodes))          # a permutation
+    sizes = np.diff(tile_ptr)
+    assert tile_ptr[0] == 0 and tile_ptr[-1] == mesh.num_nodes and sizes.min() >= 1 and sizes.max() <= 256
+    for t in range(len(sizes)):                                               # node ids ascending inside a tile
+        assert np.all(np.diff(perm[tile_ptr[t]:tile_ptr[t + 1]]) > 0)
+    ref = tile_reference(mesh.edge_index.numpy(), mesh.num_nodes, perm, tile_ptr, mesh.edge_attr.numpy())
+    assert np.array_equal(plan.export("halo_cnt"), ref["halo_cnt"])
+    halo = plan.export("halo").reshape(-1, 512)
+    for t, h in enumerate(ref["halo"]):
+        assert np.array_equal(halo[t, :len(h)], h), t
+    assert np.array_equal(plan.export("tile_slice"), ref["tile_slice"])
+    assert np.array_equal(plan.export("slice_deg").reshape(-1, 2), ref["slice_deg"])
+    off = plan.export("slice_off")
+    assert off[0] == 0 and np.array_equal(np.diff(off), ref["slice_deg"].astype(np.int32).sum(1))
+    assert np.array_equal(plan.export("ell_idx").reshape(-1, 64), ref["ell_idx"])
+    assert np.array_equal(plan.export("ell_attr").reshape(-1, 3, 64), ref["ell_attr"])
+    assert plan.max_tile_rows == int((sizes + ref["halo_cnt"]).max())
+    # spatial quality: the halo is a perimeter, not a copy of the mesh
+    if mesh.num_nodes > 1000:
+        assert ref["halo_cnt"].mean() < 0.8 * sizes.mean()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_tiled_kernel_equals_global_gather_kernel(name, dev):
+    """Tile kernel (LDS-staged) vs global-gather kernel: same arithmetic in the same order -> identical bits;
+    both against the oracle.  Also the plan-order entry point and the permutation round trip."""
+    g, mesh, md, sd, fmap = bind(name, dev)
+    eng = pkg("engine")
+    assert fmap.plan.tiled
+    flat = eng.FixedPointMap(eng.MeshPlan(md, tile_target=-1), fmap.weights, fmap.h0, md.prb_data,
+                             getattr(md, "unit_normal_vector", None))
+    assert not flat.plan.tiled
+    x = torch.from_numpy(g["f1"]).to(dev)
+    a, b = fmap(x), flat(x)
+    assert rel_l2(a, g["f2"]) < 2e-6 and rel_l2(b, g["f2"]) < 2e-6
+    assert torch.equal(a, b)
+    xp = fmap.to_plan(x)
+    assert torch.equal(fmap.from_plan(xp), x)
+    assert torch.equal(fmap.from_plan(fmap.fp(xp)), a)
+    for tt in (32, 100, 256):
+        fm = eng.FixedPointMap(eng.MeshPlan(md, tile_target=tt), fmap.weights, fmap.h0, md.prb_data,
+                               getattr(md, "unit_normal_vector", None))
+        assert torch.equal(fm(x), a), tt
+
+
+def test_tiling_without_coordinates_and_fallback(dev):
+    """No pos -> tiles are consecutive chunks of the given numbering; a numbering with no locality overflows
+    the halo capacity and the plan silently keeps the global-gather kernels.  Results never change."""
+    g, mesh, md, sd, fmap = bind("hex26_dirichlet_s0", dev)
+    eng = pkg("engine")
+    x = torch.from_numpy(g["f1"]).to(dev)
+    want = fmap(x)
+    m2 = md.clone()
+    m2.pos = None
+    p2 = eng.MeshPlan(m2, tile_target=128)
+    assert p2.tiled and np.array_equal(p2.export("perm"), np.arange(mesh.num_nodes))
+    assert torch.equal(eng.FixedPointMap(p2, fmap.weights, fmap.h0, md.prb_data)(x), want)
+    # scrambled numbering, no coordinates: every tile touches nodes all over the mesh
+    gen = torch.Generator().manual_seed(4)
+    sc = torch.randperm(mesh.num_nodes, generator=gen)
+    inv = torch.empty_like(sc)
+    inv[sc] = torch.arange(mesh.num_nodes)
+    m3 = mesh.clone()
+    m3.edge_index = inv[mesh.edge_index]
+    for k in ("x", "y", "sol", "prb_data", "tags"):
+        setattr(m3, k, getattr(mesh, k)[sc])
+    m3.pos = None
+    m3d = m3.to(dev)
+    p3 = eng.MeshPlan(m3d, tile_target=256)
+    fm3 = eng.FixedPointMap(p3, fmap.weights, fmap.h0[sc.to(dev)], m3d.prb_data)
+    got = fm3(x[sc.to(dev)])
+    assert rel_l2(got, want[sc.to(dev)]) < 1e-6
+    assert p3.max_tile_rows == 0 or p3.max_tile_rows <= 256 + 512
