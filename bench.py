@@ -155,7 +155,9 @@ def main():
         "config": {"workload": f"{args.bc}/psignn single {N}-node hexagon Poisson mesh per GPU "
                                f"(BASELINE configs[4] size), on-device Broyden iterations 1..{K}, trained checkpoint weights",
                    "nodes": N, "edges_nonself": Ep, "edges_total": E, "solver": "broyden", "latent_dim": D,
-                   "meshes_per_gpu": 1, "parallelism": f"independent meshes x{world}"},
+                   "meshes_per_gpu": 1, "parallelism": f"independent meshes x{world}",
+                   "tiled_plan": bool(fmap.plan.tiled), "tiles": fmap.plan.n_tiles,
+                   "max_tile_rows": fmap.plan.max_tile_rows, "ell_rows": fmap.plan.ell_rows},
         "rel_residual_after_K": out["rel_trace"][K - 1], "setup_s": round(t_setup, 2),
         "broyden_state_bytes": solver.nbytes,
         "roofline_iter": {"bound": "hbm", "achieved": total_iter_bytes / elapsed / 1e9, "peak": HBM_PEAK_GBS,
@@ -170,9 +172,11 @@ def main():
         prof = nat.prof_collect()
         nat.prof_enable(False)
         kern = {}
-        f_ms = prof.get("k_project", (0, 0.0))[1] + prof.get("k_node", (0, 0.0))[1]
-        f_calls = prof.get("k_node", (1, 0.0))[0]
-        kern["f(k_project+k_node)"] = (f_calls, f_ms, per_launch["f(k_project+k_node)"] * f_calls)
+        f_names = ("k_project", "k_node", "k_f_tile")
+        f_ms = sum(prof.get(k, (0, 0.0))[1] for k in f_names)
+        f_calls = max(prof.get("k_node", (0, 0.0))[0], prof.get("k_f_tile", (0, 0.0))[0], 1)
+        f_label = "f(k_f_tile)" if "k_f_tile" in prof else "f(k_project+k_node)"
+        kern[f_label] = (f_calls, f_ms, per_launch["f(k_project+k_node)"] * f_calls)
         for name in ("k_xnext", "k_resid", "k_final"):
             if name in prof:
                 kern[name] = (prof[name][0], prof[name][1], per_launch[name] * prof[name][0])
@@ -190,7 +194,7 @@ def main():
         for row in table:
             row["time_share"] = row["time_share"] / tot_ms
         for name, (calls, ms) in prof.items():
-            if name not in ("k_project", "k_node") and name not in kern:
+            if name not in f_names and name not in kern:
                 table.append({"kernel": name, "launches": calls, "avg_us": 1e3 * ms / max(calls, 1),
                               "time_share": ms / tot_ms})
         table.sort(key=lambda r: -r["time_share"])

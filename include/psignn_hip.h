@@ -84,8 +84,8 @@ int64_t psignn_plan_num_nonself_edges(const psignn_plan_t* plan);  /* E' */
  * which: 0 csr_ptr(N+1 i32) 1 csr_nbr(E' i32) 2 csr_eid(E' i32) 3 csc_ptr 4 csc_nbr 5 csc_eid
  *        6 node_flags (N u8) 7 csr_attr (E'*3 f32) 8 csc_attr 9 a_ptr (N+1 i32) 10 a_col (E i32)
  *        11 a_val (E f32); tiled plans only: 12 perm (N i32, perm[new] = old) 13 tile_ptr (T+1 i32)
- *        14 halo_cnt (T i32) 15 halo (T*512 i32) 16 slice_off (S+1 i32) 17 slice_deg (S*2 u8)
- *        18 ell_idx (rows*64 u16) 19 ell_attr (rows*3*64 f32) 20 tile_slice (T+1 i32).  Synchronous. */
+ *        14 halo_cnt (T i32) 15 halo (T*512 i32) 16 slice_off (S+1 i32) 17 slice_deg (S u8)
+ *        18 ell (rows*64*4 u32: pair-merged neighbour slots) 20 tile_slice (T+1 i32).  Synchronous. */
 int psignn_plan_export(const psignn_plan_t* plan, int which, void* h_dst, size_t dst_bytes);
 
 /* ------------------------------------------------------------------------------------------

@@ -33,8 +33,12 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // Weight pack layout (floats).  All blocks are nn.Linear (out,in) row-major.
 //   shared : ln_gamma[10] ln_beta[10] alpha_w[30+P] alpha_b[1]            (padded to SHARED_SZ)
 //   layer l: phi_to{W1[10x23] b1[10] W2[10x10] b2[10]}  phi_from{...}  update{U1[10x(30+P)] c1[10] U2[10x10] c2[10]}
-//   mixed  : phi_neu{...350}  upd_neu{N1[10x25] n1[10] N2[10x10] n2[10]}
+//            fold{G_to[10x10] g_to[10] G_fr[10x10] g_fr[10] a_to[10] a_fr[10] ab_to ab_fr}          (FOLD_SZ 244)
+//   mixed  : phi_neu{...350}  upd_neu{N1[10x25] n1[10] N2[10x10] n2[10]}  nfold{G_n[10x10] g_n[10]} (NFOLD_SZ 112)
 // P = second_member_dim = 2 (dirichlet) / 3 (mixed).
+// fold blocks are derived on the host (engine.pack_weights): the second Phi layer is linear, so
+//   U1[:, mp_to cols] (W2_to S + deg b2_to) = G_to S + deg g_to   with G_to = U1_to W2_to, g_to = U1_to b2_to
+// and likewise for the alpha gate (a_to = w_alpha,to W2_to, ab_to = w_alpha,to . b2_to) and the Neumann MLP.
 // ---------------------------------------------------------------------------------------------
 template <int P>
 struct WLayout {
@@ -46,16 +50,20 @@ struct WLayout {
   static constexpr int PHI_W1 = 0, PHI_B1 = D * EIN, PHI_W2 = D * EIN + D, PHI_B2 = D * EIN + D + D * D;
   static constexpr int UPD_SZ = D * CAT + D + D * D + D;
   static constexpr int UPD_W1 = 0, UPD_B1 = D * CAT, UPD_W2 = D * CAT + D, UPD_B2 = D * CAT + D + D * D;
-  static constexpr int LAYER_SZ = 2 * PHI_SZ + UPD_SZ;
-  static constexpr int L_TO = 0, L_FROM = PHI_SZ, L_UPD = 2 * PHI_SZ;
+  static constexpr int FOLD_SZ = 244;
+  static constexpr int F_GTO = 0, F_gTO = 100, F_GFR = 110, F_gFR = 210, F_ATO = 220, F_AFR = 230, F_ABTO = 240, F_ABFR = 241;
+  static constexpr int LAYER_SZ = 2 * PHI_SZ + UPD_SZ + FOLD_SZ;
+  static constexpr int L_TO = 0, L_FROM = PHI_SZ, L_UPD = 2 * PHI_SZ, L_FOLD = 2 * PHI_SZ + UPD_SZ;
+  static constexpr int NFOLD_SZ = 112, NF_G = 0, NF_g = 100;
   static constexpr int NEU_CAT = 2 * D + P + 2;  // 25 (mixed only)
   static constexpr int NEU_SZ = D * NEU_CAT + D + D * D + D;
   static constexpr int NEU_W1 = 0, NEU_B1 = D * NEU_CAT, NEU_W2 = D * NEU_CAT + D, NEU_B2 = D * NEU_CAT + D + D * D;
   __host__ __device__ static constexpr int layer(int l) { return SHARED_SZ + l * LAYER_SZ; }
   __host__ __device__ static constexpr int phi_neu(int nl) { return SHARED_SZ + nl * LAYER_SZ; }
   __host__ __device__ static constexpr int upd_neu(int nl) { return SHARED_SZ + nl * LAYER_SZ + PHI_SZ; }
+  __host__ __device__ static constexpr int nfold(int nl) { return SHARED_SZ + nl * LAYER_SZ + PHI_SZ + NEU_SZ; }
   __host__ __device__ static constexpr int total(int nl, bool mixed) {
-    return SHARED_SZ + nl * LAYER_SZ + (mixed ? PHI_SZ + NEU_SZ : 0);
+    return SHARED_SZ + nl * LAYER_SZ + (mixed ? PHI_SZ + NEU_SZ + NFOLD_SZ : 0);
   }
 };
 
@@ -84,9 +92,8 @@ struct psignn_plan {
   int32_t* tile_slice = nullptr;               // (n_tiles+1) first 64-lane slice of each tile
   int32_t *halo = nullptr, *halo_cnt = nullptr;  // (n_tiles, HALO_CAP) sorted new ids ; (n_tiles)
   int32_t* slice_off = nullptr;                // (n_slices+1) first ELL slot-row of each slice
-  uint8_t* slice_deg = nullptr;                // (n_slices, 2) max in-degree, max out-degree of the slice
-  uint16_t* ell_idx = nullptr;                 // (ell_rows, 64) LDS row of the neighbour, 0xFFFF = empty
-  float* ell_attr = nullptr;                   // (ell_rows, 3, 64) edge_attr, SoA per slot-row
+  uint8_t* slice_deg = nullptr;                // (n_slices) slot-rows of the slice (max neighbour slots of its nodes)
+  uint4* ell = nullptr;                        // (ell_rows, 64) pair-merged slots {row|IN|OUT, a0, a1, a2}, tiles.hip
   uint8_t* flags_p = nullptr;                  // node flags in plan order
   float cell_size = 0.f, xmin = 0.f, ymin = 0.f;
   int nx = 0, ny = 0;

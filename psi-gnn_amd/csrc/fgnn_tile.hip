@@ -1,77 +1,68 @@
 // f_theta on the tiled plan: one workgroup per mesh tile, neighbour projections staged in LDS (gfx950).
 //
-// Same arithmetic as fgnn.hip (reference: dirichlet/psignn/model.py:279-300, mixed/psignn/model.py:216-245),
+// Same function as fgnn.hip (reference: dirichlet/psignn/model.py:279-300, mixed/psignn/model.py:216-245),
 // different data movement:
 //   stage 1  every lane takes one row of the tile + halo (<= 256 + HALO_CAP rows): loads h (tile rows are
 //            one coalesced 40 B/lane stream, halo rows a short indexed gather), projects it with the
-//            neighbour-side weights W1j_{to,from[,neu]} and parks the result in LDS
-//   stage 2  every lane owns one tile node: walks its sliced-ELL in- and out-lists (coalesced uint16 LDS row
-//            ids + SoA edge_attr), gathers the projected neighbour rows with ds_read_b128, sums relu terms in
-//            the plan's canonical order (no atomics), then gate / update MLP / LayerNorm / boundary rows
-// All node-level tensors are in PLAN order (plan->perm); the solver keeps its state in that order.
+//            neighbour-side weights W1j_{to,from[,neu]} and parks the 80-byte result row in LDS
+//   stage 2  every lane owns one tile node and walks its pair-merged ELL slots (tiles.hip): one coalesced
+//            16-byte load {LDS row, IN/OUT, edge_attr} and one LDS row read (5 x ds_read_b128) serve BOTH
+//            directions of a neighbour; relu terms are summed in the plan's canonical order (no atomics,
+//            bitwise reproducible), then gate / update MLP / LayerNorm / boundary rows.
+// The second Phi layer (W2 S + deg b2) is linear and is folded into the consumers' first-layer weights on
+// the host (WLayout fold block).  All node tensors are in PLAN order; the solver keeps its state there.
 #include "fgnn_common.h"
+
+#define SLOT_IN 0x10000u
+#define SLOT_OUT 0x20000u
 
 template <bool MIXED>
 struct TileRow {
-  static constexpr int RS = MIXED ? 36 : 24;   // floats per LDS row: [to 10|pad 2][from 10|pad 2]([neu 10|pad 2])
+  static constexpr int RS = MIXED ? 32 : 20;  // floats per LDS row: [to 10 | from 10] (| neu 10 | pad 2)
 };
 
-__device__ __forceinline__ void lds_store10(float* __restrict__ p, const float* __restrict__ t) {
-  reinterpret_cast<float4*>(p)[0] = make_float4(t[0], t[1], t[2], t[3]);
-  reinterpret_cast<float4*>(p)[1] = make_float4(t[4], t[5], t[6], t[7]);
-  reinterpret_cast<float2*>(p)[4] = make_float2(t[8], t[9]);
+__device__ __forceinline__ void lds_store20(float* __restrict__ p, const float* __restrict__ a, const float* __restrict__ b) {
+  float4* q = reinterpret_cast<float4*>(p);
+  q[0] = make_float4(a[0], a[1], a[2], a[3]);
+  q[1] = make_float4(a[4], a[5], a[6], a[7]);
+  q[2] = make_float4(a[8], a[9], b[0], b[1]);
+  q[3] = make_float4(b[2], b[3], b[4], b[5]);
+  q[4] = make_float4(b[6], b[7], b[8], b[9]);
 }
-__device__ __forceinline__ void lds_load10(const float* __restrict__ p, float* __restrict__ t) {
-  float4 a = reinterpret_cast<const float4*>(p)[0];
-  float4 b = reinterpret_cast<const float4*>(p)[1];
-  float2 c = reinterpret_cast<const float2*>(p)[4];
-  t[0] = a.x; t[1] = a.y; t[2] = a.z; t[3] = a.w;
-  t[4] = b.x; t[5] = b.y; t[6] = b.z; t[7] = b.w;
-  t[8] = c.x; t[9] = c.y;
+__device__ __forceinline__ void lds_load20(const float* __restrict__ p, float* __restrict__ a, float* __restrict__ b) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+  float4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4];
+  a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
+  a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+  a[8] = v2.x; a[9] = v2.y; b[0] = v2.z; b[1] = v2.w;
+  b[2] = v3.x; b[3] = v3.y; b[4] = v3.z; b[5] = v3.w;
+  b[6] = v4.x; b[7] = v4.y; b[8] = v4.z; b[9] = v4.w;
 }
-
-// S[o] = sum over the lane's ELL slots of relu(Pi[o] + Pj[row][o] + W1a[o,:] . attr)
-template <int RS>
-__device__ __forceinline__ int ell_sum(int64_t row0, int nslots, int lane, const uint16_t* __restrict__ ell_idx,
-                                       const float* __restrict__ ell_attr, const float* __restrict__ W1, int ld,
-                                       const float* __restrict__ lds, int col, const float* Pi, float* S) {
-  int deg = 0;
+__device__ __forceinline__ void lds_store10at(float* __restrict__ p, const float* __restrict__ t) {  // 8-byte aligned
+  float2* q = reinterpret_cast<float2*>(p);
 #pragma unroll
-  for (int o = 0; o < D; ++o) S[o] = 0.f;
-  for (int r = 0; r < nslots; ++r) {
-    const int64_t row = row0 + r;
-    const unsigned li = ell_idx[row * 64 + lane];
-    const float a0 = ell_attr[(row * 3 + 0) * 64 + lane];
-    const float a1 = ell_attr[(row * 3 + 1) * 64 + lane];
-    const float a2 = ell_attr[(row * 3 + 2) * 64 + lane];
-    if (li != ELL_EMPTY) {
-      ++deg;
-      float pj[D];
-      lds_load10(lds + (int)li * RS + col, pj);
+  for (int i = 0; i < 5; ++i) q[i] = make_float2(t[2 * i], t[2 * i + 1]);
+}
+__device__ __forceinline__ void lds_load10at(const float* __restrict__ p, float* __restrict__ t) {
+  const float2* q = reinterpret_cast<const float2*>(p);
 #pragma unroll
-      for (int o = 0; o < D; ++o) {
-        float z = Pi[o] + pj[o];
-        z = fmaf(W1[o * ld + 2 * D + 0], a0, z);
-        z = fmaf(W1[o * ld + 2 * D + 1], a1, z);
-        z = fmaf(W1[o * ld + 2 * D + 2], a2, z);
-        S[o] += fmaxf(z, 0.f);
-      }
-    }
+  for (int i = 0; i < 5; ++i) {
+    float2 v = q[i];
+    t[2 * i] = v.x;
+    t[2 * i + 1] = v.y;
   }
-  return deg;  // the node's real degree (padding slots excluded), for the deg * b2 term
 }
 
 template <int P, bool MIXED>
 __global__ __launch_bounds__(256) void k_f_tile(int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
                                                 const int32_t* __restrict__ tile_slice, const int32_t* __restrict__ halo,
                                                 const int32_t* __restrict__ halo_cnt, const int32_t* __restrict__ slice_off,
-                                                const uint8_t* __restrict__ slice_deg, const uint16_t* __restrict__ ell_idx,
-                                                const float* __restrict__ ell_attr, const uint8_t* __restrict__ flags,
-                                                const float* __restrict__ W, int lofs, int nofs, int unofs, int apply_ln,
-                                                const float* __restrict__ h, const int32_t* __restrict__ hsel,
-                                                int64_t hstride, const float* __restrict__ h0,
-                                                const float* __restrict__ prb, const float* __restrict__ nrm,
-                                                float* __restrict__ out) {
+                                                const uint8_t* __restrict__ slice_deg, const uint4* __restrict__ ell,
+                                                const uint8_t* __restrict__ flags, const float* __restrict__ W, int lofs,
+                                                int nofs, int unofs, int nl, int apply_ln, const float* __restrict__ h,
+                                                const int32_t* __restrict__ hsel, int64_t hstride,
+                                                const float* __restrict__ h0, const float* __restrict__ prb,
+                                                const float* __restrict__ nrm, float* __restrict__ out) {
   using L = WLayout<P>;
   constexpr int RS = TileRow<MIXED>::RS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -94,20 +85,18 @@ __global__ __launch_bounds__(256) void k_f_tile(int n_tiles, int chunk, const in
   float x[D];
   for (int row = tid; row < n_t + n_h; row += 256) {
     const int64_t node = row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t];
-    float xr[D], t[D];
+    float xr[D], ta[D], tb[D];
     load10(h + node * D, xr);
     if (row == tid) {
 #pragma unroll
       for (int o = 0; o < D; ++o) x[o] = xr[o];
     }
-    float* dst = lds + row * RS;
-    matvec10<D, false>(Wto + L::PHI_W1, L::EIN, D, xr, t);
-    lds_store10(dst, t);
-    matvec10<D, false>(Wfr + L::PHI_W1, L::EIN, D, xr, t);
-    lds_store10(dst + 12, t);
+    matvec10<D, false>(Wto + L::PHI_W1, L::EIN, D, xr, ta);
+    matvec10<D, false>(Wfr + L::PHI_W1, L::EIN, D, xr, tb);
+    lds_store20(lds + row * RS, ta, tb);
     if (MIXED) {
-      matvec10<D, false>(Wn + L::PHI_W1, L::EIN, D, xr, t);
-      lds_store10(dst + 24, t);
+      matvec10<D, false>(Wn + L::PHI_W1, L::EIN, D, xr, ta);
+      lds_store10at(lds + row * RS + 20, ta);
     }
   }
   __syncthreads();
@@ -124,43 +113,88 @@ __global__ __launch_bounds__(256) void k_f_tile(int n_tiles, int chunk, const in
   }
   const int lane = tid & 63;
   const int slice = tile_slice[tile] + (tid >> 6);
-  const int64_t row0 = slice_off[slice];
-  const int din = slice_deg[2 * slice], dout = slice_deg[2 * slice + 1];
+  const uint4* slots = ell + (int64_t)slice_off[slice] * 64 + lane;
+  const int nslots = slice_deg[slice];
 
-  float Pi[D], S[D], mp_to[D], mp_fr[D];
-  // Phi_to: in-edges, aggregated at the column index
+  // target-side projections (bias included)
+  float Pt[D], Pf[D], S_to[D], S_fr[D];
 #pragma unroll
-  for (int o = 0; o < D; ++o) Pi[o] = Wto[L::PHI_B1 + o];
-  matvec10<D, true>(Wto + L::PHI_W1, L::EIN, 0, x, Pi);
-  const int deg_in = ell_sum<RS>(row0, din, lane, ell_idx, ell_attr, Wto + L::PHI_W1, L::EIN, lds, 0, Pi, S);
+  for (int o = 0; o < D; ++o) {
+    Pt[o] = Wto[L::PHI_B1 + o];
+    Pf[o] = Wfr[L::PHI_B1 + o];
+    S_to[o] = 0.f;
+    S_fr[o] = 0.f;
+  }
+  matvec10<D, true>(Wto + L::PHI_W1, L::EIN, 0, x, Pt);
+  matvec10<D, true>(Wfr + L::PHI_W1, L::EIN, 0, x, Pf);
+  float deg_in = 0.f, deg_out = 0.f;
+  {
+    const float* At = Wto + L::PHI_W1 + 2 * D;  // W1[:, 20:23] of Phi_to
+    const float* Af = Wfr + L::PHI_W1 + 2 * D;
+    uint4 cur = nslots > 0 ? slots[0] : make_uint4(ELL_EMPTY, 0u, 0u, 0u);
+    for (int r = 0; r < nslots; ++r) {
+      // software prefetch of the next slot row (one 16-byte coalesced load per lane)
+      const uint4 nxt = (r + 1 < nslots) ? slots[(int64_t)(r + 1) * 64] : make_uint4(ELL_EMPTY, 0u, 0u, 0u);
+      const unsigned w = cur.x;
+      if ((w & 0xFFFFu) != ELL_EMPTY) {
+        const float a0 = __uint_as_float(cur.y), a1 = __uint_as_float(cur.z), a2 = __uint_as_float(cur.w);
+        const bool has_in = w & SLOT_IN, has_out = w & SLOT_OUT;
+        float pt[D], pf[D];
+        lds_load20(lds + (int)(w & 0xFFFFu) * RS, pt, pf);
+        deg_in += has_in ? 1.f : 0.f;
+        deg_out += has_out ? 1.f : 0.f;
 #pragma unroll
-  for (int o = 0; o < D; ++o) mp_to[o] = (float)deg_in * Wto[L::PHI_B2 + o];
-  matvec10<D, true>(Wto + L::PHI_W2, D, 0, S, mp_to);
-  // Phi_from: out-edges, aggregated at the row index
-#pragma unroll
-  for (int o = 0; o < D; ++o) Pi[o] = Wfr[L::PHI_B1 + o];
-  matvec10<D, true>(Wfr + L::PHI_W1, L::EIN, 0, x, Pi);
-  const int deg_out = ell_sum<RS>(row0 + din, dout, lane, ell_idx, ell_attr, Wfr + L::PHI_W1, L::EIN, lds, 12, Pi, S);
-#pragma unroll
-  for (int o = 0; o < D; ++o) mp_fr[o] = (float)deg_out * Wfr[L::PHI_B2 + o];
-  matvec10<D, true>(Wfr + L::PHI_W2, D, 0, S, mp_fr);
+        for (int o = 0; o < D; ++o) {
+          // in-edge (u -> v): its attr is the mirror (-a0, -a1, a2) of the stored out-edge attr
+          float zt = Pt[o] + pt[o];
+          zt = fmaf(At[o * L::EIN + 0], -a0, zt);
+          zt = fmaf(At[o * L::EIN + 1], -a1, zt);
+          zt = fmaf(At[o * L::EIN + 2], a2, zt);
+          S_to[o] += has_in ? fmaxf(zt, 0.f) : 0.f;
+          float zf = Pf[o] + pf[o];
+          zf = fmaf(Af[o * L::EIN + 0], a0, zf);
+          zf = fmaf(Af[o * L::EIN + 1], a1, zf);
+          zf = fmaf(Af[o * L::EIN + 2], a2, zf);
+          S_fr[o] += has_out ? fmaxf(zf, 0.f) : 0.f;
+        }
+      }
+      cur = nxt;
+    }
+  }
 
   float y[D];
   if (MIXED && (fl & FLAG_NEUMANN)) {
-    // Phi_neumann (Phi_from type) + update_neumann: the row is REPLACED (mixed/psignn/model.py:236,241)
+    // Phi_neumann (Phi_from type: out-edges) + update_neumann: the row is REPLACED (mixed/psignn/model.py:236,241)
     const float* Un = W + unofs;
-    float mp_n[D], hid[D];
+    const float* Nf = W + L::nfold(nl);
+    const float* An = Wn + L::PHI_W1 + 2 * D;
+    float Pn[D], S_n[D], hid[D];
 #pragma unroll
-    for (int o = 0; o < D; ++o) Pi[o] = Wn[L::PHI_B1 + o];
-    matvec10<D, true>(Wn + L::PHI_W1, L::EIN, 0, x, Pi);
-    ell_sum<RS>(row0 + din, dout, lane, ell_idx, ell_attr, Wn + L::PHI_W1, L::EIN, lds, 24, Pi, S);
+    for (int o = 0; o < D; ++o) {
+      Pn[o] = Wn[L::PHI_B1 + o];
+      S_n[o] = 0.f;
+    }
+    matvec10<D, true>(Wn + L::PHI_W1, L::EIN, 0, x, Pn);
+    for (int r = 0; r < nslots; ++r) {
+      const uint4 cur = slots[(int64_t)r * 64];
+      if ((cur.x & 0xFFFFu) != ELL_EMPTY && (cur.x & SLOT_OUT)) {
+        const float a0 = __uint_as_float(cur.y), a1 = __uint_as_float(cur.z), a2 = __uint_as_float(cur.w);
+        float pn[D];
+        lds_load10at(lds + (int)(cur.x & 0xFFFFu) * RS + 20, pn);
 #pragma unroll
-    for (int o = 0; o < D; ++o) mp_n[o] = (float)deg_out * Wn[L::PHI_B2 + o];
-    matvec10<D, true>(Wn + L::PHI_W2, D, 0, S, mp_n);
+        for (int o = 0; o < D; ++o) {
+          float z = Pn[o] + pn[o];
+          z = fmaf(An[o * L::EIN + 0], a0, z);
+          z = fmaf(An[o * L::EIN + 1], a1, z);
+          z = fmaf(An[o * L::EIN + 2], a2, z);
+          S_n[o] += fmaxf(z, 0.f);
+        }
+      }
+    }
 #pragma unroll
-    for (int o = 0; o < D; ++o) hid[o] = Un[L::NEU_B1 + o];
+    for (int o = 0; o < D; ++o) hid[o] = fmaf(deg_out, Nf[L::NF_g + o], Un[L::NEU_B1 + o]);
     matvec10<D, true>(Un + L::NEU_W1, L::NEU_CAT, 0, x, hid);
-    matvec10<D, true>(Un + L::NEU_W1, L::NEU_CAT, D, mp_n, hid);
+    matvec10<D, true>(Nf + L::NF_G, D, 0, S_n, hid);
     float pq[P + 2];
 #pragma unroll
     for (int k = 0; k < P; ++k) pq[k] = prb[n * P + k];
@@ -174,28 +208,30 @@ __global__ __launch_bounds__(256) void k_f_tile(int n_tiles, int chunk, const in
     }
     matvec10<D, true>(Un + L::NEU_W2, D, 0, hid, y);
   } else {
-    // gate + update MLP on cat = [h | mp_to | mp_from | prb]
+    // gate + update MLP on cat = [h | mp_to | mp_from | prb], with mp_* = W2 S + deg b2 folded in
     const float* Wu = W + lofs + L::L_UPD;
+    const float* Wf = W + lofs + L::L_FOLD;
     const float* Wa = W + L::AL_W;
     float pq[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) pq[k] = prb[n * P + k];
-    float al = W[L::AL_B];
+    float al = fmaf(deg_in, Wf[L::F_ABTO], fmaf(deg_out, Wf[L::F_ABFR], W[L::AL_B]));
 #pragma unroll
     for (int k = 0; k < D; ++k) al = fmaf(Wa[k], x[k], al);
 #pragma unroll
-    for (int k = 0; k < D; ++k) al = fmaf(Wa[D + k], mp_to[k], al);
+    for (int k = 0; k < D; ++k) al = fmaf(Wf[L::F_ATO + k], S_to[k], al);
 #pragma unroll
-    for (int k = 0; k < D; ++k) al = fmaf(Wa[2 * D + k], mp_fr[k], al);
+    for (int k = 0; k < D; ++k) al = fmaf(Wf[L::F_AFR + k], S_fr[k], al);
 #pragma unroll
     for (int k = 0; k < P; ++k) al = fmaf(Wa[3 * D + k], pq[k], al);
     al = 1.f / (1.f + expf(-al));
     float hid[D], upd[D];
 #pragma unroll
-    for (int o = 0; o < D; ++o) hid[o] = Wu[L::UPD_B1 + o];
+    for (int o = 0; o < D; ++o)
+      hid[o] = fmaf(deg_in, Wf[L::F_gTO + o], fmaf(deg_out, Wf[L::F_gFR + o], Wu[L::UPD_B1 + o]));
     matvec10<D, true>(Wu + L::UPD_W1, L::CAT, 0, x, hid);
-    matvec10<D, true>(Wu + L::UPD_W1, L::CAT, D, mp_to, hid);
-    matvec10<D, true>(Wu + L::UPD_W1, L::CAT, 2 * D, mp_fr, hid);
+    matvec10<D, true>(Wf + L::F_GTO, D, 0, S_to, hid);
+    matvec10<D, true>(Wf + L::F_GFR, D, 0, S_fr, hid);
     matvec10<P, true>(Wu + L::UPD_W1, L::CAT, 3 * D, pq, hid);
 #pragma unroll
     for (int o = 0; o < D; ++o) {
@@ -225,15 +261,13 @@ __global__ __launch_bounds__(256) void k_f_tile(int n_tiles, int chunk, const in
   store10(out + n * D, y);
 }
 
-// gather / scatter of node rows between the caller's numbering and the plan order
+// gather of node rows between the caller's numbering and the plan order: dst[i] = src[map[i]]
 __global__ void k_permute_rows(int64_t N, int cols, const int32_t* __restrict__ map, const float* __restrict__ src,
-                               float* __restrict__ dst, int scatter) {
+                               float* __restrict__ dst) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * cols) return;
   int64_t r = i / cols, c = i - r * cols;
-  int64_t m = map[r];
-  if (scatter) dst[m * cols + c] = src[i];
-  else dst[i] = src[m * cols + c];
+  dst[i] = src[(int64_t)map[r] * cols + c];
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -250,9 +284,8 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
     using L = WLayout<3>;
     size_t lds = (size_t)p->max_rows * TileRow<true>::RS * 4;
     LAUNCH("k_f_tile", st, (k_f_tile<3, true><<<grid, 256, lds, st>>>(
-        (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg,
-        p->ell_idx, p->ell_attr, p->flags_p, W, L::layer(nl - 1), L::phi_neu(nl), L::upd_neu(nl), 1, h, hsel, hstride,
-        h0, prb, nrm, out)));
+        (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
+        p->flags_p, W, L::layer(nl - 1), L::phi_neu(nl), L::upd_neu(nl), nl, 1, h, hsel, hstride, h0, prb, nrm, out)));
   } else {
     using L = WLayout<2>;
     size_t lds = (size_t)p->max_rows * TileRow<false>::RS * 4;
@@ -262,9 +295,8 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
     for (int l = 0; l < nl; ++l) {
       float* dst = (l == nl - 1) ? out : pp[l & 1];
       LAUNCH("k_f_tile", st, (k_f_tile<2, false><<<grid, 256, lds, st>>>(
-          (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg,
-          p->ell_idx, p->ell_attr, p->flags_p, W, L::layer(l), 0, 0, l == nl - 1, cur, l == 0 ? hsel : nullptr, hstride,
-          h0, prb, nrm, dst)));
+          (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
+          p->flags_p, W, L::layer(l), 0, 0, nl, l == nl - 1, cur, l == 0 ? hsel : nullptr, hstride, h0, prb, nrm, dst)));
       cur = dst;
     }
   }
@@ -282,7 +314,7 @@ extern "C" int psignn_plan_permute(const psignn_plan_t* p, const float* src, int
     return PSIGNN_OK;
   }
   int64_t n = p->N * cols;
-  k_permute_rows<<<(unsigned)cdiv(n, 256), 256, 0, st>>>(p->N, cols, to_plan ? p->perm : p->inv, src, dst, 0);
+  k_permute_rows<<<(unsigned)cdiv(n, 256), 256, 0, st>>>(p->N, cols, to_plan ? p->perm : p->inv, src, dst);
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }

@@ -405,9 +405,8 @@ extern "C" int psignn_plan_export(const psignn_plan_t* p, int which, void* h_dst
     case 14: src = p->halo_cnt; bytes = p->tiled ? (size_t)p->n_tiles * 4 : 0; break;
     case 15: src = p->halo; bytes = p->tiled ? (size_t)p->n_tiles * HALO_CAP * 4 : 0; break;
     case 16: src = p->slice_off; bytes = p->tiled ? (size_t)(p->n_slices + 1) * 4 : 0; break;
-    case 17: src = p->slice_deg; bytes = p->tiled ? (size_t)p->n_slices * 2 : 0; break;
-    case 18: src = p->ell_idx; bytes = p->tiled ? (size_t)p->ell_rows * 64 * 2 : 0; break;
-    case 19: src = p->ell_attr; bytes = p->tiled ? (size_t)p->ell_rows * 3 * 64 * 4 : 0; break;
+    case 17: src = p->slice_deg; bytes = p->tiled ? (size_t)p->n_slices : 0; break;
+    case 18: src = p->ell; bytes = p->tiled ? (size_t)p->ell_rows * 64 * 16 : 0; break;
     case 20: src = p->tile_slice; bytes = p->tiled ? (size_t)(p->n_tiles + 1) * 4 : 0; break;
     default: ARG_CHECK(false, "unknown array id");
   }

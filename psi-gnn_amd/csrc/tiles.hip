@@ -10,8 +10,8 @@
 //      size from the occupied-cell count); counting sort by cell, node id ascending inside a cell
 //   2. cells -> tiles (cells above TILE_MAX nodes are split evenly); tiles -> 64-lane slices
 //   3. per tile: halo = sorted distinct out-of-tile neighbours (both directions)
-//   4. per slice: ELL slot-rows [max in-degree | max out-degree] x 64 lanes holding the LDS row of each
-//      neighbour (uint16) and edge_attr (SoA), in the canonical neighbour order of the CSR/CSC plan
+//   4. per slice: pair-merged ELL slot-rows x 64 lanes: one 16-byte slot per neighbour {LDS row, IN/OUT, attr}
+//      (see 'pair-merged ELL' below), in the canonical neighbour order of the CSR/CSC plan
 // If a structure limit is exceeded (cell > SORT_CAP nodes, halo > HALO_CAP, degree > 255) the plan
 // stays untiled and the global-gather kernels (fgnn.hip) are used.
 #include "common.h"
@@ -65,11 +65,11 @@ __global__ void k_cell_count(int64_t N, const float* __restrict__ pos, float xmi
   if (i >= N) return;
   atomicAdd(&cnt[cell_of(pos[2 * i], pos[2 * i + 1], xmin, ymin, inv_cs, nx, ny)], 1);
 }
-__global__ void k_count_nonempty(int64_t n, const int32_t* __restrict__ cnt, int32_t* __restrict__ out) {
+__global__ void k_count_max(int64_t n, const int32_t* __restrict__ cnt, int32_t* __restrict__ out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int v = (i < n && cnt[i] > 0) ? 1 : 0;
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+  int v = i < n ? cnt[i] : 0;
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
 }
 __global__ void k_cell_fill(int64_t N, const float* __restrict__ pos, float xmin, float ymin, float inv_cs, int nx,
                             int ny, const int32_t* __restrict__ cptr, int32_t* __restrict__ cur,
@@ -168,32 +168,76 @@ __global__ __launch_bounds__(256) void k_halo(const int32_t* __restrict__ tile_p
   }
 }
 
-// ---------------------------------------------------------------- slices / ELL
-// One wave per slice: max in-/out-degree of its (up to) 64 nodes.
+// ---------------------------------------------------------------- slices / pair-merged ELL
+// A node's neighbour u usually appears twice: as in-edge (u -> v) and as out-edge (v -> u), and for mesh
+// data the two edge_attr triples are exact mirror images, a_uv = (-a_vu[0], -a_vu[1], a_vu[2]) (differences
+// of coordinates and a length).  Such a pair is stored as ONE slot {LDS row of u, IN|OUT, a_vu}: the kernel
+// reads 16 bytes and one LDS row per neighbour instead of per edge direction.  The mirror property is
+// checked bit-for-bit per pair when the plan is built; anything else (one-directional edges such as those
+// into Dirichlet rows, duplicate edges, attrs that are not mirrors) becomes an IN-only or OUT-only slot, so
+// the result is exact for arbitrary input.  Slot order = merge of the canonical in- and out-lists, which keeps
+// each direction's summation order.
+#define SLOT_IN 0x10000u
+#define SLOT_OUT 0x20000u
+
+// emit(r, kind, i, j) is called once per slot in order; kind: 1 in-only, 2 out-only, 3 merged pair;
+// i / j = positions in the CSC (in) / CSR (out) lists.
+template <typename F>
+__device__ __forceinline__ int merge_slots(int32_t ib, int32_t ie, int32_t jb, int32_t je,
+                                           const int32_t* __restrict__ csc_nbr, const float* __restrict__ csc_attr,
+                                           const int32_t* __restrict__ csr_nbr, const float* __restrict__ csr_attr, F emit) {
+  int n = 0;
+  int32_t i = ib, j = jb;
+  while (i < ie || j < je) {
+    const int32_t ni = i < ie ? csc_nbr[i] : INT32_MAX;
+    const int32_t nj = j < je ? csr_nbr[j] : INT32_MAX;
+    if (ni == nj) {
+      const bool single = (i + 1 >= ie || csc_nbr[i + 1] != ni) && (j + 1 >= je || csr_nbr[j + 1] != nj);
+      const uint32_t* ai = reinterpret_cast<const uint32_t*>(csc_attr) + 3 * (int64_t)i;
+      const uint32_t* aj = reinterpret_cast<const uint32_t*>(csr_attr) + 3 * (int64_t)j;
+      const bool mirror = ai[0] == (aj[0] ^ 0x80000000u) && ai[1] == (aj[1] ^ 0x80000000u) && ai[2] == aj[2];
+      if (single && mirror) {
+        emit(n, 3, i, j);
+        ++i; ++j;
+      } else {
+        emit(n, 1, i, j);
+        ++i;
+      }
+    } else if (ni < nj) {
+      emit(n, 1, i, j);
+      ++i;
+    } else {
+      emit(n, 2, i, j);
+      ++j;
+    }
+    ++n;
+  }
+  return n;
+}
+
+// One wave per slice: max slot count of its (up to) 64 nodes.
 __global__ __launch_bounds__(256) void k_slice_deg(int64_t n_slices, const int32_t* __restrict__ slice_tile,
                                                    const int32_t* __restrict__ tile_slice,
                                                    const int32_t* __restrict__ tile_ptr, const int32_t* __restrict__ perm,
-                                                   const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csc_ptr,
+                                                   const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_nbr,
+                                                   const float* __restrict__ csr_attr, const int32_t* __restrict__ csc_ptr,
+                                                   const int32_t* __restrict__ csc_nbr, const float* __restrict__ csc_attr,
                                                    uint8_t* __restrict__ slice_deg, int32_t* __restrict__ misc) {
   int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= n_slices) return;
   int lane = threadIdx.x & 63;
   int tile = slice_tile[s];
   int32_t node = tile_ptr[tile] + 64 * (int32_t)(s - tile_slice[tile]) + lane;
-  int din = 0, dout = 0;
+  int ns = 0;
   if (node < tile_ptr[tile + 1]) {
     int32_t old = perm[node];
-    din = csc_ptr[old + 1] - csc_ptr[old];
-    dout = csr_ptr[old + 1] - csr_ptr[old];
+    ns = merge_slots(csc_ptr[old], csc_ptr[old + 1], csr_ptr[old], csr_ptr[old + 1], csc_nbr, csc_attr, csr_nbr, csr_attr,
+                     [](int, int, int32_t, int32_t) {});
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    din = max(din, __shfl_xor(din, o));
-    dout = max(dout, __shfl_xor(dout, o));
-  }
+  for (int o = 32; o > 0; o >>= 1) ns = max(ns, __shfl_xor(ns, o));
   if (lane == 0) {
-    if (din > 255 || dout > 255) atomicOr(&misc[0], 8);
-    slice_deg[2 * s] = (uint8_t)min(din, 255);
-    slice_deg[2 * s + 1] = (uint8_t)min(dout, 255);
+    if (ns > 255) atomicOr(&misc[0], 8);
+    slice_deg[s] = (uint8_t)min(ns, 255);
   }
 }
 
@@ -206,6 +250,9 @@ __device__ __forceinline__ int lower_bound_i32(const int32_t* __restrict__ a, in
   return lo;
 }
 
+// ell: (ell_rows, 64) slots of 4 words {LDS row | SLOT_IN | SLOT_OUT, a0, a1, a2}; an empty slot is {0xFFFF,0,0,0}.
+// a = edge_attr of the OUT edge (v -> u); for an IN-only slot a = mirror of the in-edge's attr, so that the
+// kernel's mirror of a gives the in-edge's attr back bit-exactly.
 __global__ __launch_bounds__(256) void k_ell_fill(int64_t n_slices, const int32_t* __restrict__ slice_tile,
                                                   const int32_t* __restrict__ tile_slice,
                                                   const int32_t* __restrict__ tile_ptr, const int32_t* __restrict__ perm,
@@ -215,7 +262,7 @@ __global__ __launch_bounds__(256) void k_ell_fill(int64_t n_slices, const int32_
                                                   const float* __restrict__ csr_attr, const int32_t* __restrict__ csc_ptr,
                                                   const int32_t* __restrict__ csc_nbr, const float* __restrict__ csc_attr,
                                                   const int32_t* __restrict__ slice_off, const uint8_t* __restrict__ slice_deg,
-                                                  uint16_t* __restrict__ ell_idx, float* __restrict__ ell_attr) {
+                                                  uint4* __restrict__ ell) {
   int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= n_slices) return;
   int lane = threadIdx.x & 63;
@@ -223,33 +270,31 @@ __global__ __launch_bounds__(256) void k_ell_fill(int64_t n_slices, const int32_
   const int32_t t0 = tile_ptr[tile], t1 = tile_ptr[tile + 1];
   const int32_t n_t = t1 - t0;
   int32_t node = t0 + 64 * (int32_t)(s - tile_slice[tile]) + lane;
-  bool valid = node < t1;
-  int32_t old = valid ? perm[node] : 0;
   const int32_t* hl = halo + (int64_t)tile * HALO_CAP;
   const int hc = min(halo_cnt[tile], HALO_CAP);
-  int64_t row = slice_off[s];
-  for (int pass = 0; pass < 2; ++pass) {
-    const int32_t* ptr = pass ? csr_ptr : csc_ptr;
-    const int32_t* nbr = pass ? csr_nbr : csc_nbr;
-    const float* attr = pass ? csr_attr : csc_attr;
-    int dmax = slice_deg[2 * s + pass];
-    int32_t b = valid ? ptr[old] : 0, e = valid ? ptr[old + 1] : 0;
-    for (int r = 0; r < dmax; ++r, ++row) {
-      uint16_t li = ELL_EMPTY;
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-      if (b + r < e) {
-        int32_t nb = inv[nbr[b + r]];
-        li = (nb >= t0 && nb < t1) ? (uint16_t)(nb - t0) : (uint16_t)(n_t + lower_bound_i32(hl, hc, nb));
-        a0 = attr[3 * (int64_t)(b + r)];
-        a1 = attr[3 * (int64_t)(b + r) + 1];
-        a2 = attr[3 * (int64_t)(b + r) + 2];
-      }
-      ell_idx[row * 64 + lane] = li;
-      ell_attr[(row * 3 + 0) * 64 + lane] = a0;
-      ell_attr[(row * 3 + 1) * 64 + lane] = a1;
-      ell_attr[(row * 3 + 2) * 64 + lane] = a2;
-    }
+  const int64_t row0 = slice_off[s];
+  const int dmax = slice_deg[s];
+  int ns = 0;
+  if (node < t1) {
+    int32_t old = perm[node];
+    ns = merge_slots(csc_ptr[old], csc_ptr[old + 1], csr_ptr[old], csr_ptr[old + 1], csc_nbr, csc_attr, csr_nbr, csr_attr,
+                     [&](int r, int kind, int32_t i, int32_t j) {
+                       if (r >= dmax) return;
+                       const int32_t nb = inv[(kind & 2) ? csr_nbr[j] : csc_nbr[i]];
+                       uint32_t li = (nb >= t0 && nb < t1) ? (uint32_t)(nb - t0) : (uint32_t)(n_t + lower_bound_i32(hl, hc, nb));
+                       uint4 v;
+                       v.x = li | ((kind & 1) ? SLOT_IN : 0u) | ((kind & 2) ? SLOT_OUT : 0u);
+                       if (kind & 2) {
+                         const uint32_t* a = reinterpret_cast<const uint32_t*>(csr_attr) + 3 * (int64_t)j;
+                         v.y = a[0]; v.z = a[1]; v.w = a[2];
+                       } else {
+                         const uint32_t* a = reinterpret_cast<const uint32_t*>(csc_attr) + 3 * (int64_t)i;
+                         v.y = a[0] ^ 0x80000000u; v.z = a[1] ^ 0x80000000u; v.w = a[2];
+                       }
+                       ell[(row0 + r) * 64 + lane] = v;
+                     });
   }
+  for (int r = ns; r < dmax; ++r) ell[(row0 + r) * 64 + lane] = make_uint4(ELL_EMPTY, 0u, 0u, 0u);
 }
 
 // ---------------------------------------------------------------- host
@@ -257,11 +302,11 @@ int psignn_exclusive_scan(const int32_t* in, int64_t n, int32_t* out, int32_t* b
 
 void psignn_tiles_free(psignn_plan* p) {
   void* ptrs[] = {p->perm, p->inv, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt,
-                  p->slice_off, p->slice_deg, p->ell_idx, p->ell_attr, p->flags_p};
+                  p->slice_off, p->slice_deg, p->ell, p->flags_p};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   p->perm = p->inv = p->tile_ptr = p->tile_slice = p->halo = p->halo_cnt = p->slice_off = nullptr;
-  p->slice_deg = nullptr; p->ell_idx = nullptr; p->ell_attr = nullptr; p->flags_p = nullptr;
+  p->slice_deg = nullptr; p->ell = nullptr; p->flags_p = nullptr;
   p->tiled = 0;
 }
 
@@ -281,8 +326,7 @@ int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipS
   const int64_t N = p->N;
   const unsigned TB = 256;
   int rc = 0;
-  if (tile_target <= 0) tile_target = 160;
-  if (tile_target > TILE_MAX) tile_target = TILE_MAX;
+  if (tile_target <= 0 || tile_target > TILE_MAX) tile_target = TILE_MAX;
   int32_t *cnt = nullptr, *cptr = nullptr, *cur = nullptr, *bsum = nullptr, *misc = nullptr, *slice_tile = nullptr;
   uint32_t* box = nullptr;
   std::vector<int32_t> h_cptr, h_tile_ptr, h_tile_slice, h_slice_tile, h_slice_off;
@@ -308,9 +352,13 @@ int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipS
     float xmin = o2f(h_box[0]), ymin = o2f(h_box[1]), xmax = o2f(h_box[2]), ymax = o2f(h_box[3]);
     if (!(isfinite(xmin) && isfinite(ymin) && isfinite(xmax) && isfinite(ymax))) goto done;  // NaN/inf positions: stay untiled
     double w = fmax((double)xmax - xmin, 1e-30), hgt = fmax((double)ymax - ymin, 1e-30);
-    double cs = sqrt((double)tile_target * w * hgt / (double)N);
+    // Cell size: the FULLEST cell should hold just under `goal` nodes, so that tiles fill the 256-lane
+    // workgroup (idle lanes are paid for in every f evaluation).  Start from the box area, then rescale by
+    // the measured maximum (domains do not fill their bounding box, meshes are not uniform).
+    const int goal = tile_target;
+    double cs = sqrt(0.75 * goal * w * hgt / (double)N);
     int nx = 1, ny = 1;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
       nx = (int)fmin(fmax(ceil(w / cs), 1.0), 32768.0);
       ny = (int)fmin(fmax(ceil(hgt / cs), 1.0), 32768.0);
       ncell = (int64_t)nx * ny;
@@ -318,15 +366,12 @@ int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipS
       HT(hipMalloc((void**)&cnt, (ncell + 1) * 4));
       HT(hipMemsetAsync(cnt, 0, (ncell + 1) * 4, st));
       k_cell_count<<<gn, TB, 0, st>>>(N, d_pos, xmin, ymin, (float)(1.0 / cs), nx, ny, cnt);
-      if (attempt == 1) break;
-      // refine the cell size once so that OCCUPIED cells hold ~tile_target nodes (domains do not fill their box)
-      k_count_nonempty<<<(unsigned)cdiv(ncell, TB), TB, 0, st>>>(ncell, cnt, cnt + ncell);
-      int32_t nonempty = 0;
-      HT(hipMemcpyAsync(&nonempty, cnt + ncell, 4, hipMemcpyDeviceToHost, st));
+      k_count_max<<<(unsigned)cdiv(ncell, TB), TB, 0, st>>>(ncell, cnt, cnt + ncell);
+      int32_t mx = 0;
+      HT(hipMemcpyAsync(&mx, cnt + ncell, 4, hipMemcpyDeviceToHost, st));
       HT(hipStreamSynchronize(st));
-      double avg = (double)N / fmax(1.0, (double)nonempty);
-      if (avg < 1.12 * tile_target && avg > 0.88 * tile_target) break;
-      cs *= sqrt((double)tile_target / avg);
+      if (attempt == 3 || (mx <= goal && mx >= 0.9 * goal) || mx <= 0) break;
+      cs *= sqrt(0.96 * goal / (double)mx);
     }
     p->cell_size = (float)cs; p->xmin = xmin; p->ymin = ymin; p->nx = nx; p->ny = ny;
     HT(hipMalloc((void**)&cptr, (ncell + 1) * 4));
@@ -371,7 +416,7 @@ int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipS
   HT(hipMalloc((void**)&slice_tile, p->n_slices * 4 + 4));
   HT(hipMalloc((void**)&p->halo, p->n_tiles * HALO_CAP * 4));
   HT(hipMalloc((void**)&p->halo_cnt, p->n_tiles * 4));
-  HT(hipMalloc((void**)&p->slice_deg, p->n_slices * 2 + 2));
+  HT(hipMalloc((void**)&p->slice_deg, p->n_slices + 2));
   HT(hipMalloc((void**)&p->slice_off, (p->n_slices + 1) * 4));
   HT(hipMemcpyAsync(p->tile_ptr, h_tile_ptr.data(), (p->n_tiles + 1) * 4, hipMemcpyHostToDevice, st));
   HT(hipMemcpyAsync(p->tile_slice, h_tile_slice.data(), (p->n_tiles + 1) * 4, hipMemcpyHostToDevice, st));
@@ -382,9 +427,10 @@ int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipS
                                                p->csc_nbr, p->halo, p->halo_cnt, misc);
   // ---- 4. slices / ELL
   k_slice_deg<<<(unsigned)cdiv(p->n_slices, 4), TB, 0, st>>>(p->n_slices, slice_tile, p->tile_slice, p->tile_ptr,
-                                                              p->perm, p->csr_ptr, p->csc_ptr, p->slice_deg, misc);
-  h_deg.resize(p->n_slices * 2);
-  HT(hipMemcpyAsync(h_deg.data(), p->slice_deg, p->n_slices * 2, hipMemcpyDeviceToHost, st));
+                                                              p->perm, p->csr_ptr, p->csr_nbr, p->csr_attr, p->csc_ptr,
+                                                              p->csc_nbr, p->csc_attr, p->slice_deg, misc);
+  h_deg.resize(p->n_slices);
+  HT(hipMemcpyAsync(h_deg.data(), p->slice_deg, p->n_slices, hipMemcpyDeviceToHost, st));
   HT(hipMemcpyAsync(h_misc, misc, 8, hipMemcpyDeviceToHost, st));
   HT(hipStreamSynchronize(st));
   if (h_misc[0]) goto done;  // halo or degree limit exceeded: stay untiled
@@ -392,18 +438,17 @@ int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipS
   h_slice_off.resize(p->n_slices + 1);
   h_slice_off[0] = 0;
   for (int64_t s = 0; s < p->n_slices; ++s) {
-    int64_t nxt = (int64_t)h_slice_off[s] + h_deg[2 * s] + h_deg[2 * s + 1];
+    int64_t nxt = (int64_t)h_slice_off[s] + h_deg[s];
     if (nxt > (int64_t)INT32_MAX / 256) goto done;
     h_slice_off[s + 1] = (int32_t)nxt;
   }
   p->ell_rows = h_slice_off[p->n_slices];
   HT(hipMemcpyAsync(p->slice_off, h_slice_off.data(), (p->n_slices + 1) * 4, hipMemcpyHostToDevice, st));
-  HT(hipMalloc((void**)&p->ell_idx, (size_t)(p->ell_rows + 1) * 64 * 2));
-  HT(hipMalloc((void**)&p->ell_attr, (size_t)(p->ell_rows + 1) * 3 * 64 * 4));
+  HT(hipMalloc((void**)&p->ell, (size_t)(p->ell_rows + 1) * 64 * 16));
   k_ell_fill<<<(unsigned)cdiv(p->n_slices, 4), TB, 0, st>>>(p->n_slices, slice_tile, p->tile_slice, p->tile_ptr, p->perm,
                                                              p->inv, p->halo, p->halo_cnt, p->csr_ptr, p->csr_nbr,
                                                              p->csr_attr, p->csc_ptr, p->csc_nbr, p->csc_attr,
-                                                             p->slice_off, p->slice_deg, p->ell_idx, p->ell_attr);
+                                                             p->slice_off, p->slice_deg, p->ell);
   HT(hipStreamSynchronize(st));
   HT(hipGetLastError());
   p->tiled = 1;

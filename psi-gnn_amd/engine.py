@@ -52,11 +52,29 @@ def pack_weights(sd, device=None) -> torch.Tensor:
                       g(f"{phi}.{l}.mlp.mlp.2.weight"), g(f"{phi}.{l}.mlp.mlp.2.bias")]
         parts += [g(f"update_list.{l}.mlp.0.weight"), g(f"update_list.{l}.mlp.0.bias"),
                   g(f"update_list.{l}.mlp.2.weight"), g(f"update_list.{l}.mlp.2.bias")]
+        # fold block: second Phi layer pushed through the consumers of mp_to / mp_from (float64, rounded once)
+        m = lambda k: sd[P + k].detach().to("cpu", torch.float64)
+        U1, wa = m(f"update_list.{l}.mlp.0.weight"), m("alpha.0.weight").reshape(-1)
+        fold = []
+        for phi, c0 in (("phi_to_list", D), ("phi_from_list", 2 * D)):
+            W2, b2 = m(f"{phi}.{l}.mlp.mlp.2.weight"), m(f"{phi}.{l}.mlp.mlp.2.bias")
+            fold += [(U1[:, c0:c0 + D] @ W2).reshape(-1), U1[:, c0:c0 + D] @ b2]
+        for phi, c0 in (("phi_to_list", D), ("phi_from_list", 2 * D)):
+            fold.append(wa[c0:c0 + D] @ m(f"{phi}.{l}.mlp.mlp.2.weight"))
+        for phi, c0 in (("phi_to_list", D), ("phi_from_list", 2 * D)):
+            fold.append((wa[c0:c0 + D] @ m(f"{phi}.{l}.mlp.mlp.2.bias")).reshape(1))
+        fold = torch.cat(fold).to(torch.float32)
+        parts.append(torch.nn.functional.pad(fold, (0, 244 - fold.numel())))
     if mixed:
         parts += [g("phi_neumann.mlp.mlp.0.weight"), g("phi_neumann.mlp.mlp.0.bias"),
                   g("phi_neumann.mlp.mlp.2.weight"), g("phi_neumann.mlp.mlp.2.bias"),
                   g("update_neumann.mlp.0.weight"), g("update_neumann.mlp.0.bias"),
                   g("update_neumann.mlp.2.weight"), g("update_neumann.mlp.2.bias")]
+        m = lambda k: sd[P + k].detach().to("cpu", torch.float64)
+        N1 = m("update_neumann.mlp.0.weight")
+        nf = torch.cat([(N1[:, D:2 * D] @ m("phi_neumann.mlp.mlp.2.weight")).reshape(-1),
+                        N1[:, D:2 * D] @ m("phi_neumann.mlp.mlp.2.bias")]).to(torch.float32)
+        parts.append(torch.nn.functional.pad(nf, (0, 112 - nf.numel())))
     flat = torch.cat(parts).contiguous()
     return flat if device is None else flat.to(device)
 
@@ -79,8 +97,8 @@ _EXPORT = {"csr_ptr": (0, np.int32), "csr_nbr": (1, np.int32), "csr_eid": (2, np
            "node_flags": (6, np.uint8), "csr_attr": (7, np.float32), "csc_attr": (8, np.float32),
            "a_ptr": (9, np.int32), "a_col": (10, np.int32), "a_val": (11, np.float32),
            "perm": (12, np.int32), "tile_ptr": (13, np.int32), "halo_cnt": (14, np.int32), "halo": (15, np.int32),
-           "slice_off": (16, np.int32), "slice_deg": (17, np.uint8), "ell_idx": (18, np.uint16),
-           "ell_attr": (19, np.float32), "tile_slice": (20, np.int32)}
+           "slice_off": (16, np.int32), "slice_deg": (17, np.uint8), "ell": (18, np.uint32),
+           "tile_slice": (20, np.int32)}
 
 HALO_CAP = 512
 
@@ -138,8 +156,8 @@ class MeshPlan:
         n = {"csr_ptr": self.N + 1, "csc_ptr": self.N + 1, "a_ptr": self.N + 1, "node_flags": self.N,
              "csr_attr": 3 * self.Ep, "csc_attr": 3 * self.Ep, "a_col": self.E, "a_val": self.E,
              "perm": self.N, "tile_ptr": self.n_tiles + 1, "tile_slice": self.n_tiles + 1, "halo_cnt": self.n_tiles,
-             "halo": self.n_tiles * HALO_CAP, "slice_off": (n_slices or 0) + 1, "slice_deg": 2 * (n_slices or 0),
-             "ell_idx": self.ell_rows * 64, "ell_attr": self.ell_rows * 192}.get(name, self.Ep)
+             "halo": self.n_tiles * HALO_CAP, "slice_off": (n_slices or 0) + 1, "slice_deg": (n_slices or 0),
+             "ell": self.ell_rows * 64 * 4}.get(name, self.Ep)
         out = np.empty(n, dtype=dt)
         nat.check(nat.lib().psignn_plan_export(self.handle, which, out.ctypes.data_as(C.c_void_p), out.nbytes),
                   "psignn_plan_export")
