@@ -53,6 +53,62 @@ __device__ __forceinline__ void lds_load10at(const float* __restrict__ p, float*
   }
 }
 
+// One direction of the neighbour sum for this lane's node:
+//   S[o] += relu(Pi[o] + row[COL + o] + A[o,:] . (sg*a0, sg*a1, a2))   over the slots that carry `MASK`
+// (MASK = SLOT_IN: in-edges, attr mirrored, sg = -1;  SLOT_OUT: out-edges, sg = +1).
+// The two directions are separate passes on purpose: one pass needs 30 wave-uniform weights, which the
+// compiler keeps in SGPRs across the loop; with both directions in one loop (60 weights) it re-issues the
+// scalar loads and their waits in every iteration.  The second pass re-reads the 16-byte slots from L1/L2.
+template <int RS, int COL, unsigned MASK>
+__device__ __forceinline__ float edge_pass(const uint4* __restrict__ slots, int nslots, const float* __restrict__ lds,
+                                           const float* __restrict__ A, int ld, const float* Pi, float* S) {
+  constexpr float SG = (MASK == SLOT_IN) ? -1.f : 1.f;
+  float deg = 0.f;
+  float wa[3 * D];
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    wa[3 * o + 0] = SG * A[o * ld + 0];
+    wa[3 * o + 1] = SG * A[o * ld + 1];
+    wa[3 * o + 2] = A[o * ld + 2];
+  }
+  auto one = [&](const uint4 s) {
+    const unsigned w = s.x;
+    if ((w & 0xFFFFu) != ELL_EMPTY && (w & MASK)) {
+      const float a0 = __uint_as_float(s.y), a1 = __uint_as_float(s.z), a2 = __uint_as_float(s.w);
+      const float* row = lds + (int)(w & 0xFFFFu) * RS + COL;
+      float pj[D];
+      if (COL % 4 == 0) {  // 16-byte aligned start: b128, b128, b64
+        float4 v0 = reinterpret_cast<const float4*>(row)[0], v1 = reinterpret_cast<const float4*>(row)[1];
+        float2 v2 = reinterpret_cast<const float2*>(row)[4];
+        pj[0] = v0.x; pj[1] = v0.y; pj[2] = v0.z; pj[3] = v0.w; pj[4] = v1.x; pj[5] = v1.y; pj[6] = v1.z; pj[7] = v1.w;
+        pj[8] = v2.x; pj[9] = v2.y;
+      } else {             // start at 8 mod 16: b64, b128, b128
+        float2 v0 = reinterpret_cast<const float2*>(row)[0];
+        float4 v1 = reinterpret_cast<const float4*>(row + 2)[0], v2 = reinterpret_cast<const float4*>(row + 2)[1];
+        pj[0] = v0.x; pj[1] = v0.y; pj[2] = v1.x; pj[3] = v1.y; pj[4] = v1.z; pj[5] = v1.w; pj[6] = v2.x; pj[7] = v2.y;
+        pj[8] = v2.z; pj[9] = v2.w;
+      }
+      deg += 1.f;
+#pragma unroll
+      for (int o = 0; o < D; ++o) {
+        float z = Pi[o] + pj[o];
+        z = fmaf(wa[3 * o + 0], a0, z);
+        z = fmaf(wa[3 * o + 1], a1, z);
+        z = fmaf(wa[3 * o + 2], a2, z);
+        S[o] += fmaxf(z, 0.f);
+      }
+    }
+  };
+  int r = 0;
+  for (; r + 1 < nslots; r += 2) {  // two independent 16-byte loads in flight per wait
+    const uint4 s0 = slots[(int64_t)r * 64], s1 = slots[(int64_t)(r + 1) * 64];
+    one(s0);
+    one(s1);
+  }
+  if (r < nslots) one(slots[(int64_t)r * 64]);
+  return deg;
+}
+
 template <int P, bool MIXED>
 __global__ __launch_bounds__(256) void k_f_tile(int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
                                                 const int32_t* __restrict__ tile_slice, const int32_t* __restrict__ halo,
@@ -116,81 +172,34 @@ __global__ __launch_bounds__(256) void k_f_tile(int n_tiles, int chunk, const in
   const uint4* slots = ell + (int64_t)slice_off[slice] * 64 + lane;
   const int nslots = slice_deg[slice];
 
-  // target-side projections (bias included)
-  float Pt[D], Pf[D], S_to[D], S_fr[D];
+  // target-side projection (bias included) + neighbour sum, one direction at a time
+  float Pi[D], S_to[D], S_fr[D];
 #pragma unroll
   for (int o = 0; o < D; ++o) {
-    Pt[o] = Wto[L::PHI_B1 + o];
-    Pf[o] = Wfr[L::PHI_B1 + o];
+    Pi[o] = Wto[L::PHI_B1 + o];
     S_to[o] = 0.f;
     S_fr[o] = 0.f;
   }
-  matvec10<D, true>(Wto + L::PHI_W1, L::EIN, 0, x, Pt);
-  matvec10<D, true>(Wfr + L::PHI_W1, L::EIN, 0, x, Pf);
-  float deg_in = 0.f, deg_out = 0.f;
-  {
-    const float* At = Wto + L::PHI_W1 + 2 * D;  // W1[:, 20:23] of Phi_to
-    const float* Af = Wfr + L::PHI_W1 + 2 * D;
-    uint4 cur = nslots > 0 ? slots[0] : make_uint4(ELL_EMPTY, 0u, 0u, 0u);
-    for (int r = 0; r < nslots; ++r) {
-      // software prefetch of the next slot row (one 16-byte coalesced load per lane)
-      const uint4 nxt = (r + 1 < nslots) ? slots[(int64_t)(r + 1) * 64] : make_uint4(ELL_EMPTY, 0u, 0u, 0u);
-      const unsigned w = cur.x;
-      if ((w & 0xFFFFu) != ELL_EMPTY) {
-        const float a0 = __uint_as_float(cur.y), a1 = __uint_as_float(cur.z), a2 = __uint_as_float(cur.w);
-        const bool has_in = w & SLOT_IN, has_out = w & SLOT_OUT;
-        float pt[D], pf[D];
-        lds_load20(lds + (int)(w & 0xFFFFu) * RS, pt, pf);
-        deg_in += has_in ? 1.f : 0.f;
-        deg_out += has_out ? 1.f : 0.f;
+  matvec10<D, true>(Wto + L::PHI_W1, L::EIN, 0, x, Pi);
+  const float deg_in = edge_pass<RS, 0, SLOT_IN>(slots, nslots, lds, Wto + L::PHI_W1 + 2 * D, L::EIN, Pi, S_to);
 #pragma unroll
-        for (int o = 0; o < D; ++o) {
-          // in-edge (u -> v): its attr is the mirror (-a0, -a1, a2) of the stored out-edge attr
-          float zt = Pt[o] + pt[o];
-          zt = fmaf(At[o * L::EIN + 0], -a0, zt);
-          zt = fmaf(At[o * L::EIN + 1], -a1, zt);
-          zt = fmaf(At[o * L::EIN + 2], a2, zt);
-          S_to[o] += has_in ? fmaxf(zt, 0.f) : 0.f;
-          float zf = Pf[o] + pf[o];
-          zf = fmaf(Af[o * L::EIN + 0], a0, zf);
-          zf = fmaf(Af[o * L::EIN + 1], a1, zf);
-          zf = fmaf(Af[o * L::EIN + 2], a2, zf);
-          S_fr[o] += has_out ? fmaxf(zf, 0.f) : 0.f;
-        }
-      }
-      cur = nxt;
-    }
-  }
+  for (int o = 0; o < D; ++o) Pi[o] = Wfr[L::PHI_B1 + o];
+  matvec10<D, true>(Wfr + L::PHI_W1, L::EIN, 0, x, Pi);
+  const float deg_out = edge_pass<RS, D, SLOT_OUT>(slots, nslots, lds, Wfr + L::PHI_W1 + 2 * D, L::EIN, Pi, S_fr);
 
   float y[D];
   if (MIXED && (fl & FLAG_NEUMANN)) {
     // Phi_neumann (Phi_from type: out-edges) + update_neumann: the row is REPLACED (mixed/psignn/model.py:236,241)
     const float* Un = W + unofs;
     const float* Nf = W + L::nfold(nl);
-    const float* An = Wn + L::PHI_W1 + 2 * D;
-    float Pn[D], S_n[D], hid[D];
+    float S_n[D], hid[D];
 #pragma unroll
     for (int o = 0; o < D; ++o) {
-      Pn[o] = Wn[L::PHI_B1 + o];
+      Pi[o] = Wn[L::PHI_B1 + o];
       S_n[o] = 0.f;
     }
-    matvec10<D, true>(Wn + L::PHI_W1, L::EIN, 0, x, Pn);
-    for (int r = 0; r < nslots; ++r) {
-      const uint4 cur = slots[(int64_t)r * 64];
-      if ((cur.x & 0xFFFFu) != ELL_EMPTY && (cur.x & SLOT_OUT)) {
-        const float a0 = __uint_as_float(cur.y), a1 = __uint_as_float(cur.z), a2 = __uint_as_float(cur.w);
-        float pn[D];
-        lds_load10at(lds + (int)(cur.x & 0xFFFFu) * RS + 20, pn);
-#pragma unroll
-        for (int o = 0; o < D; ++o) {
-          float z = Pn[o] + pn[o];
-          z = fmaf(An[o * L::EIN + 0], a0, z);
-          z = fmaf(An[o * L::EIN + 1], a1, z);
-          z = fmaf(An[o * L::EIN + 2], a2, z);
-          S_n[o] += fmaxf(z, 0.f);
-        }
-      }
-    }
+    matvec10<D, true>(Wn + L::PHI_W1, L::EIN, 0, x, Pi);
+    edge_pass<RS, 2 * D, SLOT_OUT>(slots, nslots, lds, Wn + L::PHI_W1 + 2 * D, L::EIN, Pi, S_n);
 #pragma unroll
     for (int o = 0; o < D; ++o) hid[o] = fmaf(deg_out, Nf[L::NF_g + o], Un[L::NEU_B1 + o]);
     matvec10<D, true>(Un + L::NEU_W1, L::NEU_CAT, 0, x, hid);
