@@ -42,13 +42,25 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 D = 10
 
 
+WORKLOADS = {  # preset -> (nodes per mesh, boundary conditions, meshes per GPU, BASELINE.json config)
+    "mesh1m": (1_000_000, "dirichlet", 1, "configs[4] size"),
+    "dir100k": (100_000, "dirichlet", 1, "configs[1]"),
+    "mixed100k": (100_000, "mixed", 1, "configs[2]"),
+    "batch50k": (50_000, "dirichlet", 8, "configs[3]"),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--nodes", type=int, default=1_000_000, help="target node count of the per-GPU mesh")
-    ap.add_argument("--bc", choices=["dirichlet", "mixed"], default="dirichlet")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="mesh1m",
+                    help="mesh1m = BASELINE configs[4] size (headline); dir100k = configs[1]; mixed100k = configs[2]; "
+                         "batch50k = configs[3] (8 independent 50k-node meshes per GPU, concurrent streams)")
+    ap.add_argument("--nodes", type=int, default=None, help="override the preset's per-mesh node count")
+    ap.add_argument("--bc", choices=["dirichlet", "mixed"], default=None)
+    ap.add_argument("--meshes-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -102,22 +114,31 @@ def main():
     nat = importlib.import_module("psi-gnn_amd._native")
     model_mod = importlib.import_module("psi-gnn_amd.mixed" if args.bc == "mixed" else "psi-gnn_amd.model_psignn")
 
+    nodes_p, bc_p, mpg_p, cfg_name = WORKLOADS[args.workload]
+    nodes = args.nodes or nodes_p
+    args.bc = args.bc or bc_p
+    MPG = args.meshes_per_gpu or mpg_p
     mixed = args.bc == "mixed"
-    n = pkg.data.hex_n_for_nodes(args.nodes)
-    if 3 * (n - 1) ** 2 + 3 * (n - 1) + 1 >= 0.999 * args.nodes:
-        n -= 1  # 999 919 counts as "100k"
+    n = pkg.data.hex_n_for_nodes(nodes)
+    if 3 * (n - 1) ** 2 + 3 * (n - 1) + 1 >= 0.999 * nodes:
+        n -= 1  # 99 919 counts as "100k"
     t0 = time.time()
-    mesh = pkg.data.make_hex_problem(n, seed=rank, mixed=mixed, compute_sol=False)
-    N, E = mesh.num_nodes, mesh.num_edges
     sd = load_weights(args.bc)
     net = model_mod.ModelPSIGNN(dict(latent_dim=10, n_layers=1)).eval()
     net.load_state_dict(sd)
     net = net.to(dev)
-    md = mesh.to(dev)
-    with torch.no_grad():
-        h0 = net.autoencoder.encoder(md.x)
-        fmap = net.deqdss.f.bind(h0, md)
+    meshes, fmaps = [], []
+    for j in range(MPG):  # independent problems: own seed, same topology (phase-shifted warp)
+        m = pkg.data.make_hex_problem(n, seed=rank * MPG + j, mixed=mixed, compute_sol=False, phase=0.37 * j)
+        md = m.to(dev)
+        with torch.no_grad():
+            h0 = net.autoencoder.encoder(md.x)
+            fmaps.append(net.deqdss.f.bind(h0, md))
+        meshes.append(m)
+    mesh, fmap = meshes[0], fmaps[0]
+    N, E = mesh.num_nodes, mesh.num_edges
     Ep = fmap.plan.Ep
+    Ep_rank = sum(f.plan.Ep for f in fmaps)
     t_setup = time.time() - t0
     K, W = args.steps, args.warmup
 
@@ -127,41 +148,59 @@ def main():
         ws.solve(fmap, eps=0.0)
         ws.close()
         del ws
-    solver = eng.DeviceBroyden(plan=fmap.plan, threshold=K, keep_trace=False)
+    solvers = [eng.DeviceBroyden(plan=f.plan, threshold=K, keep_trace=False) for f in fmaps]
+    solver = solvers[0]
+    streams = [torch.cuda.Stream(dev) for _ in range(MPG)] if MPG > 1 else [None]
 
-    # ---- timed region: exactly K iterations
+    def run_all():
+        """Exactly K Broyden iterations on every mesh of this rank; meshes run on their own HIP streams."""
+        if MPG == 1:
+            return [solver.solve(fmap, eps=0.0, poll_every=max(K, 1))]
+        import concurrent.futures as cf
+
+        def one(j):
+            torch.cuda.set_device(local)
+            with torch.cuda.stream(streams[j]):
+                return solvers[j].solve(fmaps[j], eps=0.0, poll_every=max(K, 1))
+        with cf.ThreadPoolExecutor(MPG) as ex:  # ctypes releases the GIL inside the library calls
+            return list(ex.map(one, range(MPG)))
+
+    # ---- timed region: exactly K iterations (per mesh)
     barrier()
     t0 = time.perf_counter()
-    out = solver.solve(fmap, eps=0.0, poll_every=max(K, 1))
+    outs = run_all()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier()
-    assert out["n_iter"] == K, f"solver stopped after {out['n_iter']} of {K} iterations (reason {out['stop_reason']})"
-    assert np.all(np.isfinite(out["rel_trace"][:K]))
+    out = outs[0]
+    for o in outs:
+        assert o["n_iter"] == K, f"solver stopped after {o['n_iter']} of {K} iterations (reason {o['stop_reason']})"
+        assert np.all(np.isfinite(o["rel_trace"][:K]))
     t_max = elapsed
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_max = float(t.item())
-    iters_per_s = world * K / t_max
-    edges_per_s = world * Ep * K / t_max
+    iters_per_s = world * MPG * K / t_max
+    edges_per_s = world * Ep_rank * K / t_max
 
     per_launch, dots_b, axpy_b, total_iter_bytes = algorithmic_bytes(N, Ep, K, mixed)
     result = {
-        "metric": "fixed-point edges/sec (E' x Broyden iterations/sec) on 1M-node Poisson mesh",
+        "metric": "fixed-point edges/sec (E' x Broyden iterations/sec) on 1M-node Poisson mesh" if args.workload == "mesh1m"
+                  else f"fixed-point edges/sec (E' x Broyden iterations/sec), workload {args.workload}",
         "value": edges_per_s, "unit": "edges/s", "iters_per_sec": iters_per_s,
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * t_max / K,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.bc}/psignn single {N}-node hexagon Poisson mesh per GPU "
-                               f"(BASELINE configs[4] size), on-device Broyden iterations 1..{K}, trained checkpoint weights",
+        "config": {"workload": f"{args.workload}: {args.bc}/psignn, {MPG} x {N}-node hexagon Poisson mesh per GPU "
+                               f"(BASELINE {cfg_name}), on-device Broyden iterations 1..{K} per mesh, trained checkpoint weights",
                    "nodes": N, "edges_nonself": Ep, "edges_total": E, "solver": "broyden", "latent_dim": D,
-                   "meshes_per_gpu": 1, "parallelism": f"independent meshes x{world}",
+                   "meshes_per_gpu": MPG, "parallelism": f"independent meshes x{world * MPG}, {MPG} concurrent streams per GPU",
                    "tiled_plan": bool(fmap.plan.tiled), "tiles": fmap.plan.n_tiles,
                    "max_tile_rows": fmap.plan.max_tile_rows, "ell_rows": fmap.plan.ell_rows},
         "rel_residual_after_K": out["rel_trace"][K - 1], "setup_s": round(t_setup, 2),
         "broyden_state_bytes": solver.nbytes,
-        "roofline_iter": {"bound": "hbm", "achieved": total_iter_bytes / elapsed / 1e9, "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "frac": total_iter_bytes / elapsed / 1e9 / HBM_PEAK_GBS,
+        "roofline_iter": {"bound": "hbm", "achieved": MPG * total_iter_bytes / elapsed / 1e9, "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": MPG * total_iter_bytes / elapsed / 1e9 / HBM_PEAK_GBS,
                           "note": "sum of algorithmic bytes of all kernels in the K iterations / wall time of this rank"},
     }
 
@@ -217,10 +256,11 @@ def main():
                 result["roofline_f"]["traffic"] = t.get(fr["kernel"])
             except Exception:
                 pass
-    solver.close()
+    for sv in solvers:
+        sv.close()
 
     # ---- CPU baseline: the oracle (port of the reference path) on this box's host cores, bounded sample
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and MPG == 1 and not args.no_cpu_baseline:
         from oracle import psignn_oracle as orc
         cores = os.cpu_count() or 1
         torch.set_num_threads(cores)

@@ -1,0 +1,48 @@
+"""Independent meshes across the GPUs of one node: one process per GPU, no data-path collective.
+
+The reference's only parallelism is ``torch_geometric.nn.DataParallel`` (``dirichlet/psignn/main.py:106``):
+a list of graphs is split over devices, and the per-replica scalar losses are averaged
+(``training_class.py:156-159``).  Meshes are independent fixed-point problems, so inference shards them
+round-robin over ranks and every rank solves its own; the only collective that exists on the reference's path —
+the loss mean over replicas — is one tiny all-reduce (RCCL over xGMI on GPUs, gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+import torch
+
+
+def shard_indices(n_items: int, rank: int, world: int):
+    """Round-robin ownership: item i belongs to rank i % world (BASELINE configs[3]: 64 meshes, 8 per GPU)."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world {world}")
+    return list(range(rank, n_items, world))
+
+
+def solve_shard(model, meshes, device, indices=None):
+    """Solve the given meshes one after the other on `device`; returns [(index, u_final, loss_dic)]."""
+    out = []
+    for i in (range(len(meshes)) if indices is None else indices):
+        u, loss = model(meshes[i].to(device))
+        out.append((i, u, loss))
+    return out
+
+
+def mean_over_replicas(values: dict, group=None) -> dict:
+    """All-reduce(SUM) / world of a dict of scalar tensors: ``loss.mean()`` over DataParallel replicas
+    (``training_class.py:156-159``).  One flat tensor, one collective."""
+    import torch.distributed as dist
+    keys = sorted(values)
+    flat = torch.stack([torch.as_tensor(values[k], dtype=torch.float32).reshape(()) for k in keys])
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat = flat / dist.get_world_size(group)
+    return {k: flat[i] for i, k in enumerate(keys)}
+
+
+def gather_counts(local_count: int, device=None, group=None):
+    """Sum of a per-rank integer (meshes / iterations / edges processed) over ranks."""
+    import torch.distributed as dist
+    t = torch.tensor([float(local_count)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t.item())

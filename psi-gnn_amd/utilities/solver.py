@@ -174,3 +174,71 @@ def newton(f, z0, eps=1.e-5, threshold=50):
     r = forward_iteration(g, z0, eps=eps, threshold=threshold)
     return {"result": r["result"], "lowest": r["lowest"], "rel_trace": r["rel_trace"], "abs_trace": r["abs_trace"],
             "xest_trace": r["xest_trace"], "nstep": r["nstep"], "eps": eps, "threshold": threshold}
+
+
+def newton_krylov(f, x0, threshold=30, eps=1e-5, inner_m=30, inner_tol=1e-2, **kwargs):
+    """Jacobian-free Newton-Krylov on g(x) = f(x) - x with the ANALYTIC Jacobian-vector product.
+
+    The reference imports ``scipy.optimize.newton_krylov`` (utilities/solver.py:6) but never calls it, so
+    there is no reference implementation; the dict keys follow ``broyden``.  Outer Newton step:
+    solve (J_f(x) - I) dx = -g(x) with restarted-free GMRES(inner_m) to relative tolerance ``inner_tol``
+    (inexact Newton), x <- x + dx.  ``rel = |g|/(|f(x)| + 1e-9)`` as in broyden; ``nstep`` counts outer
+    iterations, ``n_feval`` f + JVP evaluations (the unit comparable to one Broyden iteration).
+    With fp32 finite-difference JVPs scipy's solver does not converge on this problem; the
+    analytic JVP kernel (psignn_f_jvp) is what makes the method usable in fp32.
+    """
+    if not isinstance(f, FixedPointMap):
+        raise nat.NativeError("newton_krylov needs the analytic JVP of a FixedPointMap")
+    nat.require_cuda(x0, "x0")
+    x = x0.clone()
+    fx = f(x)
+    g = fx - x
+    trace = {"abs": [], "rel": []}
+    n_feval = 1
+    lowest, lowest_x, lowest_step = 1e8, x, 0
+    xest_trace = [x]
+    nstep = 0
+    for nstep in range(1, threshold + 1):
+        # GMRES on A dx = b, A v = J_f v - v, b = -g
+        b = -g.reshape(-1)
+        beta = torch.linalg.norm(b)
+        m = inner_m
+        V = torch.zeros(m + 1, b.numel(), device=b.device, dtype=b.dtype)
+        Hm = torch.zeros(m + 1, m, device=b.device, dtype=torch.float64)
+        V[0] = b / beta
+        e1 = torch.zeros(m + 1, device=b.device, dtype=torch.float64)
+        e1[0] = float(beta)
+        k_used, y = 0, None
+        for k in range(m):
+            w = (f.jvp(x, V[k].reshape(x.shape)) - V[k].reshape(x.shape)).reshape(-1)
+            n_feval += 1
+            h = V[:k + 1] @ w                      # classical Gram-Schmidt, twice
+            w = w - h @ V[:k + 1]
+            h2 = V[:k + 1] @ w
+            w = w - h2 @ V[:k + 1]
+            Hm[:k + 1, k] = (h + h2).double()
+            hn = torch.linalg.norm(w)
+            Hm[k + 1, k] = float(hn)
+            k_used = k + 1
+            y = torch.linalg.lstsq(Hm[:k + 2, :k + 1], e1[:k + 2, None]).solution[:, 0]
+            res = torch.linalg.norm(Hm[:k + 2, :k + 1] @ y - e1[:k + 2])
+            if float(hn) < 1e-30 or float(res) <= inner_tol * float(beta):
+                break
+            V[k + 1] = w / hn
+        dx = (y.to(b.dtype) @ V[:k_used]).reshape(x.shape)
+        x = x + dx
+        fx = f(x)
+        n_feval += 1
+        g = fx - x
+        abs_diff = torch.linalg.norm(g).item()
+        rel_diff = abs_diff / (torch.linalg.norm(fx).item() + 1e-9)
+        trace["abs"].append(abs_diff)
+        trace["rel"].append(rel_diff)
+        xest_trace.append(x)
+        if rel_diff < lowest:
+            lowest, lowest_x, lowest_step = rel_diff, x, nstep
+        if rel_diff < eps:
+            break
+    return {"result": lowest_x, "lowest": lowest, "nstep": lowest_step, "prot_break": False,
+            "abs_trace": trace["abs"], "rel_trace": trace["rel"], "xest_trace": xest_trace, "eps": eps,
+            "threshold": threshold, "n_feval": n_feval, "n_outer": nstep}

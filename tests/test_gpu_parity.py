@@ -463,3 +463,44 @@ def test_tiling_without_coordinates_and_fallback(dev):
     got = fm3(x[sc.to(dev)])
     assert rel_l2(got, want[sc.to(dev)]) < 1e-6
     assert p3.max_tile_rows == 0 or p3.max_tile_rows <= 256 + 512
+
+
+# ------------------------------------------------------------------------------------------ other solvers
+def test_newton_krylov_with_analytic_jvp(dev):
+    """Config 5 path: Newton-Krylov on the analytic JVP converges in fp32 to the Broyden / fp64 fixed point
+    (scipy's finite-difference newton_krylov does not)."""
+    g, mesh, md, sd, fmap = bind("hex13_dirichlet_s0", dev)
+    solver = pkg("utilities.solver")
+    out = solver.newton_krylov(fmap, fmap.h0, threshold=40, eps=1e-7, inner_m=40)
+    assert out["lowest"] < 1e-7
+    assert rel_l2(out["result"], g["fp64_result"]) < 1e-5
+    assert out["n_feval"] < 1500
+    assert set(solver.broyden(fmap, fmap.h0, threshold=5, eps=1e-3)) >= {"result", "lowest", "nstep", "rel_trace"}
+
+
+def test_forward_iteration_anderson_newton(dev):
+    """The other solvers of utilities/solver.py against the oracle run on the same f."""
+    g, mesh, md, sd, fmap = bind("hex13_dirichlet_s0", dev)
+    solver = pkg("utilities.solver")
+    out = solver.forward_iteration(fmap, fmap.h0, eps=1e-5, threshold=60)
+    assert out["nstep"] == int(g["fwd_nstep"])
+    assert rel_l2(out["result"], g["fwd_result"]) < 1e-5
+    np.testing.assert_allclose([float(t) for t in out["rel_trace"]], g["fwd_rel_trace"], rtol=2e-3)
+    out = solver.anderson(fmap, fmap.h0, threshold=80, eps=1e-5)
+    assert abs(out["nstep"] - int(g["anderson_nstep"])) <= 3
+    np.testing.assert_allclose(out["rel_trace"][:5], g["anderson_rel_trace"][:5], rtol=1e-2)
+    assert rel_l2(out["result"], g["anderson_result"]) < 1e-3
+    # block-diagonal Newton: the analytic blocks equal autograd's blocks on a tiny mesh
+    data, eng = pkg("data"), pkg("engine")
+    small = data.make_hex_problem(2, seed=0)
+    h0 = orc.encoder(sd, small.x)
+    fm = eng.FixedPointMap(eng.MeshPlan(small.to(dev)), eng.PackedWeights(sd, dev), h0.to(dev), small.prb_data.to(dev))
+    nb = pkg("utilities.newton_blocks")
+    z = torch.randn(small.num_nodes, 10, generator=torch.Generator().manual_seed(2))
+    B = nb.node_jacobian_blocks(fm, z.to(dev)).cpu()
+    J = torch.autograd.functional.jacobian(lambda H: orc.function_forward(sd, H, h0, small), z)
+    want = torch.einsum("bibj->bij", J)
+    assert rel_l2(B, want) < 1e-4
+    ref = orc.newton(lambda H: orc.function_forward(sd, H, h0, small), h0.clone(), eps=1e-4, threshold=4)
+    got = solver.newton(fm, fm.h0, eps=1e-4, threshold=4)
+    assert got["nstep"] == ref["nstep"] and rel_l2(got["result"], ref["result"]) < 1e-3

@@ -1,0 +1,68 @@
+"""CPU, gloo, world_size 2: the N > 1 path of the batch driver (sharding of independent meshes, the loss mean
+over replicas, max-over-ranks timing as bench.py does it).  No GPU work: per-mesh results are stand-ins."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import pkg
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_meshes, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    batch = pkg("batch")
+    mine = batch.shard_indices(n_meshes, rank, world)
+    # stand-in per-mesh "residual": a function of the mesh index only
+    local = {"residual_loss": torch.tensor(sum(float(i + 1) for i in mine) / max(len(mine), 1)),
+             "mse_loss": torch.tensor(float(rank))}
+    mean = batch.mean_over_replicas(local)
+    total = batch.gather_counts(len(mine))
+    t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
+    dist.barrier()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    q.put((rank, mine, {k: float(v) for k, v in mean.items()}, total, float(t)))
+    dist.destroy_process_group()
+
+
+def test_shards_cover_all_meshes_once():
+    batch = pkg("batch")
+    for n, w in ((64, 8), (5, 2), (3, 4), (0, 2)):
+        shards = [batch.shard_indices(n, r, w) for r in range(w)]
+        flat = sorted(i for s in shards for i in s)
+        assert flat == list(range(n))
+        assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+    assert [len(batch.shard_indices(64, r, 8)) for r in range(8)] == [8] * 8  # BASELINE configs[3]
+
+
+def test_two_ranks_gloo():
+    world, n_meshes = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_meshes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, m0, mean0, tot0, t0), (r1, m1, mean1, tot1, t1) = res
+    assert m0 == [0, 2, 4] and m1 == [1, 3]
+    assert tot0 == tot1 == n_meshes
+    # mean over replicas of the per-replica means, as DataParallel's loss.mean() (training_class.py:156-159)
+    want = 0.5 * ((1 + 3 + 5) / 3 + (2 + 4) / 2)
+    assert abs(mean0["residual_loss"] - want) < 1e-6 and mean0 == mean1
+    assert abs(mean0["mse_loss"] - 0.5) < 1e-6
+    assert t0 == t1 == 0.2  # max over ranks
