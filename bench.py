@@ -112,13 +112,13 @@ def main():
     pkg = importlib.import_module("psi-gnn_amd")
     eng = importlib.import_module("psi-gnn_amd.engine")
     nat = importlib.import_module("psi-gnn_amd._native")
-    model_mod = importlib.import_module("psi-gnn_amd.mixed" if args.bc == "mixed" else "psi-gnn_amd.model_psignn")
 
     nodes_p, bc_p, mpg_p, cfg_name = WORKLOADS[args.workload]
     nodes = args.nodes or nodes_p
     args.bc = args.bc or bc_p
     MPG = args.meshes_per_gpu or mpg_p
     mixed = args.bc == "mixed"
+    model_mod = importlib.import_module("psi-gnn_amd.mixed" if mixed else "psi-gnn_amd.model_psignn")
     n = pkg.data.hex_n_for_nodes(nodes)
     if 3 * (n - 1) ** 2 + 3 * (n - 1) + 1 >= 0.999 * nodes:
         n -= 1  # 99 919 counts as "100k"
