@@ -109,8 +109,29 @@ __device__ __forceinline__ float edge_pass(const uint4* __restrict__ slots, int 
   return deg;
 }
 
-template <int P, bool MIXED>
-__global__ __launch_bounds__(256) void k_f_tile(int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
+// Broyden fusion (solver.hip): the kernel forms x_next = x_cur + update while loading, and its epilogue
+// writes x_next, g_new = f(x_next) - x_next, dg = g_new - g_old and the per-wave partials of |g_new|^2, |f|^2
+// -- the work of k_xnext and k_resid without their extra passes over the state vectors.
+struct FuseArgs {
+  const float* upd;   // update vector, plan order
+  float* gx;          // in: g_old, out: g_new
+  float* dg;          // out
+  float* xbuf;        // iterate buffers (stride M)
+  const int32_t* st;  // device status block (int32 view)
+  int off_done, off_cur, off_nxt;
+  int64_t M;
+  float* part;
+  int npart;
+};
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int P, bool MIXED, bool FUSED>
+__global__ __launch_bounds__(256) void k_f_tile(FuseArgs fa, int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
                                                 const int32_t* __restrict__ tile_slice, const int32_t* __restrict__ halo,
                                                 const int32_t* __restrict__ halo_cnt, const int32_t* __restrict__ slice_off,
                                                 const uint8_t* __restrict__ slice_deg, const uint4* __restrict__ ell,
@@ -126,12 +147,14 @@ __global__ __launch_bounds__(256) void k_f_tile(int n_tiles, int chunk, const in
   // neighbouring tiles' halo rows hit the same L2.  Speed only; any mapping is correct.
   const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (tile >= n_tiles) return;
+  if (FUSED && fa.st[fa.off_done]) return;
   const int tid = threadIdx.x;
   const int32_t t0 = tile_ptr[tile];
   const int n_t = tile_ptr[tile + 1] - t0;
   const int n_h = halo_cnt[tile];
   const int32_t* hl = halo + (int64_t)tile * HALO_CAP;
   if (hsel) h += (int64_t)(*hsel) * hstride;
+  if (FUSED) h = fa.xbuf + (int64_t)fa.st[fa.off_cur] * fa.M;
 
   const float* Wto = W + lofs + L::L_TO;
   const float* Wfr = W + lofs + L::L_FROM;
@@ -143,6 +166,12 @@ __global__ __launch_bounds__(256) void k_f_tile(int n_tiles, int chunk, const in
     const int64_t node = row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t];
     float xr[D], ta[D], tb[D];
     load10(h + node * D, xr);
+    if (FUSED) {  // x_next = x_cur + update (line_search with on=False: step 1, solver.py:85-94)
+      float ur[D];
+      load10(fa.upd + node * D, ur);
+#pragma unroll
+      for (int o = 0; o < D; ++o) xr[o] += ur[o];
+    }
     if (row == tid) {
 #pragma unroll
       for (int o = 0; o < D; ++o) x[o] = xr[o];
@@ -156,17 +185,22 @@ __global__ __launch_bounds__(256) void k_f_tile(int n_tiles, int chunk, const in
     }
   }
   __syncthreads();
-  if (tid >= n_t) return;
+  if (!FUSED && tid >= n_t) return;
 
   // ---- stage 2: one tile node per lane
-  const int64_t n = (int64_t)t0 + tid;
+  const bool active = tid < n_t;
+  const int64_t n = (int64_t)t0 + (active ? tid : 0);
   const uint8_t fl = flags[n];
-  if (fl & FLAG_DIRICHLET) {  // Dirichlet rows <- h_initial rows (model.py:298)
-    float r[D];
-    load10(h0 + n * D, r);
-    store10(out + n * D, r);
-    return;
+  float y[D];
+  const bool dirichlet = fl & FLAG_DIRICHLET;
+  if (dirichlet) {  // Dirichlet rows <- h_initial rows (model.py:298)
+    load10(h0 + n * D, y);
+    if (!FUSED) {
+      store10(out + n * D, y);
+      return;
+    }
   }
+  if (!dirichlet && active) {
   const int lane = tid & 63;
   const int slice = tile_slice[tile] + (tid >> 6);
   const uint4* slots = ell + (int64_t)slice_off[slice] * 64 + lane;
@@ -187,7 +221,6 @@ __global__ __launch_bounds__(256) void k_f_tile(int n_tiles, int chunk, const in
   matvec10<D, true>(Wfr + L::PHI_W1, L::EIN, 0, x, Pi);
   const float deg_out = edge_pass<RS, D, SLOT_OUT>(slots, nslots, lds, Wfr + L::PHI_W1 + 2 * D, L::EIN, Pi, S_fr);
 
-  float y[D];
   if (MIXED && (fl & FLAG_NEUMANN)) {
     // Phi_neumann (Phi_from type: out-edges) + update_neumann: the row is REPLACED (mixed/psignn/model.py:236,241)
     const float* Un = W + unofs;
@@ -267,7 +300,33 @@ __global__ __launch_bounds__(256) void k_f_tile(int n_tiles, int chunk, const in
 #pragma unroll
     for (int o = 0; o < D; ++o) y[o] = fmaf((y[o] - mu) * rs, W[L::LN_G + o], W[L::LN_B + o]);
   }
-  store10(out + n * D, y);
+  }  // !dirichlet && active
+  if (!FUSED) {
+    store10(out + n * D, y);
+    return;
+  }
+  // ---- fused Broyden epilogue
+  float sg = 0.f, sf = 0.f;
+  if (active) {
+    float go[D], gn[D];
+    load10(fa.gx + n * D, go);
+#pragma unroll
+    for (int o = 0; o < D; ++o) {
+      gn[o] = y[o] - x[o];
+      sg = fmaf(gn[o], gn[o], sg);
+      sf = fmaf(y[o], y[o], sf);
+      go[o] = gn[o] - go[o];
+    }
+    store10(fa.gx + n * D, gn);
+    store10(fa.dg + n * D, go);
+    store10(fa.xbuf + (int64_t)fa.st[fa.off_nxt] * fa.M + n * D, x);
+  }
+  sg = wave_sum_f(sg);
+  sf = wave_sum_f(sf);
+  if ((tid & 63) == 0) {
+    fa.part[tile * 4 + (tid >> 6)] = sg;
+    fa.part[fa.npart + tile * 4 + (tid >> 6)] = sf;
+  }
 }
 
 // gather of node rows between the caller's numbering and the plan order: dst[i] = src[map[i]]
@@ -292,8 +351,8 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
   if (p->mixed) {
     using L = WLayout<3>;
     size_t lds = (size_t)p->max_rows * TileRow<true>::RS * 4;
-    LAUNCH("k_f_tile", st, (k_f_tile<3, true><<<grid, 256, lds, st>>>(
-        (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
+    LAUNCH("k_f_tile", st, (k_f_tile<3, true, false><<<grid, 256, lds, st>>>(
+        FuseArgs{}, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
         p->flags_p, W, L::layer(nl - 1), L::phi_neu(nl), L::upd_neu(nl), nl, 1, h, hsel, hstride, h0, prb, nrm, out)));
   } else {
     using L = WLayout<2>;
@@ -303,14 +362,42 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
     const float* cur = h;
     for (int l = 0; l < nl; ++l) {
       float* dst = (l == nl - 1) ? out : pp[l & 1];
-      LAUNCH("k_f_tile", st, (k_f_tile<2, false><<<grid, 256, lds, st>>>(
-          (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
+      LAUNCH("k_f_tile", st, (k_f_tile<2, false, false><<<grid, 256, lds, st>>>(
+          FuseArgs{}, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
           p->flags_p, W, L::layer(l), 0, 0, nl, l == nl - 1, cur, l == 0 ? hsel : nullptr, hstride, h0, prb, nrm, dst)));
       cur = dst;
     }
   }
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
+}
+
+// Fused Broyden step (single-layer models): x_next = x_cur + upd, f(x_next), g/dg/x_next/norm partials.
+// Returns the number of partial entries per norm (n_tiles * 4), or a negative error.
+int psignn_f_tile_fused(const psignn_plan* p, const float* W, int nl, float* xbuf, int64_t M, const int32_t* st_words,
+                        int off_done, int off_cur, int off_nxt, const float* upd, float* gx, float* dg,
+                        const float* h0, const float* prb, const float* nrm, float* part, hipStream_t st) {
+  ARG_CHECK(p && p->tiled, "plan has no tile structures");
+  ARG_CHECK(nl == 1 || p->mixed, "fused step supports single-layer evaluation");
+  const int chunk = (int)cdiv(p->n_tiles, 8);
+  const unsigned grid = (unsigned)(chunk * 8);
+  const int npart = (int)p->n_tiles * 4;
+  FuseArgs fa{upd, gx, dg, xbuf, st_words, off_done, off_cur, off_nxt, M, part, npart};
+  if (p->mixed) {
+    using L = WLayout<3>;
+    size_t lds = (size_t)p->max_rows * TileRow<true>::RS * 4;
+    LAUNCH("k_f_tile_fused", st, (k_f_tile<3, true, true><<<grid, 256, lds, st>>>(
+        fa, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
+        p->flags_p, W, L::layer(nl - 1), L::phi_neu(nl), L::upd_neu(nl), nl, 1, xbuf, nullptr, 0, h0, prb, nrm, nullptr)));
+  } else {
+    using L = WLayout<2>;
+    size_t lds = (size_t)p->max_rows * TileRow<false>::RS * 4;
+    LAUNCH("k_f_tile_fused", st, (k_f_tile<2, false, true><<<grid, 256, lds, st>>>(
+        fa, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
+        p->flags_p, W, L::layer(0), 0, 0, nl, 1, xbuf, nullptr, 0, h0, prb, nrm, nullptr)));
+  }
+  HIP_TRY(hipGetLastError());
+  return npart;
 }
 
 // dst[new] = src[perm[new]]  (to_plan = 1)   or   dst[old] = src[inv[old]]  (to_plan = 0); rows of `cols` floats

@@ -18,9 +18,9 @@
 #include <math.h>
 #include <vector>
 
-#define VEC 16           // elements per thread in the vector kernels
+// The vector kernels are templated on VEC = elements per thread (16 for long vectors, 4 when N*d is small so that
+// the grid still covers the 256 CUs; chosen at solver creation).
 #define TB 256           // threads per block
-#define CHUNK (VEC * TB) // 4096 elements per block
 
 struct Status {
   int32_t n_iter;       // iterations done
@@ -42,6 +42,7 @@ struct psignn_broyden {
   int seq_len = D;
   int thr = 0;
   int keep_trace = 0;
+  int vec = 16;             // elements per thread of the vector kernels
   int nblk = 0, npart = 0;
   float *U = nullptr, *V = nullptr;
   float* xbuf = nullptr;    // (thr+2, M) with trace, else (3, M)
@@ -62,31 +63,26 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ void ld16(const float* __restrict__ p, float* r) {
-  const float4* q = reinterpret_cast<const float4*>(p);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float4 t = q[i];
-    r[4 * i] = t.x; r[4 * i + 1] = t.y; r[4 * i + 2] = t.z; r[4 * i + 3] = t.w;
-  }
-}
-__device__ __forceinline__ void st16(float* __restrict__ p, const float* r) {
-  float4* q = reinterpret_cast<float4*>(p);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) q[i] = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
-}
-// Tail-safe vector access: each thread owns VEC consecutive elements starting at e0.
+template <int VEC>
 __device__ __forceinline__ void ldv(const float* __restrict__ p, int64_t e0, int64_t M, float* r) {
   if (e0 + VEC <= M) {
-    ld16(p + e0, r);
-  } else {
+    const float4* q = reinterpret_cast<const float4*>(p + e0);
+#pragma unroll
+    for (int i = 0; i < VEC / 4; ++i) {
+      float4 t = q[i];
+      r[4 * i] = t.x; r[4 * i + 1] = t.y; r[4 * i + 2] = t.z; r[4 * i + 3] = t.w;
+    }
+  } else {  // tail
 #pragma unroll
     for (int i = 0; i < VEC; ++i) r[i] = (e0 + i < M) ? p[e0 + i] : 0.f;
   }
 }
+template <int VEC>
 __device__ __forceinline__ void stv(float* __restrict__ p, int64_t e0, int64_t M, const float* r) {
   if (e0 + VEC <= M) {
-    st16(p + e0, r);
+    float4* q = reinterpret_cast<float4*>(p + e0);
+#pragma unroll
+    for (int i = 0; i < VEC / 4; ++i) q[i] = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
   } else {
 #pragma unroll
     for (int i = 0; i < VEC; ++i)
@@ -107,21 +103,23 @@ __global__ void k_init_status(Status* st, double* rel_trace, double* abs_trace, 
 }
 
 // gx = fx0 - x0 ; upd = gx ; xbuf[0] = x0
+template <int VEC>
 __global__ __launch_bounds__(TB) void k_begin(int64_t M, const float* __restrict__ x0, const float* __restrict__ fx0,
                                               float* __restrict__ xb, float* __restrict__ gx, float* __restrict__ upd) {
   int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
   if (e0 >= M) return;
   float a[VEC], b[VEC];
-  ldv(x0, e0, M, a);
-  ldv(fx0, e0, M, b);
-  stv(xb, e0, M, a);
+  ldv<VEC>(x0, e0, M, a);
+  ldv<VEC>(fx0, e0, M, b);
+  stv<VEC>(xb, e0, M, a);
 #pragma unroll
   for (int i = 0; i < VEC; ++i) b[i] -= a[i];
-  stv(gx, e0, M, b);
-  stv(upd, e0, M, b);
+  stv<VEC>(gx, e0, M, b);
+  stv<VEC>(upd, e0, M, b);
 }
 
 // x_next = x_cur + upd   (line_search with on=False: s = 1, solver.py:85-94)
+template <int VEC>
 __global__ __launch_bounds__(TB) void k_xnext(int64_t M, const Status* __restrict__ st, float* __restrict__ xb,
                                               const float* __restrict__ upd, float* __restrict__ copy_out) {
   if (st->done) return;
@@ -130,15 +128,16 @@ __global__ __launch_bounds__(TB) void k_xnext(int64_t M, const Status* __restric
   const float* xc = xb + (int64_t)st->cur * M;
   float* xn = xb + (int64_t)st->nxt * M;
   float a[VEC], b[VEC];
-  ldv(xc, e0, M, a);
-  ldv(upd, e0, M, b);
+  ldv<VEC>(xc, e0, M, a);
+  ldv<VEC>(upd, e0, M, b);
 #pragma unroll
   for (int i = 0; i < VEC; ++i) a[i] += b[i];
-  stv(xn, e0, M, a);
-  if (copy_out) stv(copy_out, e0, M, a);
+  stv<VEC>(xn, e0, M, a);
+  if (copy_out) stv<VEC>(copy_out, e0, M, a);
 }
 
 // g_new = fx - x_next ; dg = g_new - g ; g = g_new ; per-wave partials of |g_new|^2 and |fx|^2
+template <int VEC>
 __global__ __launch_bounds__(TB) void k_resid(int64_t M, const Status* __restrict__ st, const float* __restrict__ xb,
                                               const float* __restrict__ fx, float* __restrict__ gx,
                                               float* __restrict__ dg, float* __restrict__ part, int npart) {
@@ -148,9 +147,9 @@ __global__ __launch_bounds__(TB) void k_resid(int64_t M, const Status* __restric
   if (e0 < M) {
     const float* xn = xb + (int64_t)st->nxt * M;
     float x[VEC], f[VEC], g[VEC];
-    ldv(xn, e0, M, x);
-    ldv(fx, e0, M, f);
-    ldv(gx, e0, M, g);
+    ldv<VEC>(xn, e0, M, x);
+    ldv<VEC>(fx, e0, M, f);
+    ldv<VEC>(gx, e0, M, g);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       float gn = f[i] - x[i];
@@ -159,8 +158,8 @@ __global__ __launch_bounds__(TB) void k_resid(int64_t M, const Status* __restric
       g[i] = gn - g[i];
       x[i] = gn;
     }
-    stv(gx, e0, M, x);
-    stv(dg, e0, M, g);
+    stv<VEC>(gx, e0, M, x);
+    stv<VEC>(dg, e0, M, g);
   }
   sg = wave_sum(sg);
   sf = wave_sum(sf);
@@ -172,8 +171,16 @@ __global__ __launch_bounds__(TB) void k_resid(int64_t M, const Status* __restric
 }
 
 __device__ double block_sum_partials(const float* __restrict__ p, int n, double* sh) {
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += TB) s += (double)p[i];
+  // fixed summation shape (lane-strided, 4 independent accumulators, then a tree): reproducible, and the
+  // loads of one lane do not wait on each other (a dependent scalar loop here cost 20-30 us per call)
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * TB < n; i += 4 * TB) {
+    float a = p[i], b = p[i + TB], c = p[i + 2 * TB], d = p[i + 3 * TB];
+    s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
+  }
+  for (; i < n; i += TB) s0 += (double)p[i];
+  double s = (s0 + s1) + (s2 + s3);
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int o = TB / 2; o > 0; o >>= 1) {
@@ -247,6 +254,7 @@ __global__ __launch_bounds__(TB) void k_check(Status* st, const float* __restric
 }
 
 // dots pass: per-wave partials of a_j = dx.U_j, c_j = V_j.dg, b_j = V_j.g   for j < k
+template <int VEC>
 __global__ __launch_bounds__(TB) void k_dots(int64_t M, int k, const Status* __restrict__ st,
                                              const float* __restrict__ U, const float* __restrict__ V,
                                              const float* __restrict__ dxv, const float* __restrict__ dgv,
@@ -256,9 +264,9 @@ __global__ __launch_bounds__(TB) void k_dots(int64_t M, int k, const Status* __r
   float dx[VEC], dg[VEC], g[VEC];
   bool act = e0 < M;
   if (act) {
-    ldv(dxv, e0, M, dx);
-    ldv(dgv, e0, M, dg);
-    ldv(gv, e0, M, g);
+    ldv<VEC>(dxv, e0, M, dx);
+    ldv<VEC>(dgv, e0, M, dg);
+    ldv<VEC>(gv, e0, M, g);
   } else {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) dx[i] = dg[i] = g[i] = 0.f;
@@ -269,8 +277,8 @@ __global__ __launch_bounds__(TB) void k_dots(int64_t M, int k, const Status* __r
     float u[VEC], v[VEC];
     float sa = 0.f, sc = 0.f, sb = 0.f;
     if (act) {
-      ldv(U + (int64_t)j * M, e0, M, u);
-      ldv(V + (int64_t)j * M, e0, M, v);
+      ldv<VEC>(U + (int64_t)j * M, e0, M, u);
+      ldv<VEC>(V + (int64_t)j * M, e0, M, v);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         sa = fmaf(dx[i], u[i], sa);
@@ -300,6 +308,7 @@ __global__ __launch_bounds__(TB) void k_reduce(const Status* __restrict__ st, co
 }
 
 // axpy pass.  Writes vT (NaN->0) to V[k], D1 to U[k] (unscaled), D2 to upd, partials of vT.dg, vT.g
+template <int VEC>
 __global__ __launch_bounds__(TB) void k_axpy(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
                                              float* __restrict__ V, float* __restrict__ upd /* in: dx, out: D2 */,
                                              const float* __restrict__ dgv, const float* __restrict__ gv,
@@ -309,9 +318,9 @@ __global__ __launch_bounds__(TB) void k_axpy(int64_t M, int k, const Status* __r
   float p1 = 0.f, p2 = 0.f;
   if (e0 < M) {
     float av[VEC], a1[VEC], a2[VEC], dg[VEC], g[VEC];
-    ldv(upd, e0, M, av);
-    ldv(dgv, e0, M, dg);
-    ldv(gv, e0, M, g);
+    ldv<VEC>(upd, e0, M, av);
+    ldv<VEC>(dgv, e0, M, dg);
+    ldv<VEC>(gv, e0, M, g);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       a1[i] = av[i] + dg[i];
@@ -321,8 +330,8 @@ __global__ __launch_bounds__(TB) void k_axpy(int64_t M, int k, const Status* __r
     for (int j = 0; j < k; ++j) {
       float u[VEC], v[VEC];
       float ca = coef[j], cc = coef[thr + j], cb = coef[2 * thr + j];
-      ldv(U + (int64_t)j * M, e0, M, u);
-      ldv(V + (int64_t)j * M, e0, M, v);
+      ldv<VEC>(U + (int64_t)j * M, e0, M, u);
+      ldv<VEC>(V + (int64_t)j * M, e0, M, v);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         av[i] = fmaf(ca, v[i], av[i]);
@@ -336,9 +345,9 @@ __global__ __launch_bounds__(TB) void k_axpy(int64_t M, int k, const Status* __r
       av[i] = (av[i] != av[i]) ? 0.f : av[i];
       p2 = fmaf(av[i], g[i], p2);
     }
-    stv(V + (int64_t)k * M, e0, M, av);
-    stv(U + (int64_t)k * M, e0, M, a1);
-    stv(upd, e0, M, a2);
+    stv<VEC>(V + (int64_t)k * M, e0, M, av);
+    stv<VEC>(U + (int64_t)k * M, e0, M, a1);
+    stv<VEC>(upd, e0, M, a2);
   }
   p1 = wave_sum(p1);
   p2 = wave_sum(p2);
@@ -361,6 +370,7 @@ __global__ __launch_bounds__(TB) void k_reduce2(Status* st, const float* __restr
 }
 
 // u = D1 / s (NaN -> 0) -> U[k] ;  update = D2 - u * beta
+template <int VEC>
 __global__ __launch_bounds__(TB) void k_final(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
                                               float* __restrict__ upd) {
   if (st->done) return;
@@ -369,8 +379,8 @@ __global__ __launch_bounds__(TB) void k_final(int64_t M, int k, const Status* __
   float s = (float)st->s, beta = (float)st->beta;
   float u[VEC], d2[VEC];
   float* Uk = U + (int64_t)k * M;
-  ldv(Uk, e0, M, u);
-  ldv(upd, e0, M, d2);
+  ldv<VEC>(Uk, e0, M, u);
+  ldv<VEC>(upd, e0, M, d2);
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     float q = u[i] / s;
@@ -378,19 +388,29 @@ __global__ __launch_bounds__(TB) void k_final(int64_t M, int k, const Status* __
     u[i] = q;
     d2[i] = fmaf(-q, beta, d2[i]);
   }
-  stv(Uk, e0, M, u);
-  stv(upd, e0, M, d2);
+  stv<VEC>(Uk, e0, M, u);
+  stv<VEC>(upd, e0, M, d2);
 }
 
+template <int VEC>
 __global__ __launch_bounds__(TB) void k_copy_sel(int64_t M, const float* __restrict__ xb, const int32_t* __restrict__ sel,
                                                  int fixed, float* __restrict__ dst) {
   int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
   if (e0 >= M) return;
   int idx = sel ? *sel : fixed;
   float a[VEC];
-  ldv(xb + (int64_t)idx * M, e0, M, a);
-  stv(dst, e0, M, a);
+  ldv<VEC>(xb + (int64_t)idx * M, e0, M, a);
+  stv<VEC>(dst, e0, M, a);
 }
+
+// launch a VEC-templated kernel with the solver's vector width
+#define VPLAIN(vec, kern, cfg, ...)                                     \
+  do {                                                                  \
+    if ((vec) == 16) kern<16><<<VCFG cfg>>>(__VA_ARGS__);               \
+    else kern<4><<<VCFG cfg>>>(__VA_ARGS__);                            \
+  } while (0)
+#define VCFG(...) __VA_ARGS__
+#define VLAUNCH(name, st, vec, kern, cfg, ...) LAUNCH(name, st, VPLAIN(vec, kern, cfg, __VA_ARGS__))
 
 // ------------------------------------------------------------------------------------------ host
 // f kernels with a device-selected input buffer (fgnn.hip)
@@ -398,9 +418,14 @@ int psignn_f_eval_p(const psignn_plan_t* p, const float* W, int nl, const float*
                     int64_t stride, const float* h0, const float* prb, const float* nrm, float* out, float* work,
                     hipStream_t st);
 
+int psignn_f_tile_fused(const psignn_plan* p, const float* W, int nl, float* xbuf, int64_t M, const int32_t* st_words,
+                        int off_done, int off_cur, int off_nxt, const float* upd, float* gx, float* dg,
+                        const float* h0, const float* prb, const float* nrm, float* part, hipStream_t st);
+
 static int broyden_alloc(psignn_broyden* s) {
   size_t M = (size_t)s->M, thr = (size_t)s->thr;
-  s->nblk = (int)cdiv(s->M, CHUNK);
+  s->vec = s->M >= (int64_t)4 << 20 ? 16 : 4;
+  s->nblk = (int)cdiv(s->M, (int64_t)s->vec * TB);
   s->npart = s->nblk * (TB / 64);
   size_t nx = s->keep_trace ? thr + 2 : 3;
   struct { void** p; size_t n; } allocs[] = {
@@ -452,7 +477,7 @@ extern "C" int psignn_broyden_create_n(psignn_broyden_t** out, int64_t n_elems, 
   ARG_CHECK(out, "out is NULL");
   *out = nullptr;
   ARG_CHECK(n_elems > 0 && threshold > 0 && seq_len > 0, "bad sizes");
-  ARG_CHECK(cdiv(n_elems, CHUNK) * (TB / 64) < (int64_t)INT32_MAX, "vector too long");
+  ARG_CHECK(cdiv(n_elems, 16 * TB) * (TB / 64) < (int64_t)INT32_MAX, "vector too long");
   psignn_broyden* s = new psignn_broyden();
   s->M = n_elems;
   s->seq_len = seq_len;
@@ -493,18 +518,21 @@ static inline int sel_off_low() { return offsetof(Status, low) / 4; }
 static inline int sel_off_nxt() { return offsetof(Status, nxt) / 4; }
 
 // everything of one iteration after fx = f(x_next) is available; k = pairs stored so far
-static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st) {
+// fused_npart > 0: the f kernel already produced g, dg and the norm partials (fused_npart entries each)
+static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, int fused_npart = 0) {
   unsigned g = (unsigned)s->nblk;
-  LAUNCH("k_resid", st, (k_resid<<<g, TB, 0, st>>>(s->M, s->st, s->xbuf, s->fx, s->gx, s->dg, s->part, s->npart)));
-  LAUNCH("k_check", st, (k_check<<<1, TB, 0, st>>>(s->st, s->part, s->npart, s->rel_trace, s->abs_trace, eps, s->thr, s->seq_len, s->keep_trace)));
+  if (!fused_npart)
+    VLAUNCH("k_resid", st, s->vec, k_resid, (g, TB, 0, st), s->M, s->st, s->xbuf, s->fx, s->gx, s->dg, s->part, s->npart);
+  const int np = fused_npart ? fused_npart : s->npart;
+  LAUNCH("k_check", st, (k_check<<<1, TB, 0, st>>>(s->st, s->part, np, s->rel_trace, s->abs_trace, eps, s->thr, s->seq_len, s->keep_trace)));
   if (k >= s->thr) return;  // the threshold stop has fired; no slot left for another pair
   if (k > 0) {
-    LAUNCH("k_dots", st, (k_dots<<<g, TB, 0, st>>>(s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->npart, s->thr)));
+    VLAUNCH("k_dots", st, s->vec, k_dots, (g, TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->npart, s->thr);
     LAUNCH("k_reduce", st, (k_reduce<<<dim3(k, 3), TB, 0, st>>>(s->st, s->part, s->npart, s->thr, s->coef)));
   }
-  LAUNCH("k_axpy", st, (k_axpy<<<g, TB, 0, st>>>(s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->npart)));
+  VLAUNCH("k_axpy", st, s->vec, k_axpy, (g, TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->npart);
   LAUNCH("k_reduce2", st, (k_reduce2<<<1, TB, 0, st>>>(s->st, s->part, s->npart)));
-  LAUNCH("k_final", st, (k_final<<<g, TB, 0, st>>>(s->M, k, s->st, s->U, s->upd)));
+  VLAUNCH("k_final", st, s->vec, k_final, (g, TB, 0, st), s->M, k, s->st, s->U, s->upd);
 }
 
 static int read_status(psignn_broyden* s, hipStream_t st) {
@@ -520,10 +548,10 @@ static int finish(psignn_broyden* s, float* d_result, psignn_solve_info_t* info,
   if (d_result) {
     const int32_t* sel_low = reinterpret_cast<const int32_t*>(s->st) + sel_off_low();
     if (s->plan) {  // iterates live in plan order: select into fx, then back to the caller's numbering
-      k_copy_sel<<<g, TB, 0, st>>>(s->M, s->xbuf, sel_low, 0, s->fx);
+      VPLAIN(s->vec, k_copy_sel, (g, TB, 0, st), s->M, s->xbuf, sel_low, 0, s->fx);
       if ((rc = psignn_plan_permute(s->plan, s->fx, D, d_result, 0, st))) return rc;
     } else {
-      k_copy_sel<<<g, TB, 0, st>>>(s->M, s->xbuf, sel_low, 0, d_result);
+      VPLAIN(s->vec, k_copy_sel, (g, TB, 0, st), s->M, s->xbuf, sel_low, 0, d_result);
     }
   }
   if ((rc = read_status(s, st))) return rc;
@@ -568,12 +596,22 @@ extern "C" int psignn_broyden_solve(psignn_broyden_t* s, const float* W, int nl,
   const float* nrmp = p->mixed ? s->nrmp : nullptr;
   // gx0 = f(x0) - x0, update = gx0 (solver.py:131-136)
   if ((rc = psignn_f_eval_p(p, W, nl, s->h0p, nullptr, 0, s->h0p, s->prbp, nrmp, s->fx, s->fwork, st))) return rc;
-  k_begin<<<g, TB, 0, st>>>(s->M, s->h0p, s->fx, s->xbuf, s->gx, s->upd);
+  VPLAIN(s->vec, k_begin, (g, TB, 0, st), s->M, s->h0p, s->fx, s->xbuf, s->gx, s->upd);
+  const bool fused = p->tiled && (nl == 1 || p->mixed) && (size_t)p->n_tiles * 8 <= 3 * (size_t)s->thr * s->npart;
+  const int32_t* st_words = reinterpret_cast<const int32_t*>(s->st);
   for (int it = 0; it < s->thr; ++it) {
-    LAUNCH("k_xnext", st, (k_xnext<<<g, TB, 0, st>>>(s->M, s->st, s->xbuf, s->upd, nullptr)));
-    rc = psignn_f_eval_p(p, W, nl, s->xbuf, sel_nxt, s->M, s->h0p, s->prbp, nrmp, s->fx, s->fwork, st);
-    if (rc) return rc;
-    launch_update(s, it, eps, st);
+    if (fused) {
+      // one kernel: x_next = x_cur + update, f(x_next), g_new, dg, x_next and the norm partials
+      rc = psignn_f_tile_fused(p, W, nl, s->xbuf, s->M, st_words, offsetof(Status, done) / 4, sel_off_cur(),
+                               sel_off_nxt(), s->upd, s->gx, s->dg, s->h0p, s->prbp, nrmp, s->part, st);
+      if (rc < 0) return rc;
+      launch_update(s, it, eps, st, rc);
+    } else {
+      VLAUNCH("k_xnext", st, s->vec, k_xnext, (g, TB, 0, st), s->M, s->st, s->xbuf, s->upd, nullptr);
+      rc = psignn_f_eval_p(p, W, nl, s->xbuf, sel_nxt, s->M, s->h0p, s->prbp, nrmp, s->fx, s->fwork, st);
+      if (rc) return rc;
+      launch_update(s, it, eps, st);
+    }
     if ((it + 1) % poll_every == 0 || it + 1 == s->thr) {
       rc = read_status(s, st);
       if (rc) return rc;
@@ -588,10 +626,10 @@ extern "C" int psignn_broyden_get_iterate(const psignn_broyden_t* s, int i, floa
   ARG_CHECK(s->keep_trace, "solver was created without keep_trace");
   ARG_CHECK(i >= 0 && i <= s->thr, "iterate index out of range");
   if (s->plan) {
-    k_copy_sel<<<(unsigned)s->nblk, TB, 0, (hipStream_t)stream>>>(s->M, s->xbuf, nullptr, i, s->fx);
+    VPLAIN(s->vec, k_copy_sel, ((unsigned)s->nblk, TB, 0, (hipStream_t)stream), s->M, s->xbuf, nullptr, i, s->fx);
     return psignn_plan_permute(s->plan, s->fx, D, d_dst, 0, stream);
   }
-  k_copy_sel<<<(unsigned)s->nblk, TB, 0, (hipStream_t)stream>>>(s->M, s->xbuf, nullptr, i, d_dst);
+  VPLAIN(s->vec, k_copy_sel, ((unsigned)s->nblk, TB, 0, (hipStream_t)stream), s->M, s->xbuf, nullptr, i, d_dst);
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }
@@ -601,14 +639,14 @@ extern "C" int psignn_broyden_ext_begin(psignn_broyden_t* s, const float* d_x0, 
   ARG_CHECK(s && d_x0 && d_fx0, "NULL argument");
   hipStream_t st = (hipStream_t)stream;
   k_init_status<<<4, TB, 0, st>>>(s->st, s->rel_trace, s->abs_trace, s->thr);
-  k_begin<<<(unsigned)s->nblk, TB, 0, st>>>(s->M, d_x0, d_fx0, s->xbuf, s->gx, s->upd);
+  VPLAIN(s->vec, k_begin, ((unsigned)s->nblk, TB, 0, st), s->M, d_x0, d_fx0, s->xbuf, s->gx, s->upd);
   s->ext_iter = 0;
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }
 extern "C" int psignn_broyden_ext_next_x(psignn_broyden_t* s, float* d_x_new, void* stream) {
   ARG_CHECK(s && d_x_new, "NULL argument");
-  k_xnext<<<(unsigned)s->nblk, TB, 0, (hipStream_t)stream>>>(s->M, s->st, s->xbuf, s->upd, d_x_new);
+  VPLAIN(s->vec, k_xnext, ((unsigned)s->nblk, TB, 0, (hipStream_t)stream), s->M, s->st, s->xbuf, s->upd, d_x_new);
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }
