@@ -62,8 +62,21 @@ struct WLayout {
   __host__ __device__ static constexpr int phi_neu(int nl) { return SHARED_SZ + nl * LAYER_SZ; }
   __host__ __device__ static constexpr int upd_neu(int nl) { return SHARED_SZ + nl * LAYER_SZ + PHI_SZ; }
   __host__ __device__ static constexpr int nfold(int nl) { return SHARED_SZ + nl * LAYER_SZ + PHI_SZ + NEU_SZ; }
-  __host__ __device__ static constexpr int total(int nl, bool mixed) {
+  __host__ __device__ static constexpr int base_total(int nl, bool mixed) {
     return SHARED_SZ + nl * LAYER_SZ + (mixed ? PHI_SZ + NEU_SZ + NFOLD_SZ : 0);
+  }
+  // ---- transposed section (tile kernel): every matrix again as [in k][out o], o fastest, so that the outputs
+  // (o, o+1) of one input k are adjacent -> one SGPR pair feeds a v_pk_fma_f32.  FP32 peak on CDNA needs the
+  // packed form; the scalar form issues at half the rate.  Derived on the host (engine.pack_weights).
+  static constexpr int T_W1J_TO = 0, T_W1J_FR = 100, T_W1I_TO = 200, T_W1I_FR = 300, T_A_TO = 400, T_A_FR = 430,
+                       T_B1_TO = 460, T_B1_FR = 470, T_U1H = 480, T_GTO = 580, T_GFR = 680, T_U1P = 780, T_HB = 810,
+                       T_gTO = 820, T_gFR = 830, T_U2 = 840, T_C2 = 940, TPL_SZ = 950;
+  static constexpr int N_W1J = 0, N_W1I = 100, N_A = 200, N_B1 = 230, N_N1H = 240, N_GN = 340, N_N1P = 440,
+                       N_NB1 = 490, N_gN = 500, N_N2 = 510, N_NB2 = 610, TPN_SZ = 620;
+  __host__ __device__ static constexpr int tp_layer(int nl, bool mixed, int l) { return base_total(nl, mixed) + l * TPL_SZ; }
+  __host__ __device__ static constexpr int tp_neu(int nl) { return base_total(nl, true) + nl * TPL_SZ; }
+  __host__ __device__ static constexpr int total(int nl, bool mixed) {
+    return base_total(nl, mixed) + nl * TPL_SZ + (mixed ? TPN_SZ : 0);
   }
 };
 

@@ -53,59 +53,91 @@ __device__ __forceinline__ void lds_load10at(const float* __restrict__ p, float*
   }
 }
 
+// Packed fp32: CDNA issues one VALU instruction per wave every 4 cycles; v_pk_fma_f32 / v_pk_add_f32 carry two
+// floats per lane in that slot, so the FP32 peak (and this kernel, which is VALU-issue bound) needs them.  All
+// matrices are read from the transposed weight section ([in k][out o], o fastest): the outputs (2p, 2p+1) of one
+// input k sit in one SGPR pair.  Each output is still the same k-ordered fma chain as in fgnn.hip.
+// Workgroup = 4 waves = TILE_MAX lanes.  (A fifth wave that only helps with the halo rows of stage 1 was tried:
+// 79 us instead of 67 us per 1M-node evaluation -- it costs a wave slot per workgroup for the whole residency.)
+#define TILE_THREADS 256
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
+
+// acc[p] += WT[k][2p..2p+1] * x[k],  p < 5, k < K
+template <int K>
+__device__ __forceinline__ void mv2(const float* __restrict__ WT, const float* x, v2f* acc) {
+  const v2f* w = reinterpret_cast<const v2f*>(WT);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const v2f xs = splat(x[k]);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) acc[p] = __builtin_elementwise_fma(w[k * 5 + p], xs, acc[p]);
+  }
+}
+__device__ __forceinline__ void ld5(const float* __restrict__ p, v2f* r) {  // 10 wave-uniform floats (8-byte aligned)
+  const v2f* q = reinterpret_cast<const v2f*>(p);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) r[i] = q[i];
+}
+
 // One direction of the neighbour sum for this lane's node:
-//   S[o] += relu(Pi[o] + row[COL + o] + A[o,:] . (sg*a0, sg*a1, a2))   over the slots that carry `MASK`
-// (MASK = SLOT_IN: in-edges, attr mirrored, sg = -1;  SLOT_OUT: out-edges, sg = +1).
-// The two directions are separate passes on purpose: one pass needs 30 wave-uniform weights, which the
-// compiler keeps in SGPRs across the loop; with both directions in one loop (60 weights) it re-issues the
-// scalar loads and their waits in every iteration.  The second pass re-reads the 16-byte slots from L1/L2.
+//   S[o] += relu(Pi[o] + row[COL + o] + AT[:, o] . (a0, a1, a2))   over the slots that carry `MASK`
+// (AT = W1[:, 20:23]^T; for in-edges its first two rows are stored negated, because an in-edge's attr is the
+// mirror (-a0, -a1, a2) of the slot's attr).  The two directions are separate passes on purpose: one pass needs
+// 30 wave-uniform weights, which stay in SGPRs across the loop; with 60 the compiler re-issues the scalar loads
+// and their waits in every iteration.  The second pass re-reads the 16-byte slots from L1/L2.
 template <int RS, int COL, unsigned MASK>
 __device__ __forceinline__ float edge_pass(const uint4* __restrict__ slots, int nslots, const float* __restrict__ lds,
-                                           const float* __restrict__ A, int ld, const float* Pi, float* S) {
-  constexpr float SG = (MASK == SLOT_IN) ? -1.f : 1.f;
+                                           const float* __restrict__ AT, const v2f* Pi, v2f* S) {
   float deg = 0.f;
-  float wa[3 * D];
+  v2f wa[15];
 #pragma unroll
-  for (int o = 0; o < D; ++o) {
-    wa[3 * o + 0] = SG * A[o * ld + 0];
-    wa[3 * o + 1] = SG * A[o * ld + 1];
-    wa[3 * o + 2] = A[o * ld + 2];
-  }
+  for (int i = 0; i < 15; ++i) wa[i] = reinterpret_cast<const v2f*>(AT)[i];
   auto one = [&](const uint4 s) {
     const unsigned w = s.x;
     if ((w & 0xFFFFu) != ELL_EMPTY && (w & MASK)) {
-      const float a0 = __uint_as_float(s.y), a1 = __uint_as_float(s.z), a2 = __uint_as_float(s.w);
+      const v2f a0 = splat(__uint_as_float(s.y)), a1 = splat(__uint_as_float(s.z)), a2 = splat(__uint_as_float(s.w));
       const float* row = lds + (int)(w & 0xFFFFu) * RS + COL;
-      float pj[D];
+      v2f pj[5];
       if (COL % 4 == 0) {  // 16-byte aligned start: b128, b128, b64
         float4 v0 = reinterpret_cast<const float4*>(row)[0], v1 = reinterpret_cast<const float4*>(row)[1];
         float2 v2 = reinterpret_cast<const float2*>(row)[4];
-        pj[0] = v0.x; pj[1] = v0.y; pj[2] = v0.z; pj[3] = v0.w; pj[4] = v1.x; pj[5] = v1.y; pj[6] = v1.z; pj[7] = v1.w;
-        pj[8] = v2.x; pj[9] = v2.y;
+        pj[0] = (v2f){v0.x, v0.y}; pj[1] = (v2f){v0.z, v0.w}; pj[2] = (v2f){v1.x, v1.y}; pj[3] = (v2f){v1.z, v1.w};
+        pj[4] = (v2f){v2.x, v2.y};
       } else {             // start at 8 mod 16: b64, b128, b128
         float2 v0 = reinterpret_cast<const float2*>(row)[0];
         float4 v1 = reinterpret_cast<const float4*>(row + 2)[0], v2 = reinterpret_cast<const float4*>(row + 2)[1];
-        pj[0] = v0.x; pj[1] = v0.y; pj[2] = v1.x; pj[3] = v1.y; pj[4] = v1.z; pj[5] = v1.w; pj[6] = v2.x; pj[7] = v2.y;
-        pj[8] = v2.z; pj[9] = v2.w;
+        pj[0] = (v2f){v0.x, v0.y}; pj[1] = (v2f){v1.x, v1.y}; pj[2] = (v2f){v1.z, v1.w}; pj[3] = (v2f){v2.x, v2.y};
+        pj[4] = (v2f){v2.z, v2.w};
       }
       deg += 1.f;
+      // five independent chains, written stage by stage so that dependent packed ops are never back to back
+      v2f z[5];
 #pragma unroll
-      for (int o = 0; o < D; ++o) {
-        float z = Pi[o] + pj[o];
-        z = fmaf(wa[3 * o + 0], a0, z);
-        z = fmaf(wa[3 * o + 1], a1, z);
-        z = fmaf(wa[3 * o + 2], a2, z);
-        S[o] += fmaxf(z, 0.f);
-      }
+      for (int p = 0; p < 5; ++p) z[p] = Pi[p] + pj[p];
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[p], a0, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[5 + p], a1, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[10 + p], a2, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) S[p] += __builtin_elementwise_max(z[p], splat(0.f));
     }
   };
-  int r = 0;
-  for (; r + 1 < nslots; r += 2) {  // two independent 16-byte loads in flight per wait
-    const uint4 s0 = slots[(int64_t)r * 64], s1 = slots[(int64_t)(r + 1) * 64];
-    one(s0);
-    one(s1);
+  // software pipeline, distance 2: the 16-byte slot loads are unconditional (index clamped, never branched
+  // on) so the compiler keeps them whole and places their waits one iteration later
+  if (nslots <= 0) return deg;
+  uint4 c0 = slots[0];
+  uint4 c1 = slots[(int64_t)min(1, nslots - 1) * 64];
+  for (int r = 0; r < nslots; ++r) {
+    const uint4 nx = slots[(int64_t)min(r + 2, nslots - 1) * 64];
+    one(c0);
+    c0 = c1;
+    c1 = nx;
   }
-  if (r < nslots) one(slots[(int64_t)r * 64]);
   return deg;
 }
 
@@ -131,12 +163,12 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 }
 
 template <int P, bool MIXED, bool FUSED>
-__global__ __launch_bounds__(256) void k_f_tile(FuseArgs fa, int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
+__global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
                                                 const int32_t* __restrict__ tile_slice, const int32_t* __restrict__ halo,
                                                 const int32_t* __restrict__ halo_cnt, const int32_t* __restrict__ slice_off,
                                                 const uint8_t* __restrict__ slice_deg, const uint4* __restrict__ ell,
-                                                const uint8_t* __restrict__ flags, const float* __restrict__ W, int lofs,
-                                                int nofs, int unofs, int nl, int apply_ln, const float* __restrict__ h,
+                                                const uint8_t* __restrict__ flags, const float* __restrict__ W, int lofs, int tofs,
+                                                int tnofs, int apply_ln, const float* __restrict__ h,
                                                 const int32_t* __restrict__ hsel, int64_t hstride,
                                                 const float* __restrict__ h0, const float* __restrict__ prb,
                                                 const float* __restrict__ nrm, float* __restrict__ out) {
@@ -156,15 +188,14 @@ __global__ __launch_bounds__(256) void k_f_tile(FuseArgs fa, int n_tiles, int ch
   if (hsel) h += (int64_t)(*hsel) * hstride;
   if (FUSED) h = fa.xbuf + (int64_t)fa.st[fa.off_cur] * fa.M;
 
-  const float* Wto = W + lofs + L::L_TO;
-  const float* Wfr = W + lofs + L::L_FROM;
-  const float* Wn = W + nofs;
+  const float* T = W + tofs;    // transposed section of this layer
+  const float* TN = W + tnofs;  // transposed Neumann blocks (mixed)
 
   // ---- stage 1: neighbour-side projections of tile + halo rows -> LDS
   float x[D];
-  for (int row = tid; row < n_t + n_h; row += 256) {
+  for (int row = tid; row < n_t + n_h; row += TILE_THREADS) {
     const int64_t node = row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t];
-    float xr[D], ta[D], tb[D];
+    float xr[D];
     load10(h + node * D, xr);
     if (FUSED) {  // x_next = x_cur + update (line_search with on=False: step 1, solver.py:85-94)
       float ur[D];
@@ -176,12 +207,24 @@ __global__ __launch_bounds__(256) void k_f_tile(FuseArgs fa, int n_tiles, int ch
 #pragma unroll
       for (int o = 0; o < D; ++o) x[o] = xr[o];
     }
-    matvec10<D, false>(Wto + L::PHI_W1, L::EIN, D, xr, ta);
-    matvec10<D, false>(Wfr + L::PHI_W1, L::EIN, D, xr, tb);
-    lds_store20(lds + row * RS, ta, tb);
+    v2f ta[5], tb[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) ta[p] = tb[p] = splat(0.f);
+    mv2<D>(T + L::T_W1J_TO, xr, ta);
+    mv2<D>(T + L::T_W1J_FR, xr, tb);
+    float4* q = reinterpret_cast<float4*>(lds + row * RS);
+    q[0] = make_float4(ta[0].x, ta[0].y, ta[1].x, ta[1].y);
+    q[1] = make_float4(ta[2].x, ta[2].y, ta[3].x, ta[3].y);
+    q[2] = make_float4(ta[4].x, ta[4].y, tb[0].x, tb[0].y);
+    q[3] = make_float4(tb[1].x, tb[1].y, tb[2].x, tb[2].y);
+    q[4] = make_float4(tb[3].x, tb[3].y, tb[4].x, tb[4].y);
     if (MIXED) {
-      matvec10<D, false>(Wn + L::PHI_W1, L::EIN, D, xr, ta);
-      lds_store10at(lds + row * RS + 20, ta);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) ta[p] = splat(0.f);
+      mv2<D>(TN + L::N_W1J, xr, ta);
+      q[5] = make_float4(ta[0].x, ta[0].y, ta[1].x, ta[1].y);
+      q[6] = make_float4(ta[2].x, ta[2].y, ta[3].x, ta[3].y);
+      reinterpret_cast<float2*>(q + 7)[0] = make_float2(ta[4].x, ta[4].y);
     }
   }
   __syncthreads();
@@ -207,53 +250,47 @@ __global__ __launch_bounds__(256) void k_f_tile(FuseArgs fa, int n_tiles, int ch
   const int nslots = slice_deg[slice];
 
   // target-side projection (bias included) + neighbour sum, one direction at a time
-  float Pi[D], S_to[D], S_fr[D];
+  v2f Pi[5], S_to[5], S_fr[5];
+  ld5(T + L::T_B1_TO, Pi);
 #pragma unroll
-  for (int o = 0; o < D; ++o) {
-    Pi[o] = Wto[L::PHI_B1 + o];
-    S_to[o] = 0.f;
-    S_fr[o] = 0.f;
-  }
-  matvec10<D, true>(Wto + L::PHI_W1, L::EIN, 0, x, Pi);
-  const float deg_in = edge_pass<RS, 0, SLOT_IN>(slots, nslots, lds, Wto + L::PHI_W1 + 2 * D, L::EIN, Pi, S_to);
-#pragma unroll
-  for (int o = 0; o < D; ++o) Pi[o] = Wfr[L::PHI_B1 + o];
-  matvec10<D, true>(Wfr + L::PHI_W1, L::EIN, 0, x, Pi);
-  const float deg_out = edge_pass<RS, D, SLOT_OUT>(slots, nslots, lds, Wfr + L::PHI_W1 + 2 * D, L::EIN, Pi, S_fr);
+  for (int p = 0; p < 5; ++p) S_to[p] = S_fr[p] = splat(0.f);
+  mv2<D>(T + L::T_W1I_TO, x, Pi);
+  const float deg_in = edge_pass<RS, 0, SLOT_IN>(slots, nslots, lds, T + L::T_A_TO, Pi, S_to);
+  ld5(T + L::T_B1_FR, Pi);
+  mv2<D>(T + L::T_W1I_FR, x, Pi);
+  const float deg_out = edge_pass<RS, D, SLOT_OUT>(slots, nslots, lds, T + L::T_A_FR, Pi, S_fr);
 
+  v2f y2[5];
   if (MIXED && (fl & FLAG_NEUMANN)) {
     // Phi_neumann (Phi_from type: out-edges) + update_neumann: the row is REPLACED (mixed/psignn/model.py:236,241)
-    const float* Un = W + unofs;
-    const float* Nf = W + L::nfold(nl);
-    float S_n[D], hid[D];
+    v2f S_n[5], hid[5], gN[5];
+    ld5(TN + L::N_B1, Pi);
 #pragma unroll
-    for (int o = 0; o < D; ++o) {
-      Pi[o] = Wn[L::PHI_B1 + o];
-      S_n[o] = 0.f;
-    }
-    matvec10<D, true>(Wn + L::PHI_W1, L::EIN, 0, x, Pi);
-    edge_pass<RS, 2 * D, SLOT_OUT>(slots, nslots, lds, Wn + L::PHI_W1 + 2 * D, L::EIN, Pi, S_n);
+    for (int p = 0; p < 5; ++p) S_n[p] = splat(0.f);
+    mv2<D>(TN + L::N_W1I, x, Pi);
+    edge_pass<RS, 2 * D, SLOT_OUT>(slots, nslots, lds, TN + L::N_A, Pi, S_n);
+    ld5(TN + L::N_NB1, hid);
+    ld5(TN + L::N_gN, gN);
 #pragma unroll
-    for (int o = 0; o < D; ++o) hid[o] = fmaf(deg_out, Nf[L::NF_g + o], Un[L::NEU_B1 + o]);
-    matvec10<D, true>(Un + L::NEU_W1, L::NEU_CAT, 0, x, hid);
-    matvec10<D, true>(Nf + L::NF_G, D, 0, S_n, hid);
+    for (int p = 0; p < 5; ++p) hid[p] = __builtin_elementwise_fma(splat(deg_out), gN[p], hid[p]);
+    mv2<D>(TN + L::N_N1H, x, hid);
+    mv2<D>(TN + L::N_GN, reinterpret_cast<const float*>(S_n), hid);
     float pq[P + 2];
 #pragma unroll
     for (int k = 0; k < P; ++k) pq[k] = prb[n * P + k];
     pq[P] = nrm[n * 2];
     pq[P + 1] = nrm[n * 2 + 1];
-    matvec10<P + 2, true>(Un + L::NEU_W1, L::NEU_CAT, 2 * D, pq, hid);
+    mv2<P + 2>(TN + L::N_N1P, pq, hid);
 #pragma unroll
-    for (int o = 0; o < D; ++o) {
-      hid[o] = fmaxf(hid[o], 0.f);
-      y[o] = Un[L::NEU_B2 + o];
-    }
-    matvec10<D, true>(Un + L::NEU_W2, D, 0, hid, y);
+    for (int p = 0; p < 5; ++p) hid[p] = __builtin_elementwise_max(hid[p], splat(0.f));
+    ld5(TN + L::N_NB2, y2);
+    mv2<D>(TN + L::N_N2, reinterpret_cast<const float*>(hid), y2);
   } else {
     // gate + update MLP on cat = [h | mp_to | mp_from | prb], with mp_* = W2 S + deg b2 folded in
-    const float* Wu = W + lofs + L::L_UPD;
-    const float* Wf = W + lofs + L::L_FOLD;
+    const float* Wf = W + lofs + L::L_FOLD;  // this layer's fold vectors of the (shared) alpha gate
     const float* Wa = W + L::AL_W;
+    const float* sto = reinterpret_cast<const float*>(S_to);
+    const float* sfr = reinterpret_cast<const float*>(S_fr);
     float pq[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) pq[k] = prb[n * P + k];
@@ -261,28 +298,34 @@ __global__ __launch_bounds__(256) void k_f_tile(FuseArgs fa, int n_tiles, int ch
 #pragma unroll
     for (int k = 0; k < D; ++k) al = fmaf(Wa[k], x[k], al);
 #pragma unroll
-    for (int k = 0; k < D; ++k) al = fmaf(Wf[L::F_ATO + k], S_to[k], al);
+    for (int k = 0; k < D; ++k) al = fmaf(Wf[L::F_ATO + k], sto[k], al);
 #pragma unroll
-    for (int k = 0; k < D; ++k) al = fmaf(Wf[L::F_AFR + k], S_fr[k], al);
+    for (int k = 0; k < D; ++k) al = fmaf(Wf[L::F_AFR + k], sfr[k], al);
 #pragma unroll
     for (int k = 0; k < P; ++k) al = fmaf(Wa[3 * D + k], pq[k], al);
     al = 1.f / (1.f + expf(-al));
-    float hid[D], upd[D];
+    v2f hid[5], g1[5], g2[5], upd[5];
+    ld5(T + L::T_HB, hid);
+    ld5(T + L::T_gTO, g1);
+    ld5(T + L::T_gFR, g2);
 #pragma unroll
-    for (int o = 0; o < D; ++o)
-      hid[o] = fmaf(deg_in, Wf[L::F_gTO + o], fmaf(deg_out, Wf[L::F_gFR + o], Wu[L::UPD_B1 + o]));
-    matvec10<D, true>(Wu + L::UPD_W1, L::CAT, 0, x, hid);
-    matvec10<D, true>(Wf + L::F_GTO, D, 0, S_to, hid);
-    matvec10<D, true>(Wf + L::F_GFR, D, 0, S_fr, hid);
-    matvec10<P, true>(Wu + L::UPD_W1, L::CAT, 3 * D, pq, hid);
+    for (int p = 0; p < 5; ++p)
+      hid[p] = __builtin_elementwise_fma(splat(deg_in), g1[p], __builtin_elementwise_fma(splat(deg_out), g2[p], hid[p]));
+    mv2<D>(T + L::T_U1H, x, hid);
+    mv2<D>(T + L::T_GTO, sto, hid);
+    mv2<D>(T + L::T_GFR, sfr, hid);
+    mv2<P>(T + L::T_U1P, pq, hid);
 #pragma unroll
-    for (int o = 0; o < D; ++o) {
-      hid[o] = fmaxf(hid[o], 0.f);
-      upd[o] = Wu[L::UPD_B2 + o];
-    }
-    matvec10<D, true>(Wu + L::UPD_W2, D, 0, hid, upd);
+    for (int p = 0; p < 5; ++p) hid[p] = __builtin_elementwise_max(hid[p], splat(0.f));
+    ld5(T + L::T_C2, upd);
+    mv2<D>(T + L::T_U2, reinterpret_cast<const float*>(hid), upd);
 #pragma unroll
-    for (int o = 0; o < D; ++o) y[o] = fmaf(al, upd[o], x[o]);
+    for (int p = 0; p < 5; ++p) y2[p] = __builtin_elementwise_fma(splat(al), upd[p], (v2f){x[2 * p], x[2 * p + 1]});
+  }
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    y[2 * p] = y2[p].x;
+    y[2 * p + 1] = y2[p].y;
   }
   if (apply_ln) {  // LayerNorm(10), eps 1e-5, biased variance, affine (model.py:293)
     float mu = 0.f;
@@ -323,7 +366,7 @@ __global__ __launch_bounds__(256) void k_f_tile(FuseArgs fa, int n_tiles, int ch
   }
   sg = wave_sum_f(sg);
   sf = wave_sum_f(sf);
-  if ((tid & 63) == 0) {
+  if ((tid & 63) == 0 && tid < 256) {
     fa.part[tile * 4 + (tid >> 6)] = sg;
     fa.part[fa.npart + tile * 4 + (tid >> 6)] = sf;
   }
@@ -351,9 +394,9 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
   if (p->mixed) {
     using L = WLayout<3>;
     size_t lds = (size_t)p->max_rows * TileRow<true>::RS * 4;
-    LAUNCH("k_f_tile", st, (k_f_tile<3, true, false><<<grid, 256, lds, st>>>(
+    LAUNCH("k_f_tile", st, (k_f_tile<3, true, false><<<grid, TILE_THREADS, lds, st>>>(
         FuseArgs{}, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
-        p->flags_p, W, L::layer(nl - 1), L::phi_neu(nl), L::upd_neu(nl), nl, 1, h, hsel, hstride, h0, prb, nrm, out)));
+        p->flags_p, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), L::tp_neu(nl), 1, h, hsel, hstride, h0, prb, nrm, out)));
   } else {
     using L = WLayout<2>;
     size_t lds = (size_t)p->max_rows * TileRow<false>::RS * 4;
@@ -362,9 +405,9 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
     const float* cur = h;
     for (int l = 0; l < nl; ++l) {
       float* dst = (l == nl - 1) ? out : pp[l & 1];
-      LAUNCH("k_f_tile", st, (k_f_tile<2, false, false><<<grid, 256, lds, st>>>(
+      LAUNCH("k_f_tile", st, (k_f_tile<2, false, false><<<grid, TILE_THREADS, lds, st>>>(
           FuseArgs{}, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
-          p->flags_p, W, L::layer(l), 0, 0, nl, l == nl - 1, cur, l == 0 ? hsel : nullptr, hstride, h0, prb, nrm, dst)));
+          p->flags_p, W, L::layer(l), L::tp_layer(nl, false, l), 0, l == nl - 1, cur, l == 0 ? hsel : nullptr, hstride, h0, prb, nrm, dst)));
       cur = dst;
     }
   }
@@ -386,15 +429,15 @@ int psignn_f_tile_fused(const psignn_plan* p, const float* W, int nl, float* xbu
   if (p->mixed) {
     using L = WLayout<3>;
     size_t lds = (size_t)p->max_rows * TileRow<true>::RS * 4;
-    LAUNCH("k_f_tile_fused", st, (k_f_tile<3, true, true><<<grid, 256, lds, st>>>(
+    LAUNCH("k_f_tile_fused", st, (k_f_tile<3, true, true><<<grid, TILE_THREADS, lds, st>>>(
         fa, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
-        p->flags_p, W, L::layer(nl - 1), L::phi_neu(nl), L::upd_neu(nl), nl, 1, xbuf, nullptr, 0, h0, prb, nrm, nullptr)));
+        p->flags_p, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), L::tp_neu(nl), 1, xbuf, nullptr, 0, h0, prb, nrm, nullptr)));
   } else {
     using L = WLayout<2>;
     size_t lds = (size_t)p->max_rows * TileRow<false>::RS * 4;
-    LAUNCH("k_f_tile_fused", st, (k_f_tile<2, false, true><<<grid, 256, lds, st>>>(
+    LAUNCH("k_f_tile_fused", st, (k_f_tile<2, false, true><<<grid, TILE_THREADS, lds, st>>>(
         fa, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
-        p->flags_p, W, L::layer(0), 0, 0, nl, 1, xbuf, nullptr, 0, h0, prb, nrm, nullptr)));
+        p->flags_p, W, L::layer(0), L::tp_layer(nl, false, 0), 0, 1, xbuf, nullptr, 0, h0, prb, nrm, nullptr)));
   }
   HIP_TRY(hipGetLastError());
   return npart;

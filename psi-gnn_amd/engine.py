@@ -75,6 +75,40 @@ def pack_weights(sd, device=None) -> torch.Tensor:
         nf = torch.cat([(N1[:, D:2 * D] @ m("phi_neumann.mlp.mlp.2.weight")).reshape(-1),
                         N1[:, D:2 * D] @ m("phi_neumann.mlp.mlp.2.bias")]).to(torch.float32)
         parts.append(torch.nn.functional.pad(nf, (0, 112 - nf.numel())))
+    # ---- transposed section for the tile kernel: [in k][out o] blocks (WLayout::T_* / N_*)
+    m = lambda k: sd[P + k].detach().to("cpu", torch.float64)
+    f32 = lambda t: t.to(torch.float32).reshape(-1)
+
+    def padto(t, n):
+        t = f32(t)
+        return torch.nn.functional.pad(t, (0, n - t.numel()))
+    mir = torch.tensor([-1.0, -1.0, 1.0], dtype=torch.float64)[:, None]  # in-edge attr = mirror of the stored out-edge attr
+    for l in range(nl):
+        Wt, Wf = m(f"phi_to_list.{l}.mlp.mlp.0.weight"), m(f"phi_from_list.{l}.mlp.mlp.0.weight")
+        U1, U2 = m(f"update_list.{l}.mlp.0.weight"), m(f"update_list.{l}.mlp.2.weight")
+        G_to = U1[:, D:2 * D] @ m(f"phi_to_list.{l}.mlp.mlp.2.weight")
+        G_fr = U1[:, 2 * D:3 * D] @ m(f"phi_from_list.{l}.mlp.mlp.2.weight")
+        g_to = U1[:, D:2 * D] @ m(f"phi_to_list.{l}.mlp.mlp.2.bias")
+        g_fr = U1[:, 2 * D:3 * D] @ m(f"phi_from_list.{l}.mlp.mlp.2.bias")
+        tp = [f32(Wt[:, D:2 * D].t()), f32(Wf[:, D:2 * D].t()), f32(Wt[:, :D].t()), f32(Wf[:, :D].t()),
+              f32(Wt[:, 2 * D:].t() * mir), f32(Wf[:, 2 * D:].t()),
+              f32(m(f"phi_to_list.{l}.mlp.mlp.0.bias")), f32(m(f"phi_from_list.{l}.mlp.mlp.0.bias")),
+              f32(U1[:, :D].t()), f32(G_to.t()), f32(G_fr.t()), padto(U1[:, 3 * D:].t(), 30),
+              f32(m(f"update_list.{l}.mlp.0.bias")), f32(g_to), f32(g_fr), f32(U2.t()),
+              f32(m(f"update_list.{l}.mlp.2.bias"))]
+        tp = torch.cat(tp)
+        assert tp.numel() == 950
+        parts.append(tp)
+    if mixed:
+        Wn, N1, N2 = m("phi_neumann.mlp.mlp.0.weight"), m("update_neumann.mlp.0.weight"), m("update_neumann.mlp.2.weight")
+        Gn = N1[:, D:2 * D] @ m("phi_neumann.mlp.mlp.2.weight")
+        gn = N1[:, D:2 * D] @ m("phi_neumann.mlp.mlp.2.bias")
+        tn = torch.cat([f32(Wn[:, D:2 * D].t()), f32(Wn[:, :D].t()), f32(Wn[:, 2 * D:].t()),
+                        f32(m("phi_neumann.mlp.mlp.0.bias")), f32(N1[:, :D].t()), f32(Gn.t()),
+                        padto(N1[:, 2 * D:].t(), 50), f32(m("update_neumann.mlp.0.bias")), f32(gn), f32(N2.t()),
+                        f32(m("update_neumann.mlp.2.bias"))])
+        assert tn.numel() == 620
+        parts.append(tn)
     flat = torch.cat(parts).contiguous()
     return flat if device is None else flat.to(device)
 

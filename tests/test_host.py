@@ -27,8 +27,8 @@ def test_pure_host_entry_points():
     nat = pkg("_native")
     lib = nat.lib()
     assert lib.psignn_version() >= 100
-    assert lib.psignn_weights_size(0, 1) == 64 + 2 * 350 + (10 * 32 + 120) + 244
-    assert lib.psignn_weights_size(1, 1) == 64 + 2 * 350 + (10 * 33 + 120) + 244 + 350 + (10 * 25 + 120) + 112
+    assert lib.psignn_weights_size(0, 1) == 64 + 2 * 350 + (10 * 32 + 120) + 244 + 950
+    assert lib.psignn_weights_size(1, 1) == 64 + 2 * 350 + (10 * 33 + 120) + 244 + 350 + (10 * 25 + 120) + 112 + 950 + 620
     assert lib.psignn_weights_size(0, 0) == -1
     assert lib.psignn_plan_num_nodes(None) == -1
 
@@ -37,7 +37,7 @@ def test_weight_packing_layout():
     eng = pkg("engine")
     sd = load_weights("dirichlet")
     flat = eng.pack_weights(sd)
-    assert flat.numel() == 1448
+    assert flat.numel() == 1448 + 950
     P = "deqdss.f."
     assert torch.equal(flat[0:10], sd[P + "laynorm.weight"])
     assert torch.equal(flat[20:52], sd[P + "alpha.0.weight"].reshape(-1))
@@ -46,8 +46,10 @@ def test_weight_packing_layout():
     assert torch.equal(flat[64 + 700:64 + 700 + 320], sd[P + "update_list.0.mlp.0.weight"].reshape(-1))
     sdm = load_weights("mixed")
     flatm = eng.pack_weights(sdm)
-    assert flatm.numel() == 2290
-    assert torch.equal(flatm[-112 - 370:-112 - 120], sdm[P + "update_neumann.mlp.0.weight"].reshape(-1))
+    assert flatm.numel() == 2290 + 950 + 620
+    assert torch.equal(flatm[-1570 - 112 - 370:-1570 - 112 - 120], sdm[P + "update_neumann.mlp.0.weight"].reshape(-1))
+    # transposed section: [k][o] copy of W1j of Phi_to starts the tile kernel's block
+    assert torch.equal(flat[1448:1548].reshape(10, 10), sd[P + "phi_to_list.0.mlp.mlp.0.weight"][:, 10:20].t())
     U1, W2 = sd[P + "update_list.0.mlp.0.weight"].double(), sd[P + "phi_to_list.0.mlp.mlp.2.weight"].double()
     assert torch.allclose(flat[64 + 700 + 440:64 + 700 + 540].double(), (U1[:, 10:20] @ W2).reshape(-1), rtol=1e-6, atol=1e-7)
     assert eng.is_mixed_state_dict(sdm) and not eng.is_mixed_state_dict(sd)
