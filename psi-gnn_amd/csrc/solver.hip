@@ -77,6 +77,29 @@ __device__ __forceinline__ void ldv(const float* __restrict__ p, int64_t e0, int
     for (int i = 0; i < VEC; ++i) r[i] = (e0 + i < M) ? p[e0 + i] : 0.f;
   }
 }
+// Loads of the U / V sweeps.  Non-temporal loads were measured and REJECTED: although every byte is read once
+// per pass, k_dots / k_axpy at N = 1M, k = 0..49 took 557 / 550 us per launch with nt against 365 / 382 us with
+// default-policy loads (round 1, MI355X).  -DPSIGNN_NT_SWEEPS=1 rebuilds the nt variant for A/B timing.
+#ifndef PSIGNN_NT_SWEEPS
+#define PSIGNN_NT_SWEEPS 0
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int VEC>
+__device__ __forceinline__ void ldv_stream(const float* __restrict__ p, int64_t e0, int64_t M, float* r) {
+#if PSIGNN_NT_SWEEPS
+  if (e0 + VEC <= M) {
+    const f4v* q = reinterpret_cast<const f4v*>(p + e0);
+#pragma unroll
+    for (int i = 0; i < VEC / 4; ++i) {
+      f4v t = __builtin_nontemporal_load(q + i);
+      r[4 * i] = t.x; r[4 * i + 1] = t.y; r[4 * i + 2] = t.z; r[4 * i + 3] = t.w;
+    }
+    return;
+  }
+#endif
+  ldv<VEC>(p, e0, M, r);
+}
+
 template <int VEC>
 __device__ __forceinline__ void stv(float* __restrict__ p, int64_t e0, int64_t M, const float* r) {
   if (e0 + VEC <= M) {
@@ -277,8 +300,8 @@ __global__ __launch_bounds__(TB) void k_dots(int64_t M, int k, const Status* __r
     float u[VEC], v[VEC];
     float sa = 0.f, sc = 0.f, sb = 0.f;
     if (act) {
-      ldv<VEC>(U + (int64_t)j * M, e0, M, u);
-      ldv<VEC>(V + (int64_t)j * M, e0, M, v);
+      ldv_stream<VEC>(U + (int64_t)j * M, e0, M, u);
+      ldv_stream<VEC>(V + (int64_t)j * M, e0, M, v);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         sa = fmaf(dx[i], u[i], sa);
@@ -330,8 +353,8 @@ __global__ __launch_bounds__(TB) void k_axpy(int64_t M, int k, const Status* __r
     for (int j = 0; j < k; ++j) {
       float u[VEC], v[VEC];
       float ca = coef[j], cc = coef[thr + j], cb = coef[2 * thr + j];
-      ldv<VEC>(U + (int64_t)j * M, e0, M, u);
-      ldv<VEC>(V + (int64_t)j * M, e0, M, v);
+      ldv_stream<VEC>(U + (int64_t)j * M, e0, M, u);
+      ldv_stream<VEC>(V + (int64_t)j * M, e0, M, v);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         av[i] = fmaf(ca, v[i], av[i]);
