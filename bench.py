@@ -272,14 +272,24 @@ def main():
     # ---- CPU baseline: the oracle (port of the reference path) on this box's host cores, bounded sample
     if rank == 0 and world == 1 and MPG == 1 and not args.no_cpu_baseline:
         from oracle import psignn_oracle as orc
-        cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
+        ncpu = os.cpu_count() or 1
         with torch.no_grad():
             h0c = orc.encoder(sd, mesh.x)
             f = lambda H: orc.function_forward(sd, H, h0c, mesh)
-            t1 = time.perf_counter()
-            f(h0c)
-            t_f = time.perf_counter() - t1
+            # thread count: torch's CPU ops get SLOWER beyond a few dozen threads on this path (measured on the
+            # 256-thread MI355X host: one 1M-node f call 0.99 s at 16 threads, 1.10 s at 32, 8.0 s at 256), so the
+            # baseline is timed at the fastest of a short calibration, not at os.cpu_count().
+            best = None
+            for nt in [t for t in (8, 16, 32) if t <= ncpu] or [ncpu]:
+                torch.set_num_threads(nt)
+                f(h0c)
+                t1 = time.perf_counter()
+                f(h0c)
+                dt = time.perf_counter() - t1
+                if best is None or dt < best[1]:
+                    best = (nt, dt)
+            cores, t_f = best
+            torch.set_num_threads(cores)
             S = int(max(2, min(K, args.cpu_seconds / (1.6 * t_f))))
             t1 = time.perf_counter()
             o = orc.broyden(f, h0c, threshold=S, eps=0.0)
@@ -287,7 +297,8 @@ def main():
         result["cpu_baseline"] = {
             "value": Ep * S / t_cpu, "unit": "edges/s", "iters_per_sec": S / t_cpu, "cores": cores, "kind": "port",
             "sample": f"oracle broyden iterations 1..{S} on the same {N}-node mesh and weights "
-                      f"(torch CPU ops, {cores} threads; one f call {t_f:.2f} s; total {t_cpu:.1f} s); "
+                      f"(torch CPU ops, {cores} of {ncpu} host threads = fastest of a calibration over 8/16/32; "
+                      f"one f call {t_f:.2f} s; total {t_cpu:.1f} s); "
                       f"CPU cost per iteration grows with k like the GPU's, the sample covers k < {S} only",
             "rel_residual_after_S": o["rel_trace"][S - 1],
             "gpu_rel_residual_at_S": out["rel_trace"][S - 1]}

@@ -181,8 +181,9 @@ def newton_krylov(f, x0, threshold=30, eps=1e-5, inner_m=30, inner_tol=1e-2, **k
 
     The reference imports ``scipy.optimize.newton_krylov`` (utilities/solver.py:6) but never calls it, so
     there is no reference implementation; the dict keys follow ``broyden``.  Outer Newton step:
-    solve (J_f(x) - I) dx = -g(x) with restarted-free GMRES(inner_m) to relative tolerance ``inner_tol``
-    (inexact Newton), x <- x + dx.  ``rel = |g|/(|f(x)| + 1e-9)`` as in broyden; ``nstep`` counts outer
+    solve (J_f(x) - I) dx = -g(x) approximately with ``inner_m`` GMRES steps (inexact Newton; ``inner_tol`` is
+    accepted for signature compatibility, the inner loop runs a fixed number of steps so that it needs no
+    host synchronisation), x <- x + dx.  ``rel = |g|/(|f(x)| + 1e-9)`` as in broyden; ``nstep`` counts outer
     iterations, ``n_feval`` f + JVP evaluations (the unit comparable to one Broyden iteration).
     With fp32 finite-difference JVPs scipy's solver does not converge on this problem; the
     analytic JVP kernel (psignn_f_jvp) is what makes the method usable in fp32.
@@ -199,16 +200,15 @@ def newton_krylov(f, x0, threshold=30, eps=1e-5, inner_m=30, inner_tol=1e-2, **k
     xest_trace = [x]
     nstep = 0
     for nstep in range(1, threshold + 1):
-        # GMRES on A dx = b, A v = J_f v - v, b = -g
+        # GMRES(inner_m) on A dx = b, A v = J_f v - v, b = -g.  The Arnoldi process runs a fixed number of steps
+        # with everything (Hessenberg matrix included) on the device: no host sync inside the inner loop; the
+        # small least-squares problem is solved once per outer step.
         b = -g.reshape(-1)
         beta = torch.linalg.norm(b)
         m = inner_m
         V = torch.zeros(m + 1, b.numel(), device=b.device, dtype=b.dtype)
-        Hm = torch.zeros(m + 1, m, device=b.device, dtype=torch.float64)
+        Hm = torch.zeros(m + 1, m, device=b.device, dtype=b.dtype)
         V[0] = b / beta
-        e1 = torch.zeros(m + 1, device=b.device, dtype=torch.float64)
-        e1[0] = float(beta)
-        k_used, y = 0, None
         for k in range(m):
             w = (f.jvp(x, V[k].reshape(x.shape)) - V[k].reshape(x.shape)).reshape(-1)
             n_feval += 1
@@ -216,16 +216,14 @@ def newton_krylov(f, x0, threshold=30, eps=1e-5, inner_m=30, inner_tol=1e-2, **k
             w = w - h @ V[:k + 1]
             h2 = V[:k + 1] @ w
             w = w - h2 @ V[:k + 1]
-            Hm[:k + 1, k] = (h + h2).double()
+            Hm[:k + 1, k] = h + h2
             hn = torch.linalg.norm(w)
-            Hm[k + 1, k] = float(hn)
-            k_used = k + 1
-            y = torch.linalg.lstsq(Hm[:k + 2, :k + 1], e1[:k + 2, None]).solution[:, 0]
-            res = torch.linalg.norm(Hm[:k + 2, :k + 1] @ y - e1[:k + 2])
-            if float(hn) < 1e-30 or float(res) <= inner_tol * float(beta):
-                break
-            V[k + 1] = w / hn
-        dx = (y.to(b.dtype) @ V[:k_used]).reshape(x.shape)
+            Hm[k + 1, k] = hn
+            V[k + 1] = w / hn.clamp_min(1e-30)
+        e1 = torch.zeros(m + 1, 1, device=b.device, dtype=torch.float64)
+        e1[0, 0] = beta.double()
+        y = torch.linalg.lstsq(Hm.double().cpu(), e1.cpu()).solution[:, 0].to(b.device, b.dtype)
+        dx = (y @ V[:m]).reshape(x.shape)
         x = x + dx
         fx = f(x)
         n_feval += 1
