@@ -261,9 +261,15 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
+                # committed summary of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over THIS command
+                # (scripts/collect_profiles.sh; gfx950 read-side correction applied as MI355X_MICROARCH.md prescribes)
                 t = json.load(open(pmc))
-                result["roofline"]["traffic"] = t.get(dom["kernel"])
-                result["roofline_f"]["traffic"] = t.get(fr["kernel"])
+                if t.get("_bench_args") == {"steps": K, "warmup": W, "workload": args.workload}:
+                    for key, row in (("roofline", dom), ("roofline_f", fr)):
+                        e = t.get(row["kernel"])
+                        if e:
+                            result[key]["traffic"] = e["hbm_bytes_per_launch"]
+                            result[key]["traffic_note"] = e["note"]
             except Exception:
                 pass
     for sv in solvers:

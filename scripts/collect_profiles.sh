@@ -7,8 +7,8 @@ TAG=${1:-r1}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-kernel-timing > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-kernel-timing > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-kernel-timing > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-kernel-timing > /dev/null 2> $OUT/pmc_write.err
 python3 scripts/summarise_pmc.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json
 cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 head -12 $OUT/kernel_stats.csv

@@ -20,7 +20,11 @@ def load(d, counter):
     for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
-                agg[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]].append(float(r["Counter_Value"]))
+                full = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                name = full.split("<")[0]
+                if name == "k_f_tile":  # template <P, MIXED, FUSED>: keep the fused / plain instantiations apart
+                    name = "k_f_tile_fused" if full.rstrip("> ").endswith("true") else "k_f_tile"
+                agg[name].append(float(r["Counter_Value"]))
     return agg
 
 
@@ -37,8 +41,12 @@ for k in sorted(set(fetch) | set(write)):
               "hbm_bytes_per_launch": rd + wr,
               "note": "fetch doubled (16 B/lane streaming reads, gfx950)" if k in STREAM else
                       "fetch raw; mixed access widths, true value between raw and 2x raw"}
-if "k_f_tile" in out:
-    out["f(k_f_tile)"] = out["k_f_tile"]
+for k in ("k_f_tile", "k_f_tile_fused"):
+    if k in out:
+        out[f"f({k})"] = out[k]
+out["_bench_args"] = {"steps": 50, "warmup": 5, "workload": "mesh1m"}
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 for k, v in out.items():
+    if k.startswith("_"):
+        continue
     print(f"{k:24s} launches {v['launches']:4d}  read {v['fetch_bytes_corrected'] / 1e6:9.1f} MB  write {v['write_bytes'] / 1e6:8.1f} MB")
