@@ -16,6 +16,7 @@
 // bitwise reproducible run to run.
 #include "common.h"
 #include <math.h>
+#include <algorithm>
 #include <vector>
 
 // The vector kernels are templated on VEC = elements per thread (16 for long vectors, 4 when N*d is small so that
@@ -44,6 +45,8 @@ struct psignn_broyden {
   int keep_trace = 0;
   int vec = 16;             // elements per thread of the vector kernels
   int nblk = 0, npart = 0;
+  int jgroups = 1;          // block rows of the U/V sweeps (short vectors are also split over the stored pairs)
+  float* jpart = nullptr;   // (jgroups, 3, M) partial axpy sums when jgroups > 1
   float *U = nullptr, *V = nullptr;
   float* xbuf = nullptr;    // (thr+2, M) with trace, else (3, M)
   float *gx = nullptr, *dg = nullptr, *upd = nullptr, *fx = nullptr, *fwork = nullptr;
@@ -281,8 +284,13 @@ template <int VEC>
 __global__ __launch_bounds__(TB) void k_dots(int64_t M, int k, const Status* __restrict__ st,
                                              const float* __restrict__ U, const float* __restrict__ V,
                                              const float* __restrict__ dxv, const float* __restrict__ dgv,
-                                             const float* __restrict__ gv, float* __restrict__ part, int npart, int thr) {
+                                             const float* __restrict__ gv, float* __restrict__ part, int npart, int thr,
+                                             int jstride) {
   if (st->done) return;
+  // blockIdx.y owns the stored pairs [j0, j1): short vectors (small meshes) give few blocks along x, so the
+  // sweep is also split over j to cover the 256 CUs (each j still belongs to exactly one block row)
+  const int j0 = blockIdx.y * jstride, j1 = min(k, j0 + jstride);
+  if (j0 >= j1) return;
   int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
   float dx[VEC], dg[VEC], g[VEC];
   bool act = e0 < M;
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(TB) void k_dots(int64_t M, int k, const Status* __r
   }
   int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
   bool lead = (threadIdx.x & 63) == 0;
-  for (int j = 0; j < k; ++j) {
+  for (int j = j0; j < j1; ++j) {
     float u[VEC], v[VEC];
     float sa = 0.f, sc = 0.f, sb = 0.f;
     if (act) {
@@ -330,27 +338,52 @@ __global__ __launch_bounds__(TB) void k_reduce(const Status* __restrict__ st, co
   if (threadIdx.x == 0) coef[c * thr + j] = (float)s;
 }
 
-// axpy pass.  Writes vT (NaN->0) to V[k], D1 to U[k] (unscaled), D2 to upd, partials of vT.dg, vT.g
+// axpy pass.  Writes vT (NaN->0) to V[k], D1 to U[k] (unscaled), D2 to upd, partials of vT.dg, vT.g.
+// gridDim.y == 1: the whole sum over j in one block column.  gridDim.y > 1 (short vectors): block row y sums its
+// j-range into jpart[y][3][M] and k_axpy_combine finishes -- fixed grouping, so still reproducible.
+template <int VEC>
+__device__ __forceinline__ void axpy_finish(int64_t M, int k, int64_t e0, float* av, float* a1, float* a2, const float* dg,
+                                            const float* g, float* __restrict__ U, float* __restrict__ V,
+                                            float* __restrict__ upd, float& p1, float& p2) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    p1 = fmaf(av[i], dg[i], p1);       // with the raw vT, as the reference divides before scrubbing
+    av[i] = (av[i] != av[i]) ? 0.f : av[i];
+    p2 = fmaf(av[i], g[i], p2);
+  }
+  stv<VEC>(V + (int64_t)k * M, e0, M, av);
+  stv<VEC>(U + (int64_t)k * M, e0, M, a1);
+  stv<VEC>(upd, e0, M, a2);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(TB) void k_axpy(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
                                              float* __restrict__ V, float* __restrict__ upd /* in: dx, out: D2 */,
                                              const float* __restrict__ dgv, const float* __restrict__ gv,
-                                             const float* __restrict__ coef, int thr, float* __restrict__ part, int npart) {
+                                             const float* __restrict__ coef, int thr, float* __restrict__ part, int npart,
+                                             int jstride, float* __restrict__ jpart) {
   if (st->done) return;
+  const bool split = gridDim.y > 1;
+  const int j0 = blockIdx.y * jstride, j1 = min(k, j0 + jstride);
   int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
   float p1 = 0.f, p2 = 0.f;
   if (e0 < M) {
     float av[VEC], a1[VEC], a2[VEC], dg[VEC], g[VEC];
-    ldv<VEC>(upd, e0, M, av);
-    ldv<VEC>(dgv, e0, M, dg);
-    ldv<VEC>(gv, e0, M, g);
+    if (!split) {
+      ldv<VEC>(upd, e0, M, av);
+      ldv<VEC>(dgv, e0, M, dg);
+      ldv<VEC>(gv, e0, M, g);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      a1[i] = av[i] + dg[i];
-      a2[i] = g[i];
-      av[i] = -av[i];
+      for (int i = 0; i < VEC; ++i) {
+        a1[i] = av[i] + dg[i];
+        a2[i] = g[i];
+        av[i] = -av[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) av[i] = a1[i] = a2[i] = 0.f;
     }
-    for (int j = 0; j < k; ++j) {
+    for (int j = j0; j < j1; ++j) {
       float u[VEC], v[VEC];
       float ca = coef[j], cc = coef[thr + j], cb = coef[2 * thr + j];
       ldv_stream<VEC>(U + (int64_t)j * M, e0, M, u);
@@ -362,15 +395,59 @@ __global__ __launch_bounds__(TB) void k_axpy(int64_t M, int k, const Status* __r
         a2[i] = fmaf(-cb, u[i], a2[i]);
       }
     }
+    if (split) {
+      float* base = jpart + (int64_t)blockIdx.y * 3 * M;
+      stv<VEC>(base, e0, M, av);
+      stv<VEC>(base + M, e0, M, a1);
+      stv<VEC>(base + 2 * M, e0, M, a2);
+      return;
+    }
+    axpy_finish<VEC>(M, k, e0, av, a1, a2, dg, g, U, V, upd, p1, p2);
+  }
+  if (split) return;
+  p1 = wave_sum(p1);
+  p2 = wave_sum(p2);
+  if ((threadIdx.x & 63) == 0) {
+    int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+    part[w] = p1;
+    part[npart + w] = p2;
+  }
+}
+
+// second half of a split axpy pass: init terms + the G partial sums, in group order
+template <int VEC>
+__global__ __launch_bounds__(TB) void k_axpy_combine(int64_t M, int k, int G, const Status* __restrict__ st,
+                                                     const float* __restrict__ jpart, float* __restrict__ U,
+                                                     float* __restrict__ V, float* __restrict__ upd,
+                                                     const float* __restrict__ dgv, const float* __restrict__ gv,
+                                                     float* __restrict__ part, int npart) {
+  if (st->done) return;
+  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  float p1 = 0.f, p2 = 0.f;
+  if (e0 < M) {
+    float av[VEC], a1[VEC], a2[VEC], dg[VEC], g[VEC], t[VEC];
+    ldv<VEC>(upd, e0, M, av);
+    ldv<VEC>(dgv, e0, M, dg);
+    ldv<VEC>(gv, e0, M, g);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      p1 = fmaf(av[i], dg[i], p1);       // with the raw vT, as the reference divides before scrubbing
-      av[i] = (av[i] != av[i]) ? 0.f : av[i];
-      p2 = fmaf(av[i], g[i], p2);
+      a1[i] = av[i] + dg[i];
+      a2[i] = g[i];
+      av[i] = -av[i];
     }
-    stv<VEC>(V + (int64_t)k * M, e0, M, av);
-    stv<VEC>(U + (int64_t)k * M, e0, M, a1);
-    stv<VEC>(upd, e0, M, a2);
+    for (int y = 0; y < G; ++y) {
+      const float* base = jpart + (int64_t)y * 3 * M;
+      ldv<VEC>(base, e0, M, t);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) av[i] += t[i];
+      ldv<VEC>(base + M, e0, M, t);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) a1[i] += t[i];
+      ldv<VEC>(base + 2 * M, e0, M, t);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) a2[i] += t[i];
+    }
+    axpy_finish<VEC>(M, k, e0, av, a1, a2, dg, g, U, V, upd, p1, p2);
   }
   p1 = wave_sum(p1);
   p2 = wave_sum(p2);
@@ -449,6 +526,7 @@ static int broyden_alloc(psignn_broyden* s) {
   size_t M = (size_t)s->M, thr = (size_t)s->thr;
   s->vec = s->M >= (int64_t)4 << 20 ? 16 : 4;
   s->nblk = (int)cdiv(s->M, (int64_t)s->vec * TB);
+  s->jgroups = s->nblk >= 768 ? 1 : (int)std::min<int64_t>(8, cdiv(768, s->nblk));
   s->npart = s->nblk * (TB / 64);
   size_t nx = s->keep_trace ? thr + 2 : 3;
   struct { void** p; size_t n; } allocs[] = {
@@ -463,6 +541,14 @@ static int broyden_alloc(psignn_broyden* s) {
       return PSIGNN_ENOMEM;
     }
     s->bytes += a.n;
+  }
+  if (s->jgroups > 1) {
+    size_t jb = (size_t)s->jgroups * 3 * M * 4;
+    if (hipMalloc((void**)&s->jpart, jb) != hipSuccess) {
+      psignn_set_error("broyden: hipMalloc of the split-sweep scratch failed");
+      return PSIGNN_ENOMEM;
+    }
+    s->bytes += jb;
   }
   if (s->plan) {
     size_t wf = (size_t)psignn_f_workspace_floats(s->plan) * 4;
@@ -489,7 +575,7 @@ static int broyden_alloc(psignn_broyden* s) {
 extern "C" void psignn_broyden_destroy(psignn_broyden_t* s) {
   if (!s) return;
   void* ptrs[] = {s->U, s->V, s->xbuf, s->gx, s->dg, s->upd, s->fx, s->fwork, s->part, s->coef, s->st,
-                  s->rel_trace, s->abs_trace, s->h0p, s->prbp, s->nrmp};
+                  s->rel_trace, s->abs_trace, s->h0p, s->prbp, s->nrmp, s->jpart};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (s->h_st) (void)hipHostFree(s->h_st);
@@ -549,11 +635,16 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
   const int np = fused_npart ? fused_npart : s->npart;
   LAUNCH("k_check", st, (k_check<<<1, TB, 0, st>>>(s->st, s->part, np, s->rel_trace, s->abs_trace, eps, s->thr, s->seq_len, s->keep_trace)));
   if (k >= s->thr) return;  // the threshold stop has fired; no slot left for another pair
+  // split of the sweeps over the stored pairs: only when there are enough pairs to share out
+  const int G = (s->jgroups > 1 && k >= 4 * s->jgroups) ? s->jgroups : 1;
+  const int js = (int)cdiv(std::max(k, 1), G);
   if (k > 0) {
-    VLAUNCH("k_dots", st, s->vec, k_dots, (g, TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->npart, s->thr);
+    VLAUNCH("k_dots", st, s->vec, k_dots, (dim3(g, G), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->npart, s->thr, js);
     LAUNCH("k_reduce", st, (k_reduce<<<dim3(k, 3), TB, 0, st>>>(s->st, s->part, s->npart, s->thr, s->coef)));
   }
-  VLAUNCH("k_axpy", st, s->vec, k_axpy, (g, TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->npart);
+  VLAUNCH("k_axpy", st, s->vec, k_axpy, (dim3(g, G), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->npart, js, s->jpart);
+  if (G > 1)
+    VLAUNCH("k_axpy_combine", st, s->vec, k_axpy_combine, (g, TB, 0, st), s->M, k, G, s->st, s->jpart, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->npart);
   LAUNCH("k_reduce2", st, (k_reduce2<<<1, TB, 0, st>>>(s->st, s->part, s->npart)));
   VLAUNCH("k_final", st, s->vec, k_final, (g, TB, 0, st), s->M, k, s->st, s->U, s->upd);
 }
