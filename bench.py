@@ -47,6 +47,7 @@ WORKLOADS = {  # preset -> (nodes per mesh, boundary conditions, meshes per GPU,
     "dir100k": (100_000, "dirichlet", 1, "configs[1]"),
     "mixed100k": (100_000, "mixed", 1, "configs[2]"),
     "batch50k": (50_000, "dirichlet", 8, "configs[3]"),
+    "f1m": (1_000_000, "dirichlet", 1, "configs[4] size, GNN block only"),
 }
 
 
@@ -143,6 +144,31 @@ def main():
     Ep_rank = sum(f.plan.Ep for f in fmaps)
     t_setup = time.time() - t0
     K, W = args.steps, args.warmup
+
+    if args.workload == "f1m":
+        # f only: a step is ONE evaluation of the GNN block (Picard iteration x <- f(x), no solver bookkeeping)
+        xp = fmap.to_plan(fmap.h0)
+        fmap.picard_p(xp, max(W, 1))
+        barrier()
+        t0 = time.perf_counter()
+        xp = fmap.picard_p(xp, K)
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        barrier()
+        assert bool(torch.isfinite(xp).all())
+        b_f = (102 if mixed else 89) * N + 20 * Ep
+        gbs = K * b_f / elapsed / 1e9
+        print(json.dumps({
+            "metric": "GNN-block edges/sec (E' x f evaluations/sec) on 1M-node Poisson mesh", "value": world * Ep * K / elapsed,
+            "unit": "edges/s", "iters_per_sec": world * K / elapsed, "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"f1m: {K} back-to-back evaluations of the {args.bc} GNN block on a {N}-node mesh (plan order)",
+                       "nodes": N, "edges_nonself": Ep},
+            "roofline": {"kernel": "k_f_tile", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": b_f,
+                         "avg_launch_us": 1e6 * elapsed / K}}))
+        return
 
     # ---- warmup: W untimed iterations (own solver object so its memory is released)
     if W > 0:

@@ -115,6 +115,13 @@ int psignn_f_forward_p(const psignn_plan_t* plan, const float* d_weights, int n_
                        const float* d_h, const float* d_h_initial, const float* d_prb,
                        const float* d_normals, float* d_out, float* d_work, void* stream);
 
+/* n successive applications x <- f(x) in plan order without host involvement between them.
+ * replaces: the loop body of forward_iteration (utilities/solver.py:301-341) minus its per-step norms.
+ * d_x: x_0 on entry, x_n on return; d_tmp: a second (N, d) buffer. */
+int psignn_picard_p(const psignn_plan_t* plan, const float* d_weights, int n_layers, float* d_x, float* d_tmp,
+                    const float* d_h_initial, const float* d_prb, const float* d_normals, float* d_work, int n,
+                    void* stream);
+
 /* Single message-passing aggregation (tests / diagnostics): which = 0 Phi_to, 1 Phi_from,
  * 2 Phi_neumann (mixed).  replaces: Phi_to.forward / Phi_from.forward (model.py:334-368). */
 int psignn_phi(const psignn_plan_t* plan, const float* d_weights, int n_layers, int layer, int which,
@@ -127,6 +134,13 @@ int psignn_phi(const psignn_plan_t* plan, const float* d_weights, int n_layers, 
 int psignn_f_jvp(const psignn_plan_t* plan, const float* d_weights, int n_layers,
                  const float* d_h, const float* d_prb, const float* d_normals,
                  const float* d_v, float* d_out, float* d_work, void* stream);
+
+/* Vector-Jacobian product out = w^T (df/dh) at h (dirichlet family, single layer), as two gather passes
+ * over the plan's CSR/CSC lists (no atomics).
+ * replaces: torch.autograd.grad(new_H_star, H_star, y) inside the implicit backward hook
+ *           (dirichlet/psignn/model.py:210-223), jac_loss_estimate (:416-435) and power_method (:437-452). */
+int psignn_f_vjp(const psignn_plan_t* plan, const float* d_weights, int n_layers, const float* d_h,
+                 const float* d_prb, const float* d_w, float* d_out, float* d_work, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Small dense pieces around the solve.

@@ -372,6 +372,22 @@ extern "C" int psignn_f_forward_p(const psignn_plan_t* p, const float* W, int nl
   return psignn_f_eval_p(p, W, nl, h, nullptr, 0, h0, prb, nrm, out, work, (hipStream_t)stream);
 }
 
+// n successive applications x <- f(x) in plan order (the core of forward_iteration, utilities/solver.py:301-341,
+// without its per-step norms): d_x holds x_0 on entry and x_n on return; d_tmp is a second (N, d) buffer.
+extern "C" int psignn_picard_p(const psignn_plan_t* p, const float* W, int nl, float* x, float* tmp, const float* h0,
+                               const float* prb, const float* nrm, float* work, int n, void* stream) {
+  ARG_CHECK(p && x && tmp && x != tmp && n >= 0, "bad arguments");
+  float* cur = x;
+  float* nxt = tmp;
+  for (int i = 0; i < n; ++i) {
+    int rc = psignn_f_eval_p(p, W, nl, cur, nullptr, 0, h0, prb, nrm, nxt, work, (hipStream_t)stream);
+    if (rc) return rc;
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  if (cur != x) HIP_TRY(hipMemcpyAsync(x, cur, (size_t)p->N * D * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return PSIGNN_OK;
+}
+
 extern "C" int psignn_f_forward(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* h0,
                                 const float* prb, const float* nrm, float* out, float* work, void* stream) {
   ARG_CHECK(p != nullptr, "plan is NULL");

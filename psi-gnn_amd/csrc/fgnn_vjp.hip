@@ -1,0 +1,317 @@
+// Vector-Jacobian product of f_theta:  out = w^T (d f / d h)  (gfx950), dirichlet family, single layer.
+//
+// This is what the reference obtains from autograd -- torch.autograd.grad(new_H, H, v) -- inside the implicit
+// backward hook (dirichlet/psignn/model.py:210-223: Broyden on y = J^T y + grad), the Hutchinson Jacobian
+// regulariser (jac_loss_estimate, model.py:416-435) and the power method (model.py:437-452).  SURVEY §8f-1.
+//
+// Autograd scatters every edge's cotangent to the neighbour with index_add.  Here the transpose is written as
+// two GATHER passes over the plan's CSR/CSC lists, so there are no atomics and the result is reproducible:
+//   pass 1 (node n): back through LayerNorm, the gated update MLP and the second Phi layer; keeps
+//           B[n] = { Pt[n], Pf[n] (target-side projections incl. bias), dS_to[n], dS_fr[n] } and writes the
+//           node-local part of the result: dy + U1_h^T dq + w_alpha,h * dalpha + W1i_to^T sum_e g_e + W1i_fr^T sum_e g'_e
+//           with g_e = dS_to[n] * 1[z_e > 0] over n's in-edges, g'_e likewise over its out-edges;
+//   pass 2 (node u): the contributions u receives as somebody's neighbour:
+//           for u's out-edges (u -> n), which are in-edges of n:  acc_t += dS_to[n] * 1[Pt[n] + Pjt[u] + At a > 0]
+//           for u's in-edges  (n -> u), which are out-edges of n: acc_f += dS_fr[n] * 1[Pf[n] + Pjf[u] + Af a > 0]
+//           out[u] += W1j_to^T acc_t + W1j_fr^T acc_f.
+// Dirichlet rows of f are constants (their Jacobian rows vanish): they send nothing, but still receive.
+#include "fgnn_common.h"
+
+// out[k] (+)= sum_o W[o*ld + off + k] * g[o]   (transposed product, W wave-uniform)
+template <int K, bool ACC>
+__device__ __forceinline__ void matvecT(const float* __restrict__ W, int ld, int off, const float* g, float* out) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float s = ACC ? out[k] : 0.f;
+#pragma unroll
+    for (int o = 0; o < D; ++o) s = fmaf(W[o * ld + off + k], g[o], s);
+    out[k] = s;
+  }
+}
+
+// neighbour-side projections Pj[n] = { W1j_to h_n, W1j_fr h_n }
+template <int P>
+__global__ __launch_bounds__(256) void k_vjp_project(int64_t N, const float* __restrict__ W, int lofs,
+                                                     const float* __restrict__ h, float* __restrict__ Pj) {
+  using L = WLayout<P>;
+  int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float x[D], t[D];
+  load10(h + n * D, x);
+  matvec10<D, false>(W + lofs + L::L_TO + L::PHI_W1, L::EIN, D, x, t);
+  store10(Pj + n * 2 * D, t);
+  matvec10<D, false>(W + lofs + L::L_FROM + L::PHI_W1, L::EIN, D, x, t);
+  store10(Pj + n * 2 * D + D, t);
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_vjp_local(int64_t N, const float* __restrict__ W, int lofs,
+                                                   const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_nbr,
+                                                   const float* __restrict__ csr_attr, const int32_t* __restrict__ csc_ptr,
+                                                   const int32_t* __restrict__ csc_nbr, const float* __restrict__ csc_attr,
+                                                   const uint8_t* __restrict__ flags, const float* __restrict__ h,
+                                                   const float* __restrict__ prb, const float* __restrict__ wv,
+                                                   const float* __restrict__ Pj, float* __restrict__ B,
+                                                   float* __restrict__ out) {
+  using L = WLayout<P>;
+  int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float* Wto = W + lofs + L::L_TO;
+  const float* Wfr = W + lofs + L::L_FROM;
+  const float* Wu = W + lofs + L::L_UPD;
+  const float* Wa = W + L::AL_W;
+  float x[D], Pt[D], Pf[D];
+  load10(h + n * D, x);
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    Pt[o] = Wto[L::PHI_B1 + o];
+    Pf[o] = Wfr[L::PHI_B1 + o];
+  }
+  matvec10<D, true>(Wto + L::PHI_W1, L::EIN, 0, x, Pt);
+  matvec10<D, true>(Wfr + L::PHI_W1, L::EIN, 0, x, Pf);
+  float* Bn = B + n * 4 * D;
+  store10(Bn, Pt);
+  store10(Bn + D, Pf);
+  float zero[D];
+#pragma unroll
+  for (int o = 0; o < D; ++o) zero[o] = 0.f;
+  if (flags[n] & FLAG_DIRICHLET) {  // constant row: sends nothing
+    store10(Bn + 2 * D, zero);
+    store10(Bn + 3 * D, zero);
+    store10(out + n * D, zero);
+    return;
+  }
+  // ---- forward recomputation (same order as k_node)
+  float S_to[D], S_fr[D];
+#pragma unroll
+  for (int o = 0; o < D; ++o) S_to[o] = S_fr[o] = 0.f;
+  const int32_t ib = csc_ptr[n], ie = csc_ptr[n + 1], ob = csr_ptr[n], oe = csr_ptr[n + 1];
+  for (int32_t i = ib; i < ie; ++i) {
+    float pj[D];
+    load10(Pj + (int64_t)csc_nbr[i] * 2 * D, pj);
+    float a0 = csc_attr[3 * (int64_t)i], a1 = csc_attr[3 * (int64_t)i + 1], a2 = csc_attr[3 * (int64_t)i + 2];
+#pragma unroll
+    for (int o = 0; o < D; ++o) {
+      float z = Pt[o] + pj[o];
+      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D], a0, z);
+      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D + 1], a1, z);
+      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D + 2], a2, z);
+      S_to[o] += fmaxf(z, 0.f);
+    }
+  }
+  for (int32_t i = ob; i < oe; ++i) {
+    float pj[D];
+    load10(Pj + (int64_t)csr_nbr[i] * 2 * D + D, pj);
+    float a0 = csr_attr[3 * (int64_t)i], a1 = csr_attr[3 * (int64_t)i + 1], a2 = csr_attr[3 * (int64_t)i + 2];
+#pragma unroll
+    for (int o = 0; o < D; ++o) {
+      float z = Pf[o] + pj[o];
+      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D], a0, z);
+      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D + 1], a1, z);
+      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D + 2], a2, z);
+      S_fr[o] += fmaxf(z, 0.f);
+    }
+  }
+  float mp_to[D], mp_fr[D], pq[P];
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    mp_to[o] = (float)(ie - ib) * Wto[L::PHI_B2 + o];
+    mp_fr[o] = (float)(oe - ob) * Wfr[L::PHI_B2 + o];
+  }
+  matvec10<D, true>(Wto + L::PHI_W2, D, 0, S_to, mp_to);
+  matvec10<D, true>(Wfr + L::PHI_W2, D, 0, S_fr, mp_fr);
+#pragma unroll
+  for (int k = 0; k < P; ++k) pq[k] = prb[n * P + k];
+  float al = W[L::AL_B];
+#pragma unroll
+  for (int k = 0; k < D; ++k) al = fmaf(Wa[k], x[k], al);
+#pragma unroll
+  for (int k = 0; k < D; ++k) al = fmaf(Wa[D + k], mp_to[k], al);
+#pragma unroll
+  for (int k = 0; k < D; ++k) al = fmaf(Wa[2 * D + k], mp_fr[k], al);
+#pragma unroll
+  for (int k = 0; k < P; ++k) al = fmaf(Wa[3 * D + k], pq[k], al);
+  al = 1.f / (1.f + expf(-al));
+  float q[D], upd[D], y[D];
+#pragma unroll
+  for (int o = 0; o < D; ++o) q[o] = Wu[L::UPD_B1 + o];
+  matvec10<D, true>(Wu + L::UPD_W1, L::CAT, 0, x, q);
+  matvec10<D, true>(Wu + L::UPD_W1, L::CAT, D, mp_to, q);
+  matvec10<D, true>(Wu + L::UPD_W1, L::CAT, 2 * D, mp_fr, q);
+  matvec10<P, true>(Wu + L::UPD_W1, L::CAT, 3 * D, pq, q);
+  float hid[D];
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    hid[o] = fmaxf(q[o], 0.f);
+    upd[o] = Wu[L::UPD_B2 + o];
+  }
+  matvec10<D, true>(Wu + L::UPD_W2, D, 0, hid, upd);
+  float mu = 0.f;
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    y[o] = fmaf(al, upd[o], x[o]);
+    mu += y[o];
+  }
+  mu *= (1.f / D);
+  float var = 0.f;
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    float c = y[o] - mu;
+    var = fmaf(c, c, var);
+  }
+  var *= (1.f / D);
+  const float rs = 1.f / sqrtf(var + 1e-5f);
+  // ---- backward: LayerNorm
+  float dyh[D], dy[D], w[D];
+  load10(wv + n * D, w);
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    y[o] = (y[o] - mu) * rs;  // normalised
+    dyh[o] = w[o] * W[L::LN_G + o];
+    m1 += dyh[o];
+    m2 = fmaf(dyh[o], y[o], m2);
+  }
+  m1 *= (1.f / D);
+  m2 *= (1.f / D);
+  float dal = 0.f, dupd[D], g[D];
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    dy[o] = rs * (dyh[o] - m1 - y[o] * m2);
+    dal = fmaf(dy[o], upd[o], dal);
+    dupd[o] = al * dy[o];
+    g[o] = dy[o];  // accumulates the node-local result; starts with the residual path y = x + ...
+  }
+  dal *= al * (1.f - al);
+  // ---- update MLP and gate
+  float dq[D], dmp_to[D], dmp_fr[D];
+  matvecT<D, false>(Wu + L::UPD_W2, D, 0, dupd, dq);
+#pragma unroll
+  for (int o = 0; o < D; ++o) dq[o] = q[o] > 0.f ? dq[o] : 0.f;
+  matvecT<D, true>(Wu + L::UPD_W1, L::CAT, 0, dq, g);
+  matvecT<D, false>(Wu + L::UPD_W1, L::CAT, D, dq, dmp_to);
+  matvecT<D, false>(Wu + L::UPD_W1, L::CAT, 2 * D, dq, dmp_fr);
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    g[k] = fmaf(Wa[k], dal, g[k]);
+    dmp_to[k] = fmaf(Wa[D + k], dal, dmp_to[k]);
+    dmp_fr[k] = fmaf(Wa[2 * D + k], dal, dmp_fr[k]);
+  }
+  // ---- second Phi layer
+  float dS_to[D], dS_fr[D];
+  matvecT<D, false>(Wto + L::PHI_W2, D, 0, dmp_to, dS_to);
+  matvecT<D, false>(Wfr + L::PHI_W2, D, 0, dmp_fr, dS_fr);
+  store10(Bn + 2 * D, dS_to);
+  store10(Bn + 3 * D, dS_fr);
+  // ---- target-side projections: sum of the masked cotangents over the node's own edges
+  float gt[D], gf[D];
+#pragma unroll
+  for (int o = 0; o < D; ++o) gt[o] = gf[o] = 0.f;
+  for (int32_t i = ib; i < ie; ++i) {
+    float pj[D];
+    load10(Pj + (int64_t)csc_nbr[i] * 2 * D, pj);
+    float a0 = csc_attr[3 * (int64_t)i], a1 = csc_attr[3 * (int64_t)i + 1], a2 = csc_attr[3 * (int64_t)i + 2];
+#pragma unroll
+    for (int o = 0; o < D; ++o) {
+      float z = Pt[o] + pj[o];
+      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D], a0, z);
+      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D + 1], a1, z);
+      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D + 2], a2, z);
+      gt[o] += z > 0.f ? dS_to[o] : 0.f;
+    }
+  }
+  for (int32_t i = ob; i < oe; ++i) {
+    float pj[D];
+    load10(Pj + (int64_t)csr_nbr[i] * 2 * D + D, pj);
+    float a0 = csr_attr[3 * (int64_t)i], a1 = csr_attr[3 * (int64_t)i + 1], a2 = csr_attr[3 * (int64_t)i + 2];
+#pragma unroll
+    for (int o = 0; o < D; ++o) {
+      float z = Pf[o] + pj[o];
+      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D], a0, z);
+      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D + 1], a1, z);
+      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D + 2], a2, z);
+      gf[o] += z > 0.f ? dS_fr[o] : 0.f;
+    }
+  }
+  matvecT<D, true>(Wto + L::PHI_W1, L::EIN, 0, gt, g);
+  matvecT<D, true>(Wfr + L::PHI_W1, L::EIN, 0, gf, g);
+  store10(out + n * D, g);
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_vjp_remote(int64_t N, const float* __restrict__ W, int lofs,
+                                                    const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_nbr,
+                                                    const float* __restrict__ csr_attr, const int32_t* __restrict__ csc_ptr,
+                                                    const int32_t* __restrict__ csc_nbr, const float* __restrict__ csc_attr,
+                                                    const float* __restrict__ Pj, const float* __restrict__ B,
+                                                    float* __restrict__ out) {
+  using L = WLayout<P>;
+  int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= N) return;
+  const float* Wto = W + lofs + L::L_TO;
+  const float* Wfr = W + lofs + L::L_FROM;
+  float pjt[D], pjf[D], at[D], af[D];
+  load10(Pj + u * 2 * D, pjt);
+  load10(Pj + u * 2 * D + D, pjf);
+#pragma unroll
+  for (int o = 0; o < D; ++o) at[o] = af[o] = 0.f;
+  // u's out-edges (u -> n) are in-edges of n: Phi_to terms of n that read h[u]
+  for (int32_t i = csr_ptr[u]; i < csr_ptr[u + 1]; ++i) {
+    const float* Bn = B + (int64_t)csr_nbr[i] * 4 * D;
+    float pt[D], ds[D];
+    load10(Bn, pt);
+    load10(Bn + 2 * D, ds);
+    float a0 = csr_attr[3 * (int64_t)i], a1 = csr_attr[3 * (int64_t)i + 1], a2 = csr_attr[3 * (int64_t)i + 2];
+#pragma unroll
+    for (int o = 0; o < D; ++o) {
+      float z = pt[o] + pjt[o];
+      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D], a0, z);
+      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D + 1], a1, z);
+      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D + 2], a2, z);
+      at[o] += z > 0.f ? ds[o] : 0.f;
+    }
+  }
+  // u's in-edges (n -> u) are out-edges of n: Phi_from terms of n that read h[u]
+  for (int32_t i = csc_ptr[u]; i < csc_ptr[u + 1]; ++i) {
+    const float* Bn = B + (int64_t)csc_nbr[i] * 4 * D;
+    float pf[D], ds[D];
+    load10(Bn + D, pf);
+    load10(Bn + 3 * D, ds);
+    float a0 = csc_attr[3 * (int64_t)i], a1 = csc_attr[3 * (int64_t)i + 1], a2 = csc_attr[3 * (int64_t)i + 2];
+#pragma unroll
+    for (int o = 0; o < D; ++o) {
+      float z = pf[o] + pjf[o];
+      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D], a0, z);
+      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D + 1], a1, z);
+      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D + 2], a2, z);
+      af[o] += z > 0.f ? ds[o] : 0.f;
+    }
+  }
+  float g[D];
+  load10(out + u * D, g);
+  matvecT<D, true>(Wto + L::PHI_W1, L::EIN, D, at, g);
+  matvecT<D, true>(Wfr + L::PHI_W1, L::EIN, D, af, g);
+  store10(out + u * D, g);
+}
+
+extern "C" int psignn_f_vjp(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* prb,
+                            const float* w, float* out, float* work, void* stream) {
+  ARG_CHECK(p && W && h && prb && w && out && work, "NULL argument");
+  ARG_CHECK(!p->mixed, "VJP of the mixed (Neumann) block is not implemented yet");
+  ARG_CHECK(nl == 1, "VJP of a multi-layer block is not implemented");
+  ARG_CHECK(out != w && out != h, "out must not alias its inputs");
+  using L = WLayout<2>;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)cdiv(p->N, 256);
+  float* Pj = work;                // (N, 20)
+  float* B = work + p->N * 2 * D;  // (N, 40)
+  LAUNCH("k_vjp_project", st, (k_vjp_project<2><<<grid, 256, 0, st>>>(p->N, W, L::layer(0), h, Pj)));
+  LAUNCH("k_vjp_local", st, (k_vjp_local<2><<<grid, 256, 0, st>>>(p->N, W, L::layer(0), p->csr_ptr, p->csr_nbr, p->csr_attr,
+                                                                    p->csc_ptr, p->csc_nbr, p->csc_attr, p->flags, h, prb,
+                                                                    w, Pj, B, out)));
+  LAUNCH("k_vjp_remote", st, (k_vjp_remote<2><<<grid, 256, 0, st>>>(p->N, W, L::layer(0), p->csr_ptr, p->csr_nbr,
+                                                                      p->csr_attr, p->csc_ptr, p->csc_nbr, p->csc_attr, Pj,
+                                                                      B, out)));
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}

@@ -162,6 +162,13 @@ class MeshPlan:
             pos = pos.to(torch.float32).contiguous()
             if pos.shape != (N, 2) or pos.device != self.device:
                 pos = None  # coordinates only steer the tiling; without them the given numbering is kept
+        gid = getattr(batch, "batch", None)
+        if pos is not None and gid is not None and gid.numel() == N and int(gid.max()) > 0:
+            # disjoint union of graphs (PyG Batch): the graphs overlap in space, which would mix them inside a tile.
+            # Shift graph g by g bounding-box widths for the TILING only (positions never enter the arithmetic).
+            span = (pos[:, 0].max() - pos[:, 0].min()) * 1.05 + 1e-6
+            pos = pos.clone()
+            pos[:, 0] += gid.to(pos.dtype) * span
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             nat.check(nat.lib().psignn_plan_create(C.byref(h), N, eic.shape[1], nat.ptr(eic), nat.ptr(ea),
@@ -289,6 +296,20 @@ class FixedPointMap:
                                                  nat.stream_ptr(Hc.device)), "psignn_f_forward")
         return out
 
+    def picard_p(self, Hp, n):
+        """n applications of f in plan order, back to back on the device (no host work in between)."""
+        if self._p is None:
+            self.fp(Hp)
+        h0p, prbp, nrmp = self._p
+        x = _f32c(Hp).clone()
+        tmp = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            nat.check(nat.lib().psignn_picard_p(self.plan.handle, nat.ptr(self.weights.flat), self.weights.n_layers,
+                                                nat.ptr(x), nat.ptr(tmp), nat.ptr(h0p), nat.ptr(prbp), nat.ptr(nrmp),
+                                                nat.ptr(self.plan.workspace()), int(n), nat.stream_ptr(x.device)),
+                      "psignn_picard_p")
+        return x
+
     def jvp(self, H, V):
         """Analytic J_f(H) V."""
         Hc, Vc = _f32c(H), _f32c(V)
@@ -298,6 +319,17 @@ class FixedPointMap:
                                              nat.ptr(Hc), nat.ptr(self.prb), nat.ptr(self.nrm), nat.ptr(Vc),
                                              nat.ptr(out), nat.ptr(self.plan.workspace()),
                                              nat.stream_ptr(Hc.device)), "psignn_f_jvp")
+        return out
+
+    def vjp(self, H, Wv):
+        """Wv^T J_f(H): what ``autograd.grad(f(H), H, Wv)`` returns in the reference (model.py:214,432,449)."""
+        Hc, Wc = _f32c(H), _f32c(Wv)
+        out = torch.empty_like(Hc)
+        with torch.cuda.device(Hc.device):
+            nat.check(nat.lib().psignn_f_vjp(self.plan.handle, nat.ptr(self.weights.flat), self.weights.n_layers,
+                                             nat.ptr(Hc), nat.ptr(self.prb), nat.ptr(Wc), nat.ptr(out),
+                                             nat.ptr(self.plan.workspace()), nat.stream_ptr(Hc.device)),
+                      "psignn_f_vjp")
         return out
 
     def phi(self, H, which: int, layer: int = 0):

@@ -148,6 +148,35 @@ class DeepEquilibrium(nn.Module):
 
     inference = forward  # dirichlet/psignn/model.py:245-253
 
+    # ---- adjoint side of the reference's training variant (dirichlet/psignn/model.py:204-241), on the VJP kernel
+    def implicit_backward(self, H_star, H_init, batch, grad):
+        """Solve y = J_f(H*)^T y + grad with the configured solver (the reference's backward hook, model.py:210-223):
+        returns the solver dict; ``out["result"]`` is the gradient w.r.t. the fixed point's input."""
+        fmap = self.f.bind(H_init, batch)
+        g = grad.contiguous()
+        return self.config_deq["solver"](lambda y: fmap.vjp(H_star, y) + g, torch.zeros_like(g),
+                                         threshold=self.config_deq["bw_thres"], eps=self.config_deq["bw_tol"])
+
+    def jac_loss_estimate(self, H_star, H_init, batch, vecs=1, generator=None):
+        """Hutchinson estimate of tr(J^T J) / (N d) (model.py:416-435) with the VJP kernel."""
+        fmap = self.f.bind(H_init, batch)
+        acc = 0.0
+        for _ in range(vecs):
+            v = torch.randn(H_star.shape, device=H_star.device, generator=generator)
+            acc = acc + fmap.vjp(H_star, v).norm() ** 2
+        return acc / vecs / H_star.numel()
+
+    def power_method(self, H_star, H_init, batch, n_iters=150, generator=None):
+        """Spectral-radius estimate of J by power iteration on v^T J (model.py:437-452)."""
+        fmap = self.f.bind(H_init, batch)
+        ev = torch.randn(H_star.shape, device=H_star.device, generator=generator)
+        val = torch.zeros((), device=H_star.device)
+        for _ in range(n_iters):
+            vj = fmap.vjp(H_star, ev)
+            val = (vj * ev).sum() / (ev * ev).sum()
+            ev = vj / vj.norm()
+        return ev, val.abs()
+
 
 # ----------------------------------------------------------------------------------------------
 # models
