@@ -61,6 +61,11 @@ __device__ __forceinline__ void lds_load10at(const float* __restrict__ p, float*
 // 79 us instead of 67 us per 1M-node evaluation -- it costs a wave slot per workgroup for the whole residency.)
 #define TILE_THREADS 256
 
+// 1: stage-1 projections on the matrix cores (v_mfma_f32_16x16x4_f32); 0: packed-VALU form (A/B builds)
+#ifndef PSIGNN_MFMA_STAGE1
+#define PSIGNN_MFMA_STAGE1 1
+#endif
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
@@ -193,6 +198,68 @@ __global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tile
 
   // ---- stage 1: neighbour-side projections of tile + halo rows -> LDS
   float x[D];
+#if PSIGNN_MFMA_STAGE1
+  {
+    // Dense node-feature x weight product on the matrix cores: out[row][o] = sum_k x[row][k] W1j[o][k] as
+    // v_mfma_f32_16x16x4_f32 tiles with the WEIGHTS as the A operand (A[i = output][k]) and the node rows as B
+    // (B[k][j = row]): a lane then receives D[i = 4 (lane>>4) + r][j = lane&15], r = 0..3 -- four consecutive
+    // outputs of ONE row -- which is a single 16-byte LDS store.  The f32 MFMA accumulates k in order as an fma
+    // chain starting from 0 (MI355X guide, 'FP32-input MFMA'), i.e. the same sum as the VALU form.  K = 10 is
+    // padded to 12 (three k-steps), the 20 / 30 outputs to 32 (two M-tiles); 16 rows per N-tile, N-tiles dealt
+    // round-robin to the 4 waves.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NOUT = MIXED ? 30 : 20;
+    const int lane = tid & 63, g = lane >> 4, c = lane & 15, wave = tid >> 6;
+    float wa[2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int o = 16 * mt + c, k = 4 * s + g;
+        float v = 0.f;
+        if (k < D && o < NOUT) {
+          const float* blk = o < D ? T + L::T_W1J_TO : (o < 2 * D ? T + L::T_W1J_FR : TN + L::N_W1J);
+          v = blk[k * D + (o % D)];
+        }
+        wa[mt][s] = v;
+      }
+    const int rows = n_t + n_h;
+    for (int nt = wave; nt * 16 < rows; nt += TILE_THREADS / 64) {
+      const int row = nt * 16 + c;
+      const bool ok = row < rows;
+      const int64_t node = !ok ? (int64_t)t0 : (row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t]);
+      float xb[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int k = 4 * s + g;
+        float v = 0.f;
+        if (ok && k < D) {
+          v = h[node * D + k];
+          if (FUSED) v += fa.upd[node * D + k];  // x_next = x_cur + update
+        }
+        xb[s] = v;
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][s], xb[s], acc, 0, 0, 0);
+        const int o0 = 16 * mt + 4 * g;
+        if (ok && o0 < (MIXED ? RS : NOUT))
+          *reinterpret_cast<float4*>(lds + row * RS + o0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      }
+    }
+    if (tid < n_t) {  // this lane's own node state for stage 2 (L1/L2-hot: the rows were just read above)
+      load10(h + (int64_t)(t0 + tid) * D, x);
+      if (FUSED) {
+        float ur[D];
+        load10(fa.upd + (int64_t)(t0 + tid) * D, ur);
+#pragma unroll
+        for (int o = 0; o < D; ++o) x[o] += ur[o];
+      }
+    }
+  }
+#else
   for (int row = tid; row < n_t + n_h; row += TILE_THREADS) {
     const int64_t node = row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t];
     float xr[D];
@@ -227,6 +294,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tile
       reinterpret_cast<float2*>(q + 7)[0] = make_float2(ta[4].x, ta[4].y);
     }
   }
+#endif
   __syncthreads();
   if (!FUSED && tid >= n_t) return;
 
