@@ -135,12 +135,13 @@ int psignn_f_jvp(const psignn_plan_t* plan, const float* d_weights, int n_layers
                  const float* d_h, const float* d_prb, const float* d_normals,
                  const float* d_v, float* d_out, float* d_work, void* stream);
 
-/* Vector-Jacobian product out = w^T (df/dh) at h (dirichlet family, single layer), as two gather passes
- * over the plan's CSR/CSC lists (no atomics).
+/* Vector-Jacobian product out = w^T (df/dh) at h (both families), as two gather passes over the plan's
+ * CSR/CSC lists (no atomics).  d_normals: (N,2) for mixed plans, else NULL.
  * replaces: torch.autograd.grad(new_H_star, H_star, y) inside the implicit backward hook
  *           (dirichlet/psignn/model.py:210-223), jac_loss_estimate (:416-435) and power_method (:437-452). */
 int psignn_f_vjp(const psignn_plan_t* plan, const float* d_weights, int n_layers, const float* d_h,
-                 const float* d_prb, const float* d_w, float* d_out, float* d_work, void* stream);
+                 const float* d_prb, const float* d_normals, const float* d_w, float* d_out, float* d_work,
+                 void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Small dense pieces around the solve.

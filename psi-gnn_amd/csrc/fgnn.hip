@@ -297,8 +297,9 @@ extern "C" int64_t psignn_weights_size(int mixed, int n_layers) {
 
 extern "C" int64_t psignn_f_workspace_floats(const psignn_plan_t* p) {
   if (!p) return -1;
-  // Pj (value + tangent rows, up to 3 Phi modules) + two (N,10) ping-pong buffers for n_layers > 1
-  return p->N * (2 * 3 * D + 2 * D);
+  // Pj (value + tangent rows, up to 3 Phi modules) + two (N,10) ping-pong buffers for n_layers > 1;
+  // the VJP keeps Pj (30) + B (60) rows per node
+  return p->N * (10 * D);
 }
 
 template <int P, bool MIXED, bool JVP>

@@ -1,4 +1,5 @@
-// Vector-Jacobian product of f_theta:  out = w^T (d f / d h)  (gfx950), dirichlet family, single layer.
+// Vector-Jacobian product of f_theta:  out = w^T (d f / d h)  (gfx950), both families (a multi-layer mixed block only
+// applies its last layer, mixed/psignn/model.py:221-245; multi-layer dirichlet blocks are not supported).
 //
 // This is what the reference obtains from autograd -- torch.autograd.grad(new_H, H, v) -- inside the implicit
 // backward hook (dirichlet/psignn/model.py:210-223: Broyden on y = J^T y + grad), the Hutchinson Jacobian
@@ -7,14 +8,18 @@
 // Autograd scatters every edge's cotangent to the neighbour with index_add.  Here the transpose is written as
 // two GATHER passes over the plan's CSR/CSC lists, so there are no atomics and the result is reproducible:
 //   pass 1 (node n): back through LayerNorm, the gated update MLP and the second Phi layer; keeps
-//           B[n] = { Pt[n], Pf[n] (target-side projections incl. bias), dS_to[n], dS_fr[n] } and writes the
-//           node-local part of the result: dy + U1_h^T dq + w_alpha,h * dalpha + W1i_to^T sum_e g_e + W1i_fr^T sum_e g'_e
+//           B[n] = { Pt[n], Pf[n] (target-side projections incl. bias), dS_to[n], dS_fr[n] [, Pn[n], dS_n[n]] } and
+//           writes the node-local part of the result:
+//           dy + U1_h^T dq + w_alpha,h * dalpha + W1i_to^T sum_e g_e + W1i_fr^T sum_e g'_e
 //           with g_e = dS_to[n] * 1[z_e > 0] over n's in-edges, g'_e likewise over its out-edges;
 //   pass 2 (node u): the contributions u receives as somebody's neighbour:
 //           for u's out-edges (u -> n), which are in-edges of n:  acc_t += dS_to[n] * 1[Pt[n] + Pjt[u] + At a > 0]
 //           for u's in-edges  (n -> u), which are out-edges of n: acc_f += dS_fr[n] * 1[Pf[n] + Pjf[u] + Af a > 0]
 //           out[u] += W1j_to^T acc_t + W1j_fr^T acc_f.
 // Dirichlet rows of f are constants (their Jacobian rows vanish): they send nothing, but still receive.
+// Mixed family: a Neumann row is REPLACED by update_neumann([h, Phi_neumann(h), prb, normal]) before LayerNorm
+// (mixed/psignn/model.py:236,241), so its cotangent flows through that branch only (Phi_neumann is of the
+// Phi_from type: out-edges of n; pass 2 adds acc_n over u's in-edges).
 #include "fgnn_common.h"
 
 // out[k] (+)= sum_o W[o*ld + off + k] * g[o]   (transposed product, W wave-uniform)
@@ -29,88 +34,186 @@ __device__ __forceinline__ void matvecT(const float* __restrict__ W, int ld, int
   }
 }
 
-// neighbour-side projections Pj[n] = { W1j_to h_n, W1j_fr h_n }
-template <int P>
-__global__ __launch_bounds__(256) void k_vjp_project(int64_t N, const float* __restrict__ W, int lofs,
+// z[o] = Pi[o] + pj[o] + W1[o, 20:23] . a   (pre-activation of one edge; W1 = first Phi layer, ld = 23)
+__device__ __forceinline__ void edge_z(const float* __restrict__ W1, const float* Pi, const float* pj, float a0, float a1,
+                                       float a2, float* z) {
+  constexpr int EIN = 2 * D + 3;
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    float t = Pi[o] + pj[o];
+    t = fmaf(W1[o * EIN + 2 * D], a0, t);
+    t = fmaf(W1[o * EIN + 2 * D + 1], a1, t);
+    t = fmaf(W1[o * EIN + 2 * D + 2], a2, t);
+    z[o] = t;
+  }
+}
+
+// neighbour-side projections Pj[n] = { W1j_to h_n, W1j_fr h_n [, W1j_neu h_n] }
+template <int P, bool MIXED>
+__global__ __launch_bounds__(256) void k_vjp_project(int64_t N, const float* __restrict__ W, int lofs, int nofs,
                                                      const float* __restrict__ h, float* __restrict__ Pj) {
   using L = WLayout<P>;
+  constexpr int NP = MIXED ? 3 : 2;
   int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float x[D], t[D];
   load10(h + n * D, x);
   matvec10<D, false>(W + lofs + L::L_TO + L::PHI_W1, L::EIN, D, x, t);
-  store10(Pj + n * 2 * D, t);
+  store10(Pj + n * NP * D, t);
   matvec10<D, false>(W + lofs + L::L_FROM + L::PHI_W1, L::EIN, D, x, t);
-  store10(Pj + n * 2 * D + D, t);
+  store10(Pj + n * NP * D + D, t);
+  if (MIXED) {
+    matvec10<D, false>(W + nofs + L::PHI_W1, L::EIN, D, x, t);
+    store10(Pj + n * NP * D + 2 * D, t);
+  }
 }
 
-template <int P>
-__global__ __launch_bounds__(256) void k_vjp_local(int64_t N, const float* __restrict__ W, int lofs,
+template <int P, bool MIXED>
+__global__ __launch_bounds__(256) void k_vjp_local(int64_t N, const float* __restrict__ W, int lofs, int nofs, int unofs,
                                                    const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_nbr,
                                                    const float* __restrict__ csr_attr, const int32_t* __restrict__ csc_ptr,
                                                    const int32_t* __restrict__ csc_nbr, const float* __restrict__ csc_attr,
                                                    const uint8_t* __restrict__ flags, const float* __restrict__ h,
-                                                   const float* __restrict__ prb, const float* __restrict__ wv,
-                                                   const float* __restrict__ Pj, float* __restrict__ B,
-                                                   float* __restrict__ out) {
+                                                   const float* __restrict__ prb, const float* __restrict__ nrm,
+                                                   const float* __restrict__ wv, const float* __restrict__ Pj,
+                                                   float* __restrict__ B, float* __restrict__ out) {
   using L = WLayout<P>;
+  constexpr int NP = MIXED ? 3 : 2;   // Pj row = NP * 10 floats
+  constexpr int NB = MIXED ? 6 : 4;   // B row  = NB * 10 floats
   int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   const float* Wto = W + lofs + L::L_TO;
   const float* Wfr = W + lofs + L::L_FROM;
+  const float* Wn = W + nofs;
   const float* Wu = W + lofs + L::L_UPD;
   const float* Wa = W + L::AL_W;
-  float x[D], Pt[D], Pf[D];
+  const uint8_t fl = flags[n];
+  float x[D], Pt[D], Pf[D], Pn[D], zero[D];
   load10(h + n * D, x);
 #pragma unroll
   for (int o = 0; o < D; ++o) {
     Pt[o] = Wto[L::PHI_B1 + o];
     Pf[o] = Wfr[L::PHI_B1 + o];
+    zero[o] = 0.f;
   }
   matvec10<D, true>(Wto + L::PHI_W1, L::EIN, 0, x, Pt);
   matvec10<D, true>(Wfr + L::PHI_W1, L::EIN, 0, x, Pf);
-  float* Bn = B + n * 4 * D;
+  float* Bn = B + n * NB * D;
   store10(Bn, Pt);
   store10(Bn + D, Pf);
-  float zero[D];
+  if (MIXED) {
 #pragma unroll
-  for (int o = 0; o < D; ++o) zero[o] = 0.f;
-  if (flags[n] & FLAG_DIRICHLET) {  // constant row: sends nothing
+    for (int o = 0; o < D; ++o) Pn[o] = Wn[L::PHI_B1 + o];
+    matvec10<D, true>(Wn + L::PHI_W1, L::EIN, 0, x, Pn);
+    store10(Bn + 4 * D, Pn);
+  }
+  if (fl & FLAG_DIRICHLET) {  // constant row: sends nothing
     store10(Bn + 2 * D, zero);
     store10(Bn + 3 * D, zero);
+    if (MIXED) store10(Bn + 5 * D, zero);
     store10(out + n * D, zero);
     return;
   }
-  // ---- forward recomputation (same order as k_node)
-  float S_to[D], S_fr[D];
+  const int32_t ib = csc_ptr[n], ie = csc_ptr[n + 1], ob = csr_ptr[n], oe = csr_ptr[n + 1];
+  float w[D], g[D];
+  load10(wv + n * D, w);
+
+  if (MIXED && (fl & FLAG_NEUMANN)) {
+    // ------------------------------------------------------------------ Neumann row: y = update_neumann(cat_n)
+    const float* Un = W + unofs;
+    float S_n[D], z[D], pj[D];
+#pragma unroll
+    for (int o = 0; o < D; ++o) S_n[o] = 0.f;
+    for (int32_t i = ob; i < oe; ++i) {
+      load10(Pj + (int64_t)csr_nbr[i] * NP * D + 2 * D, pj);
+      edge_z(Wn + L::PHI_W1, Pn, pj, csr_attr[3 * (int64_t)i], csr_attr[3 * (int64_t)i + 1], csr_attr[3 * (int64_t)i + 2], z);
+#pragma unroll
+      for (int o = 0; o < D; ++o) S_n[o] += fmaxf(z[o], 0.f);
+    }
+    float mp_n[D], q[D], hid[D], y[D];
+#pragma unroll
+    for (int o = 0; o < D; ++o) {
+      mp_n[o] = (float)(oe - ob) * Wn[L::PHI_B2 + o];
+      q[o] = Un[L::NEU_B1 + o];
+    }
+    matvec10<D, true>(Wn + L::PHI_W2, D, 0, S_n, mp_n);
+    matvec10<D, true>(Un + L::NEU_W1, L::NEU_CAT, 0, x, q);
+    matvec10<D, true>(Un + L::NEU_W1, L::NEU_CAT, D, mp_n, q);
+    float pq[P + 2];
+#pragma unroll
+    for (int k = 0; k < P; ++k) pq[k] = prb[n * P + k];
+    pq[P] = nrm[n * 2];
+    pq[P + 1] = nrm[n * 2 + 1];
+    matvec10<P + 2, true>(Un + L::NEU_W1, L::NEU_CAT, 2 * D, pq, q);
+#pragma unroll
+    for (int o = 0; o < D; ++o) {
+      hid[o] = fmaxf(q[o], 0.f);
+      y[o] = Un[L::NEU_B2 + o];
+    }
+    matvec10<D, true>(Un + L::NEU_W2, D, 0, hid, y);
+    // LayerNorm backward
+    float mu = 0.f, var = 0.f;
+#pragma unroll
+    for (int o = 0; o < D; ++o) mu += y[o];
+    mu *= (1.f / D);
+#pragma unroll
+    for (int o = 0; o < D; ++o) {
+      float c = y[o] - mu;
+      var = fmaf(c, c, var);
+    }
+    var *= (1.f / D);
+    const float rs = 1.f / sqrtf(var + 1e-5f);
+    float dyh[D], dy[D], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int o = 0; o < D; ++o) {
+      y[o] = (y[o] - mu) * rs;
+      dyh[o] = w[o] * W[L::LN_G + o];
+      m1 += dyh[o];
+      m2 = fmaf(dyh[o], y[o], m2);
+    }
+    m1 *= (1.f / D);
+    m2 *= (1.f / D);
+#pragma unroll
+    for (int o = 0; o < D; ++o) dy[o] = rs * (dyh[o] - m1 - y[o] * m2);
+    float dq[D], dmp_n[D], dS_n[D];
+    matvecT<D, false>(Un + L::NEU_W2, D, 0, dy, dq);
+#pragma unroll
+    for (int o = 0; o < D; ++o) dq[o] = q[o] > 0.f ? dq[o] : 0.f;
+    matvecT<D, false>(Un + L::NEU_W1, L::NEU_CAT, 0, dq, g);        // no residual path: the row was replaced
+    matvecT<D, false>(Un + L::NEU_W1, L::NEU_CAT, D, dq, dmp_n);
+    matvecT<D, false>(Wn + L::PHI_W2, D, 0, dmp_n, dS_n);
+    store10(Bn + 2 * D, zero);
+    store10(Bn + 3 * D, zero);
+    store10(Bn + 5 * D, dS_n);
+    float gn[D];
+#pragma unroll
+    for (int o = 0; o < D; ++o) gn[o] = 0.f;
+    for (int32_t i = ob; i < oe; ++i) {
+      load10(Pj + (int64_t)csr_nbr[i] * NP * D + 2 * D, pj);
+      edge_z(Wn + L::PHI_W1, Pn, pj, csr_attr[3 * (int64_t)i], csr_attr[3 * (int64_t)i + 1], csr_attr[3 * (int64_t)i + 2], z);
+#pragma unroll
+      for (int o = 0; o < D; ++o) gn[o] += z[o] > 0.f ? dS_n[o] : 0.f;
+    }
+    matvecT<D, true>(Wn + L::PHI_W1, L::EIN, 0, gn, g);
+    store10(out + n * D, g);
+    return;
+  }
+
+  // ---------------------------------------------------------------------- interior row
+  float S_to[D], S_fr[D], z[D], pj[D];
 #pragma unroll
   for (int o = 0; o < D; ++o) S_to[o] = S_fr[o] = 0.f;
-  const int32_t ib = csc_ptr[n], ie = csc_ptr[n + 1], ob = csr_ptr[n], oe = csr_ptr[n + 1];
   for (int32_t i = ib; i < ie; ++i) {
-    float pj[D];
-    load10(Pj + (int64_t)csc_nbr[i] * 2 * D, pj);
-    float a0 = csc_attr[3 * (int64_t)i], a1 = csc_attr[3 * (int64_t)i + 1], a2 = csc_attr[3 * (int64_t)i + 2];
+    load10(Pj + (int64_t)csc_nbr[i] * NP * D, pj);
+    edge_z(Wto + L::PHI_W1, Pt, pj, csc_attr[3 * (int64_t)i], csc_attr[3 * (int64_t)i + 1], csc_attr[3 * (int64_t)i + 2], z);
 #pragma unroll
-    for (int o = 0; o < D; ++o) {
-      float z = Pt[o] + pj[o];
-      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D], a0, z);
-      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D + 1], a1, z);
-      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D + 2], a2, z);
-      S_to[o] += fmaxf(z, 0.f);
-    }
+    for (int o = 0; o < D; ++o) S_to[o] += fmaxf(z[o], 0.f);
   }
   for (int32_t i = ob; i < oe; ++i) {
-    float pj[D];
-    load10(Pj + (int64_t)csr_nbr[i] * 2 * D + D, pj);
-    float a0 = csr_attr[3 * (int64_t)i], a1 = csr_attr[3 * (int64_t)i + 1], a2 = csr_attr[3 * (int64_t)i + 2];
+    load10(Pj + (int64_t)csr_nbr[i] * NP * D + D, pj);
+    edge_z(Wfr + L::PHI_W1, Pf, pj, csr_attr[3 * (int64_t)i], csr_attr[3 * (int64_t)i + 1], csr_attr[3 * (int64_t)i + 2], z);
 #pragma unroll
-    for (int o = 0; o < D; ++o) {
-      float z = Pf[o] + pj[o];
-      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D], a0, z);
-      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D + 1], a1, z);
-      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D + 2], a2, z);
-      S_fr[o] += fmaxf(z, 0.f);
-    }
+    for (int o = 0; o < D; ++o) S_fr[o] += fmaxf(z[o], 0.f);
   }
   float mp_to[D], mp_fr[D], pq[P];
 #pragma unroll
@@ -132,14 +235,13 @@ __global__ __launch_bounds__(256) void k_vjp_local(int64_t N, const float* __res
 #pragma unroll
   for (int k = 0; k < P; ++k) al = fmaf(Wa[3 * D + k], pq[k], al);
   al = 1.f / (1.f + expf(-al));
-  float q[D], upd[D], y[D];
+  float q[D], upd[D], y[D], hid[D];
 #pragma unroll
   for (int o = 0; o < D; ++o) q[o] = Wu[L::UPD_B1 + o];
   matvec10<D, true>(Wu + L::UPD_W1, L::CAT, 0, x, q);
   matvec10<D, true>(Wu + L::UPD_W1, L::CAT, D, mp_to, q);
   matvec10<D, true>(Wu + L::UPD_W1, L::CAT, 2 * D, mp_fr, q);
   matvec10<P, true>(Wu + L::UPD_W1, L::CAT, 3 * D, pq, q);
-  float hid[D];
 #pragma unroll
   for (int o = 0; o < D; ++o) {
     hid[o] = fmaxf(q[o], 0.f);
@@ -162,8 +264,7 @@ __global__ __launch_bounds__(256) void k_vjp_local(int64_t N, const float* __res
   var *= (1.f / D);
   const float rs = 1.f / sqrtf(var + 1e-5f);
   // ---- backward: LayerNorm
-  float dyh[D], dy[D], w[D];
-  load10(wv + n * D, w);
+  float dyh[D], dy[D];
   float m1 = 0.f, m2 = 0.f;
 #pragma unroll
   for (int o = 0; o < D; ++o) {
@@ -174,7 +275,7 @@ __global__ __launch_bounds__(256) void k_vjp_local(int64_t N, const float* __res
   }
   m1 *= (1.f / D);
   m2 *= (1.f / D);
-  float dal = 0.f, dupd[D], g[D];
+  float dal = 0.f, dupd[D];
 #pragma unroll
   for (int o = 0; o < D; ++o) {
     dy[o] = rs * (dyh[o] - m1 - y[o] * m2);
@@ -203,115 +304,114 @@ __global__ __launch_bounds__(256) void k_vjp_local(int64_t N, const float* __res
   matvecT<D, false>(Wfr + L::PHI_W2, D, 0, dmp_fr, dS_fr);
   store10(Bn + 2 * D, dS_to);
   store10(Bn + 3 * D, dS_fr);
+  if (MIXED) store10(Bn + 5 * D, zero);
   // ---- target-side projections: sum of the masked cotangents over the node's own edges
   float gt[D], gf[D];
 #pragma unroll
   for (int o = 0; o < D; ++o) gt[o] = gf[o] = 0.f;
   for (int32_t i = ib; i < ie; ++i) {
-    float pj[D];
-    load10(Pj + (int64_t)csc_nbr[i] * 2 * D, pj);
-    float a0 = csc_attr[3 * (int64_t)i], a1 = csc_attr[3 * (int64_t)i + 1], a2 = csc_attr[3 * (int64_t)i + 2];
+    load10(Pj + (int64_t)csc_nbr[i] * NP * D, pj);
+    edge_z(Wto + L::PHI_W1, Pt, pj, csc_attr[3 * (int64_t)i], csc_attr[3 * (int64_t)i + 1], csc_attr[3 * (int64_t)i + 2], z);
 #pragma unroll
-    for (int o = 0; o < D; ++o) {
-      float z = Pt[o] + pj[o];
-      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D], a0, z);
-      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D + 1], a1, z);
-      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D + 2], a2, z);
-      gt[o] += z > 0.f ? dS_to[o] : 0.f;
-    }
+    for (int o = 0; o < D; ++o) gt[o] += z[o] > 0.f ? dS_to[o] : 0.f;
   }
   for (int32_t i = ob; i < oe; ++i) {
-    float pj[D];
-    load10(Pj + (int64_t)csr_nbr[i] * 2 * D + D, pj);
-    float a0 = csr_attr[3 * (int64_t)i], a1 = csr_attr[3 * (int64_t)i + 1], a2 = csr_attr[3 * (int64_t)i + 2];
+    load10(Pj + (int64_t)csr_nbr[i] * NP * D + D, pj);
+    edge_z(Wfr + L::PHI_W1, Pf, pj, csr_attr[3 * (int64_t)i], csr_attr[3 * (int64_t)i + 1], csr_attr[3 * (int64_t)i + 2], z);
 #pragma unroll
-    for (int o = 0; o < D; ++o) {
-      float z = Pf[o] + pj[o];
-      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D], a0, z);
-      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D + 1], a1, z);
-      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D + 2], a2, z);
-      gf[o] += z > 0.f ? dS_fr[o] : 0.f;
-    }
+    for (int o = 0; o < D; ++o) gf[o] += z[o] > 0.f ? dS_fr[o] : 0.f;
   }
   matvecT<D, true>(Wto + L::PHI_W1, L::EIN, 0, gt, g);
   matvecT<D, true>(Wfr + L::PHI_W1, L::EIN, 0, gf, g);
   store10(out + n * D, g);
 }
 
-template <int P>
-__global__ __launch_bounds__(256) void k_vjp_remote(int64_t N, const float* __restrict__ W, int lofs,
+template <int P, bool MIXED>
+__global__ __launch_bounds__(256) void k_vjp_remote(int64_t N, const float* __restrict__ W, int lofs, int nofs,
                                                     const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_nbr,
                                                     const float* __restrict__ csr_attr, const int32_t* __restrict__ csc_ptr,
                                                     const int32_t* __restrict__ csc_nbr, const float* __restrict__ csc_attr,
                                                     const float* __restrict__ Pj, const float* __restrict__ B,
                                                     float* __restrict__ out) {
   using L = WLayout<P>;
+  constexpr int NP = MIXED ? 3 : 2;
+  constexpr int NB = MIXED ? 6 : 4;
   int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= N) return;
   const float* Wto = W + lofs + L::L_TO;
   const float* Wfr = W + lofs + L::L_FROM;
-  float pjt[D], pjf[D], at[D], af[D];
-  load10(Pj + u * 2 * D, pjt);
-  load10(Pj + u * 2 * D + D, pjf);
+  const float* Wn = W + nofs;
+  float pjt[D], pjf[D], pjn[D], at[D], af[D], an[D], z[D];
+  load10(Pj + u * NP * D, pjt);
+  load10(Pj + u * NP * D + D, pjf);
+  if (MIXED) load10(Pj + u * NP * D + 2 * D, pjn);
 #pragma unroll
-  for (int o = 0; o < D; ++o) at[o] = af[o] = 0.f;
+  for (int o = 0; o < D; ++o) at[o] = af[o] = an[o] = 0.f;
   // u's out-edges (u -> n) are in-edges of n: Phi_to terms of n that read h[u]
   for (int32_t i = csr_ptr[u]; i < csr_ptr[u + 1]; ++i) {
-    const float* Bn = B + (int64_t)csr_nbr[i] * 4 * D;
+    const float* Bn = B + (int64_t)csr_nbr[i] * NB * D;
     float pt[D], ds[D];
     load10(Bn, pt);
     load10(Bn + 2 * D, ds);
-    float a0 = csr_attr[3 * (int64_t)i], a1 = csr_attr[3 * (int64_t)i + 1], a2 = csr_attr[3 * (int64_t)i + 2];
+    edge_z(Wto + L::PHI_W1, pt, pjt, csr_attr[3 * (int64_t)i], csr_attr[3 * (int64_t)i + 1], csr_attr[3 * (int64_t)i + 2], z);
 #pragma unroll
-    for (int o = 0; o < D; ++o) {
-      float z = pt[o] + pjt[o];
-      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D], a0, z);
-      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D + 1], a1, z);
-      z = fmaf(Wto[L::PHI_W1 + o * L::EIN + 2 * D + 2], a2, z);
-      at[o] += z > 0.f ? ds[o] : 0.f;
-    }
+    for (int o = 0; o < D; ++o) at[o] += z[o] > 0.f ? ds[o] : 0.f;
   }
-  // u's in-edges (n -> u) are out-edges of n: Phi_from terms of n that read h[u]
+  // u's in-edges (n -> u) are out-edges of n: Phi_from (and Phi_neumann) terms of n that read h[u]
   for (int32_t i = csc_ptr[u]; i < csc_ptr[u + 1]; ++i) {
-    const float* Bn = B + (int64_t)csc_nbr[i] * 4 * D;
+    const float* Bn = B + (int64_t)csc_nbr[i] * NB * D;
     float pf[D], ds[D];
+    const float a0 = csc_attr[3 * (int64_t)i], a1 = csc_attr[3 * (int64_t)i + 1], a2 = csc_attr[3 * (int64_t)i + 2];
     load10(Bn + D, pf);
     load10(Bn + 3 * D, ds);
-    float a0 = csc_attr[3 * (int64_t)i], a1 = csc_attr[3 * (int64_t)i + 1], a2 = csc_attr[3 * (int64_t)i + 2];
+    edge_z(Wfr + L::PHI_W1, pf, pjf, a0, a1, a2, z);
 #pragma unroll
-    for (int o = 0; o < D; ++o) {
-      float z = pf[o] + pjf[o];
-      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D], a0, z);
-      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D + 1], a1, z);
-      z = fmaf(Wfr[L::PHI_W1 + o * L::EIN + 2 * D + 2], a2, z);
-      af[o] += z > 0.f ? ds[o] : 0.f;
+    for (int o = 0; o < D; ++o) af[o] += z[o] > 0.f ? ds[o] : 0.f;
+    if (MIXED) {
+      load10(Bn + 4 * D, pf);
+      load10(Bn + 5 * D, ds);
+      edge_z(Wn + L::PHI_W1, pf, pjn, a0, a1, a2, z);
+#pragma unroll
+      for (int o = 0; o < D; ++o) an[o] += z[o] > 0.f ? ds[o] : 0.f;
     }
   }
   float g[D];
   load10(out + u * D, g);
   matvecT<D, true>(Wto + L::PHI_W1, L::EIN, D, at, g);
   matvecT<D, true>(Wfr + L::PHI_W1, L::EIN, D, af, g);
+  if (MIXED) matvecT<D, true>(Wn + L::PHI_W1, L::EIN, D, an, g);
   store10(out + u * D, g);
 }
 
-extern "C" int psignn_f_vjp(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* prb,
-                            const float* w, float* out, float* work, void* stream) {
-  ARG_CHECK(p && W && h && prb && w && out && work, "NULL argument");
-  ARG_CHECK(!p->mixed, "VJP of the mixed (Neumann) block is not implemented yet");
-  ARG_CHECK(nl == 1, "VJP of a multi-layer block is not implemented");
-  ARG_CHECK(out != w && out != h, "out must not alias its inputs");
-  using L = WLayout<2>;
-  hipStream_t st = (hipStream_t)stream;
+template <int P, bool MIXED>
+static void launch_vjp(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* nrm,
+                       const float* w, float* out, float* work, hipStream_t st) {
+  using L = WLayout<P>;
+  const int layer = MIXED ? nl - 1 : 0;
+  const int lofs = L::layer(layer), nofs = L::phi_neu(nl), unofs = L::upd_neu(nl);
   const unsigned grid = (unsigned)cdiv(p->N, 256);
-  float* Pj = work;                // (N, 20)
-  float* B = work + p->N * 2 * D;  // (N, 40)
-  LAUNCH("k_vjp_project", st, (k_vjp_project<2><<<grid, 256, 0, st>>>(p->N, W, L::layer(0), h, Pj)));
-  LAUNCH("k_vjp_local", st, (k_vjp_local<2><<<grid, 256, 0, st>>>(p->N, W, L::layer(0), p->csr_ptr, p->csr_nbr, p->csr_attr,
-                                                                    p->csc_ptr, p->csc_nbr, p->csc_attr, p->flags, h, prb,
-                                                                    w, Pj, B, out)));
-  LAUNCH("k_vjp_remote", st, (k_vjp_remote<2><<<grid, 256, 0, st>>>(p->N, W, L::layer(0), p->csr_ptr, p->csr_nbr,
-                                                                      p->csr_attr, p->csc_ptr, p->csc_nbr, p->csc_attr, Pj,
-                                                                      B, out)));
+  float* Pj = work;                            // (N, 20 | 30)
+  float* B = work + p->N * (MIXED ? 3 : 2) * D;  // (N, 40 | 60)
+  LAUNCH("k_vjp_project", st, (k_vjp_project<P, MIXED><<<grid, 256, 0, st>>>(p->N, W, lofs, nofs, h, Pj)));
+  LAUNCH("k_vjp_local", st, (k_vjp_local<P, MIXED><<<grid, 256, 0, st>>>(p->N, W, lofs, nofs, unofs, p->csr_ptr, p->csr_nbr,
+                                                                          p->csr_attr, p->csc_ptr, p->csc_nbr, p->csc_attr,
+                                                                          p->flags, h, prb, nrm, w, Pj, B, out)));
+  LAUNCH("k_vjp_remote", st, (k_vjp_remote<P, MIXED><<<grid, 256, 0, st>>>(p->N, W, lofs, nofs, p->csr_ptr, p->csr_nbr,
+                                                                            p->csr_attr, p->csc_ptr, p->csc_nbr,
+                                                                            p->csc_attr, Pj, B, out)));
+}
+
+extern "C" int psignn_f_vjp(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* prb,
+                            const float* nrm, const float* w, float* out, float* work, void* stream) {
+  ARG_CHECK(p && W && h && prb && w && out && work, "NULL argument");
+  ARG_CHECK(p->mixed || nl == 1, "VJP of a multi-layer dirichlet block is not implemented");
+  ARG_CHECK(!p->mixed || nrm, "mixed plan needs unit normals");
+  ARG_CHECK(out != w && out != h, "out must not alias its inputs");
+  hipStream_t st = (hipStream_t)stream;
+  if (p->mixed)
+    launch_vjp<3, true>(p, W, nl, h, prb, nrm, w, out, work, st);
+  else
+    launch_vjp<2, false>(p, W, nl, h, prb, nrm, w, out, work, st);
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }

@@ -327,7 +327,7 @@ class FixedPointMap:
         out = torch.empty_like(Hc)
         with torch.cuda.device(Hc.device):
             nat.check(nat.lib().psignn_f_vjp(self.plan.handle, nat.ptr(self.weights.flat), self.weights.n_layers,
-                                             nat.ptr(Hc), nat.ptr(self.prb), nat.ptr(Wc), nat.ptr(out),
+                                             nat.ptr(Hc), nat.ptr(self.prb), nat.ptr(self.nrm), nat.ptr(Wc), nat.ptr(out),
                                              nat.ptr(self.plan.workspace()), nat.stream_ptr(Hc.device)),
                       "psignn_f_vjp")
         return out

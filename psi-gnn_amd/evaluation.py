@@ -1,0 +1,79 @@
+"""Evaluation harness in the reference's protocol, on the HIP path.
+
+* ``errors_batch(u, batch)``: per-graph metrics of a (union) batch — mean residual^2, |Au-b|/|b|, MSE vs the direct
+  solve, relative L2, boundary MSE (``dirichlet/psignn/test/test_func.py:26-66``).
+* ``test_dataset(model, meshes, batch_size)``: the loop of ``test_func.py:68-120``: meshes are collated into
+  disjoint-union batches (a PyG ``DataLoader(batch_size=50)`` does the same), each batch is ONE fixed-point
+  problem with global Broyden norms, metrics are collected per graph and averaged.
+* ``test_sample``: the timing protocol of ``tests/special_geo/spec_geo_2.py:300-345`` (wall clock around the model
+  call including the host-to-device copy).
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from . import engine
+from .data import collate
+
+HEADERS = ["Residual", "ResidualNorm", "MSE", "Rel", "MSEBound"]
+
+
+def _dirichlet_mask(batch):
+    t = batch.tags
+    return (t[:, 1] if (t.dim() == 2 and t.shape[1] == 3) else t.reshape(t.shape[0], -1)[:, 0]) == 1
+
+
+@torch.no_grad()
+def errors_batch(u, batch):
+    """Five lists with one entry per graph of the batch (test_func.py:26-66)."""
+    residual = engine.residual(engine.plan_for(batch), u, batch.y)
+    gid = getattr(batch, "batch", None)
+    if gid is None:
+        gid = torch.zeros(u.shape[0], dtype=torch.long, device=u.device)
+    bound = _dirichlet_mask(batch)
+    out = [[], [], [], [], []]
+    for i in torch.unique(gid).tolist():
+        idx = gid == i
+        r, y, uu, sol = residual[idx], batch.y[idx], u[idx], batch.sol[idx]
+        b = bound[idx]
+        out[0].append(torch.mean(r ** 2).item())
+        out[1].append((torch.linalg.norm(r) / torch.linalg.norm(y)).item())
+        out[2].append(torch.mean((uu - sol) ** 2).item())
+        out[3].append((torch.linalg.norm(uu - sol) / torch.linalg.norm(sol)).item())
+        out[4].append(torch.mean((uu[b] - sol[b]) ** 2).item())
+    return tuple(out)
+
+
+@torch.no_grad()
+def test_dataset(model, meshes, device, batch_size=50):
+    """Mean / std of the five metrics over all graphs, plus wall time and Broyden steps per batch."""
+    model.eval()
+    lists = [[], [], [], [], []]
+    steps, t0 = [], time.perf_counter()
+    for s in range(0, len(meshes), batch_size):
+        batch = collate(meshes[s:s + batch_size]).to(device)
+        out = model(batch)
+        u = out[0] if isinstance(out, tuple) else out
+        if isinstance(out, tuple) and "nsteps" in out[1]:
+            steps.append(out[1]["nsteps"])
+        for acc, vals in zip(lists, errors_batch(u, batch)):
+            acc += vals
+    torch.cuda.synchronize(device)
+    return {"mean": dict(zip(HEADERS, (float(np.mean(l)) for l in lists))),
+            "std": dict(zip(HEADERS, (float(np.std(l)) for l in lists))),
+            "graphs": len(lists[0]), "batches": (len(meshes) + batch_size - 1) // batch_size,
+            "seconds": time.perf_counter() - t0, "nsteps_per_batch": steps}
+
+
+@torch.no_grad()
+def test_sample(model, mesh, device):
+    """(u, loss_dic, seconds): wall clock around ``model(data.to(device))`` + synchronize (spec_geo_2.py:309-317)."""
+    model.eval()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    u, loss = model(mesh.to(device))
+    torch.cuda.synchronize(device)
+    return u, loss, time.perf_counter() - t0

@@ -515,7 +515,7 @@ def test_forward_iteration_anderson_newton(dev):
 
 
 # ------------------------------------------------------------------------------------------ VJP / implicit backward
-@pytest.mark.parametrize("name", ["original_dirichlet_s0", "hex13_dirichlet_s0", "hex26_dirichlet_s0"])
+@pytest.mark.parametrize("name", ["original_dirichlet_s0", "hex13_dirichlet_s0", "hex13_mixed_s1", "hex26_dirichlet_s0"])
 def test_vjp_parity(name, dev):
     """the VJP kernel against autograd on the oracle (fp64 golden + fp32 live), the adjoint
     identity against the JVP kernel, and bitwise reproducibility (two gather passes, no atomics)."""
@@ -564,3 +564,28 @@ def test_implicit_backward_solve(dev):
     assert 0.8 < float(rho) < 1.1   # logged spectral radius of the trained model ~0.99
     jl = net.deqdss.jac_loss_estimate(h_star.to(dev), h0.to(dev), md, vecs=2, generator=torch.Generator(device=dev).manual_seed(2))
     assert torch.isfinite(jl) and float(jl) > 0
+
+
+def test_eval_harness_reference_protocol(dev):
+    """SURVEY §8f-3: union batches of 50-like graphs, per-graph metrics as dirichlet/psignn/test/test_func.py:26-120;
+    the in-distribution statistics of the trained checkpoint land in the reference's recorded band."""
+    data, ev = pkg("data"), pkg("evaluation")
+    g, mesh0 = load_case("original_dirichlet_s0")
+    m = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "mesh_original.npz"))
+    dmask = np.zeros(len(m["pos"]), dtype=bool)
+    dmask[m["dirichlet_segments"].ravel()] = True
+    meshes = [data.make_from_triangulation(m["pos"], m["tri"], dmask, seed=s) for s in range(12)]
+    net = pkg("model_psignn").ModelPSIGNN(dict(latent_dim=10, n_layers=1, fw_tol=1e-5, fw_thres=500))
+    net.load_state_dict(load_weights("dirichlet"))
+    net = net.to(dev)
+    rep = ev.test_dataset(net, meshes, dev, batch_size=6)
+    assert rep["graphs"] == 12 and rep["batches"] == 2 and len(rep["nsteps_per_batch"]) == 2
+    ref = {"Residual": 2.694e-3, "ResidualNorm": 1.752e-2, "MSE": 8.498e-3, "Rel": 1.448e-2, "MSEBound": 1.978e-5}
+    for k, v in ref.items():  # dirichlet/psignn/test/test.ipynb cell 11
+        assert 0.4 * v < rep["mean"][k] < 2.5 * v, (k, rep["mean"][k], v)
+    # single-graph metrics equal the golden ones
+    u, loss, secs = ev.test_sample(net, meshes[0], dev)
+    res = ev.errors_batch(u, meshes[0].to(dev))
+    assert abs(res[0][0] - float(g["metric_residual"])) < 0.1 * float(g["metric_residual"])
+    assert abs(res[3][0] - float(g["metric_rel"])) < 0.1 * float(g["metric_rel"])
+    assert secs < 5.0
