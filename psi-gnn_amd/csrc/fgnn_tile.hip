@@ -61,10 +61,24 @@ __device__ __forceinline__ void lds_load10at(const float* __restrict__ p, float*
 // 79 us instead of 67 us per 1M-node evaluation -- it costs a wave slot per workgroup for the whole residency.)
 #define TILE_THREADS 256
 
-// 1: stage-1 projections on the matrix cores (v_mfma_f32_16x16x4_f32); 0: packed-VALU form (A/B builds)
-#ifndef PSIGNN_MFMA_STAGE1
-#define PSIGNN_MFMA_STAGE1 1
+// Stage 1 exists in two forms, chosen per launch (env PSIGNN_STAGE1 = mfma | valu overrides the default):
+// matrix cores (v_mfma_f32_16x16x4_f32) or packed VALU.
+#include <stdlib.h>
+#include <string.h>
+// default form per kernel flavour, from an A/B on one box (1M-node mesh): plain f 66.3 us (mfma) vs 68.2 us (valu),
+// mixed 99.5 vs 106.6; the fused Broyden step 122-125 us (mfma) vs 106 us (valu) -- there the MFMA form has to
+// re-load x and update for stage 2, which the VALU form gets for free from its stage-1 registers.
+#ifndef STAGE1_DEFAULT_MFMA
+#define STAGE1_DEFAULT_MFMA(fused) (!(fused))
 #endif
+static int stage1_mfma(bool fused) {
+  static int forced = [] {
+    const char* e = getenv("PSIGNN_STAGE1");
+    return !e ? -1 : (strcmp(e, "mfma") == 0 ? 1 : 0);
+  }();
+  if (forced >= 0) return forced;
+  return STAGE1_DEFAULT_MFMA(fused);
+}
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -167,7 +181,7 @@ __device__ __forceinline__ float wave_sum_f(float v) {
   return v;
 }
 
-template <int P, bool MIXED, bool FUSED>
+template <int P, bool MIXED, bool FUSED, bool MFMA1>
 __global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
                                                 const int32_t* __restrict__ tile_slice, const int32_t* __restrict__ halo,
                                                 const int32_t* __restrict__ halo_cnt, const int32_t* __restrict__ slice_off,
@@ -198,8 +212,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tile
 
   // ---- stage 1: neighbour-side projections of tile + halo rows -> LDS
   float x[D];
-#if PSIGNN_MFMA_STAGE1
-  {
+  if constexpr (MFMA1) {
     // Dense node-feature x weight product on the matrix cores: out[row][o] = sum_k x[row][k] W1j[o][k] as
     // v_mfma_f32_16x16x4_f32 tiles with the WEIGHTS as the A operand (A[i = output][k]) and the node rows as B
     // (B[k][j = row]): a lane then receives D[i = 4 (lane>>4) + r][j = lane&15], r = 0..3 -- four consecutive
@@ -258,8 +271,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tile
         for (int o = 0; o < D; ++o) x[o] += ur[o];
       }
     }
-  }
-#else
+  } else {
   for (int row = tid; row < n_t + n_h; row += TILE_THREADS) {
     const int64_t node = row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t];
     float xr[D];
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tile
       reinterpret_cast<float2*>(q + 7)[0] = make_float2(ta[4].x, ta[4].y);
     }
   }
-#endif
+  }
   __syncthreads();
   if (!FUSED && tid >= n_t) return;
 
@@ -462,7 +474,12 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
   if (p->mixed) {
     using L = WLayout<3>;
     size_t lds = (size_t)p->max_rows * TileRow<true>::RS * 4;
-    LAUNCH("k_f_tile", st, (k_f_tile<3, true, false><<<grid, TILE_THREADS, lds, st>>>(
+    if (stage1_mfma(false))
+      LAUNCH("k_f_tile", st, (k_f_tile<3, true, false, true><<<grid, TILE_THREADS, lds, st>>>(
+        FuseArgs{}, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
+        p->flags_p, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), L::tp_neu(nl), 1, h, hsel, hstride, h0, prb, nrm, out)));
+    else
+      LAUNCH("k_f_tile", st, (k_f_tile<3, true, false, false><<<grid, TILE_THREADS, lds, st>>>(
         FuseArgs{}, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
         p->flags_p, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), L::tp_neu(nl), 1, h, hsel, hstride, h0, prb, nrm, out)));
   } else {
@@ -473,7 +490,12 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
     const float* cur = h;
     for (int l = 0; l < nl; ++l) {
       float* dst = (l == nl - 1) ? out : pp[l & 1];
-      LAUNCH("k_f_tile", st, (k_f_tile<2, false, false><<<grid, TILE_THREADS, lds, st>>>(
+      if (stage1_mfma(false))
+      LAUNCH("k_f_tile", st, (k_f_tile<2, false, false, true><<<grid, TILE_THREADS, lds, st>>>(
+          FuseArgs{}, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
+          p->flags_p, W, L::layer(l), L::tp_layer(nl, false, l), 0, l == nl - 1, cur, l == 0 ? hsel : nullptr, hstride, h0, prb, nrm, dst)));
+    else
+      LAUNCH("k_f_tile", st, (k_f_tile<2, false, false, false><<<grid, TILE_THREADS, lds, st>>>(
           FuseArgs{}, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
           p->flags_p, W, L::layer(l), L::tp_layer(nl, false, l), 0, l == nl - 1, cur, l == 0 ? hsel : nullptr, hstride, h0, prb, nrm, dst)));
       cur = dst;
@@ -497,13 +519,23 @@ int psignn_f_tile_fused(const psignn_plan* p, const float* W, int nl, float* xbu
   if (p->mixed) {
     using L = WLayout<3>;
     size_t lds = (size_t)p->max_rows * TileRow<true>::RS * 4;
-    LAUNCH("k_f_tile_fused", st, (k_f_tile<3, true, true><<<grid, TILE_THREADS, lds, st>>>(
+    if (stage1_mfma(true))
+      LAUNCH("k_f_tile_fused", st, (k_f_tile<3, true, true, true><<<grid, TILE_THREADS, lds, st>>>(
+        fa, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
+        p->flags_p, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), L::tp_neu(nl), 1, xbuf, nullptr, 0, h0, prb, nrm, nullptr)));
+    else
+      LAUNCH("k_f_tile_fused", st, (k_f_tile<3, true, true, false><<<grid, TILE_THREADS, lds, st>>>(
         fa, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
         p->flags_p, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), L::tp_neu(nl), 1, xbuf, nullptr, 0, h0, prb, nrm, nullptr)));
   } else {
     using L = WLayout<2>;
     size_t lds = (size_t)p->max_rows * TileRow<false>::RS * 4;
-    LAUNCH("k_f_tile_fused", st, (k_f_tile<2, false, true><<<grid, TILE_THREADS, lds, st>>>(
+    if (stage1_mfma(true))
+      LAUNCH("k_f_tile_fused", st, (k_f_tile<2, false, true, true><<<grid, TILE_THREADS, lds, st>>>(
+        fa, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
+        p->flags_p, W, L::layer(0), L::tp_layer(nl, false, 0), 0, 1, xbuf, nullptr, 0, h0, prb, nrm, nullptr)));
+    else
+      LAUNCH("k_f_tile_fused", st, (k_f_tile<2, false, true, false><<<grid, TILE_THREADS, lds, st>>>(
         fa, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
         p->flags_p, W, L::layer(0), L::tp_layer(nl, false, 0), 0, 1, xbuf, nullptr, 0, h0, prb, nrm, nullptr)));
   }
