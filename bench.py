@@ -98,18 +98,28 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    # one process per GPU; PSIGNN_BENCH_BACKEND=gloo lets several ranks share the cards of a small box for a
+    # rehearsal of the N > 1 path (RCCL refuses two ranks on one device)
+    backend = os.environ.get("PSIGNN_BENCH_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         torch.cuda.synchronize(dev)
         if dist is not None:
-            dist.barrier(device_ids=[local])
+            if backend == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize(dev)
 
     pkg = importlib.import_module("psi-gnn_amd")
@@ -206,7 +216,7 @@ def main():
         assert np.all(np.isfinite(o["rel_trace"][:K]))
     t_max = elapsed
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_max = float(t.item())
     iters_per_s = world * MPG * K / t_max

@@ -23,7 +23,8 @@ def load(d, counter):
                 full = r["Kernel_Name"].split("(")[0].replace("void ", "")
                 name = full.split("<")[0]
                 if name == "k_f_tile":  # template <P, MIXED, FUSED>: keep the fused / plain instantiations apart
-                    name = "k_f_tile_fused" if full.rstrip("> ").endswith("true") else "k_f_tile"
+                    targs = [a.strip() for a in full[full.index("<") + 1:full.rindex(">")].split(",")]
+                    name = "k_f_tile_fused" if len(targs) > 2 and targs[2] == "true" else "k_f_tile"
                 agg[name].append(float(r["Counter_Value"]))
     return agg
 
