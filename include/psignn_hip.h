@@ -185,6 +185,14 @@ int psignn_broyden_solve(psignn_broyden_t* s, const float* d_weights, int n_laye
                          const float* d_h_initial, const float* d_prb, const float* d_normals,
                          double eps, int poll_every, float* d_result, psignn_solve_info_t* h_info,
                          double* h_rel_trace, double* h_abs_trace, void* stream);
+/* Adjoint fixed point y = J_f(h*)^T y + grad with the same Broyden machinery, the VJP kernel as the map, y_0 = 0.
+ * replaces: the backward hook of DeepEquilibrium.forward (dirichlet/psignn/model.py:210-223), i.e.
+ *           solver(lambda y: autograd.grad(new_H, H, y) + grad, zeros, bw_thres, bw_tol).
+ * All tensors in the caller's numbering. */
+int psignn_broyden_solve_adjoint(psignn_broyden_t* s, const float* d_weights, int n_layers, const float* d_h_star,
+                                 const float* d_prb, const float* d_normals, const float* d_grad, double eps,
+                                 int poll_every, float* d_result, psignn_solve_info_t* h_info,
+                                 double* h_rel_trace, double* h_abs_trace, void* stream);
 /* Copy iterate i (0..n_iter) of the last solve to d_dst (needs keep_trace). */
 int psignn_broyden_get_iterate(const psignn_broyden_t* s, int i, float* d_dst, void* stream);
 

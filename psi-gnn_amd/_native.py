@@ -61,6 +61,8 @@ SIGNATURES = {
     "psignn_broyden_bytes": (C.c_size_t, [_P]),
     "psignn_broyden_solve": (_INT, [_P, _P, _INT, _P, _P, _P, C.c_double, _INT, _P, C.POINTER(SolveInfo),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
+    "psignn_broyden_solve_adjoint": (_INT, [_P, _P, _INT, _P, _P, _P, _P, C.c_double, _INT, _P, C.POINTER(SolveInfo),
+                                            C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
     "psignn_broyden_get_iterate": (_INT, [_P, _INT, _P, _P]),
     "psignn_broyden_ext_begin": (_INT, [_P, _P, _P, _P]),
     "psignn_broyden_ext_next_x": (_INT, [_P, _P, _P]),

@@ -58,6 +58,7 @@ struct psignn_broyden {
   Status* h_st = nullptr;   // pinned host mirror
   size_t bytes = 0;
   int ext_iter = 0;
+  int plan_order = 1;       // 0 while iterates are kept in the caller's numbering (adjoint solve on the gather kernels)
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -661,7 +662,7 @@ static int finish(psignn_broyden* s, float* d_result, psignn_solve_info_t* info,
   int rc = 0;
   if (d_result) {
     const int32_t* sel_low = reinterpret_cast<const int32_t*>(s->st) + sel_off_low();
-    if (s->plan) {  // iterates live in plan order: select into fx, then back to the caller's numbering
+    if (s->plan && s->plan_order) {  // iterates live in plan order: select into fx, then back to the caller's numbering
       VPLAIN(s->vec, k_copy_sel, (g, TB, 0, st), s->M, s->xbuf, sel_low, 0, s->fx);
       if ((rc = psignn_plan_permute(s->plan, s->fx, D, d_result, 0, st))) return rc;
     } else {
@@ -697,6 +698,7 @@ extern "C" int psignn_broyden_solve(psignn_broyden_t* s, const float* W, int nl,
   ARG_CHECK(W && h0 && prb, "NULL argument");
   ARG_CHECK(!s->plan->mixed || nrm, "mixed plan needs unit normals");
   hipStream_t st = (hipStream_t)stream;
+  s->plan_order = 1;
   if (poll_every <= 0) poll_every = 8;
   unsigned g = (unsigned)s->nblk;
   const int32_t* sel_nxt = reinterpret_cast<const int32_t*>(s->st) + sel_off_nxt();
@@ -735,11 +737,60 @@ extern "C" int psignn_broyden_solve(psignn_broyden_t* s, const float* W, int nl,
   return finish(s, d_result, info, h_rel, h_abs, st);
 }
 
+
+// ---- adjoint fixed point  y = J_f(h*)^T y + grad  (the reference's backward hook, dirichlet/psignn/model.py:210-223)
+template <int VEC>
+__global__ __launch_bounds__(TB) void k_addv(int64_t M, const Status* __restrict__ st, float* __restrict__ a,
+                                             const float* __restrict__ b) {
+  if (st->done) return;
+  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  if (e0 >= M) return;
+  float x[VEC], y[VEC];
+  ldv<VEC>(a, e0, M, x);
+  ldv<VEC>(b, e0, M, y);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) x[i] += y[i];
+  stv<VEC>(a, e0, M, x);
+}
+
+extern "C" int psignn_f_vjp(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* prb,
+                            const float* nrm, const float* w, float* out, float* work, void* stream);
+
+extern "C" int psignn_broyden_solve_adjoint(psignn_broyden_t* s, const float* W, int nl, const float* h_star,
+                                            const float* prb, const float* nrm, const float* grad, double eps,
+                                            int poll_every, float* d_result, psignn_solve_info_t* info, double* h_rel,
+                                            double* h_abs, void* stream) {
+  ARG_CHECK(s && s->plan, "solver was not created from a mesh plan");
+  ARG_CHECK(W && h_star && prb && grad, "NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  s->plan_order = 0;  // the VJP kernels work in the caller's numbering
+  if (poll_every <= 0) poll_every = 8;
+  unsigned g = (unsigned)s->nblk;
+  k_init_status<<<4, TB, 0, st>>>(s->st, s->rel_trace, s->abs_trace, s->thr);
+  // y0 = 0, map(y0) = grad  ->  g0 = grad, update = grad  (solver.py:131-136 with f(0) = grad)
+  HIP_TRY(hipMemsetAsync(s->h0p, 0, (size_t)s->M * 4, st));
+  VPLAIN(s->vec, k_begin, (g, TB, 0, st), s->M, s->h0p, grad, s->xbuf, s->gx, s->upd);
+  for (int it = 0; it < s->thr; ++it) {
+    // x_next = x + update, kept also in h0p (fixed address for the VJP kernels)
+    VLAUNCH("k_xnext", st, s->vec, k_xnext, (g, TB, 0, st), s->M, s->st, s->xbuf, s->upd, s->h0p);
+    int rc = psignn_f_vjp(s->plan, W, nl, h_star, prb, nrm, s->h0p, s->fx, s->fwork, st);
+    if (rc) return rc;
+    VLAUNCH("k_addv", st, s->vec, k_addv, (g, TB, 0, st), s->M, s->st, s->fx, grad);
+    launch_update(s, it, eps, st);
+    if ((it + 1) % poll_every == 0 || it + 1 == s->thr) {
+      rc = read_status(s, st);
+      if (rc) return rc;
+      if (s->h_st->done) break;
+    }
+  }
+  return finish(s, d_result, info, h_rel, h_abs, st);
+}
+
 extern "C" int psignn_broyden_get_iterate(const psignn_broyden_t* s, int i, float* d_dst, void* stream) {
   ARG_CHECK(s && d_dst, "NULL argument");
   ARG_CHECK(s->keep_trace, "solver was created without keep_trace");
   ARG_CHECK(i >= 0 && i <= s->thr, "iterate index out of range");
-  if (s->plan) {
+  if (s->plan && s->plan_order) {
     VPLAIN(s->vec, k_copy_sel, ((unsigned)s->nblk, TB, 0, (hipStream_t)stream), s->M, s->xbuf, nullptr, i, s->fx);
     return psignn_plan_permute(s->plan, s->fx, D, d_dst, 0, stream);
   }

@@ -423,6 +423,22 @@ class DeviceBroyden:
         out["result"] = result
         return out
 
+    def solve_adjoint(self, fmap: FixedPointMap, h_star, grad, eps, poll_every=8):
+        """y = J_f(h*)^T y + grad, y_0 = 0, entirely on the device (VJP kernel inside the Broyden loop)."""
+        hs, gr = _f32c(h_star), _f32c(grad)
+        result = torch.empty_like(gr)
+        info = nat.SolveInfo()
+        rel = (C.c_double * self.threshold)()
+        abs_ = (C.c_double * self.threshold)()
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().psignn_broyden_solve_adjoint(
+                self.handle, nat.ptr(fmap.weights.flat), fmap.weights.n_layers, nat.ptr(hs), nat.ptr(fmap.prb),
+                nat.ptr(fmap.nrm), nat.ptr(gr), float(eps), int(poll_every), nat.ptr(result), C.byref(info), rel, abs_,
+                nat.stream_ptr(self.device)), "psignn_broyden_solve_adjoint")
+        out = self._collect(info, rel, abs_, result.shape, result.device)
+        out["result"] = result
+        return out
+
     def iterate(self, i, like):
         dst = torch.empty_like(like)
         with torch.cuda.device(self.device):

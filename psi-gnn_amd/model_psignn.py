@@ -154,6 +154,11 @@ class DeepEquilibrium(nn.Module):
         returns the solver dict; ``out["result"]`` is the gradient w.r.t. the fixed point's input."""
         fmap = self.f.bind(H_init, batch)
         g = grad.contiguous()
+        if self.config_deq["solver"] is _solver.broyden:  # whole adjoint solve on the device
+            sv = engine.DeviceBroyden(plan=fmap.plan, threshold=self.config_deq["bw_thres"], keep_trace=False)
+            out = sv.solve_adjoint(fmap, H_star, g, self.config_deq["bw_tol"])
+            out.update(eps=self.config_deq["bw_tol"], threshold=self.config_deq["bw_thres"])
+            return out
         return self.config_deq["solver"](lambda y: fmap.vjp(H_star, y) + g, torch.zeros_like(g),
                                          threshold=self.config_deq["bw_thres"], eps=self.config_deq["bw_tol"])
 

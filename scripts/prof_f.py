@@ -37,3 +37,13 @@ for _ in range(reps):
 t1.record(); torch.cuda.synchronize()
 print(f"N={plan.N} Ep={plan.Ep} tiled={plan.tiled} tiles={plan.n_tiles} max_rows={plan.max_tile_rows} ell_rows={plan.ell_rows} "
       f"f avg {t0.elapsed_time(t1) / reps * 1e3:.1f} us")
+if len(sys.argv) > 5 and sys.argv[5] == "adjoint":
+    H = fm.from_plan(x)
+    V = torch.randn_like(H)
+    for name, fn in (("jvp", lambda: fm.jvp(H, V)), ("vjp", lambda: fm.vjp(H, V)), ("f (caller order)", lambda: fm(H))):
+        fn(); torch.cuda.synchronize()
+        t0.record()
+        for _ in range(reps):
+            fn()
+        t1.record(); torch.cuda.synchronize()
+        print(f"{name} avg {t0.elapsed_time(t1) / reps * 1e3:.1f} us")

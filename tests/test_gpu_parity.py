@@ -550,8 +550,13 @@ def test_implicit_backward_solve(dev):
     h_star = torch.from_numpy(g["broyden_e7_result"])
     h0 = torch.from_numpy(g["h0"])
     grad = torch.randn(h_star.shape, generator=torch.Generator().manual_seed(9))
-    out = net.deqdss.implicit_backward(h_star.to(dev), h0.to(dev), md, grad.to(dev))
+    out = net.deqdss.implicit_backward(h_star.to(dev), h0.to(dev), md, grad.to(dev))   # on-device adjoint solve
     assert out["lowest"] < 1e-6
+    # the same solve driven from the host through the generic solver(f, x0, ...) API agrees
+    fm = net.deqdss.f.bind(h0.to(dev), md)
+    gd = grad.to(dev)
+    host = solver.broyden(lambda yy: fm.vjp(h_star.to(dev), yy) + gd, torch.zeros_like(gd), threshold=600, eps=1e-6)
+    assert rel_l2(out["result"], host["result"]) < 1e-3
     y = out["result"]
     # residual of the adjoint equation, evaluated with the ORACLE's VJP
     r = orc.function_vjp(sd, h_star, h0, mesh, y.cpu()) + grad - y.cpu()
