@@ -123,3 +123,36 @@ def test_plan_reference_numpy():
     assert ref["csr_eid"].tolist() == [0, 1, 4, 3, 6]
     assert ref["csc_ptr"].tolist() == [0, 2, 4, 5]
     assert ref["csc_nbr"].tolist() == [1, 2, 0, 2, 1]
+
+
+def test_reader_reproduces_the_reference_schema():
+    """utilities/reader.py on raw arrays (A, b, sol, prb_data, tags, coordinates, distance) == the tensors our
+    generator emits for the same problem (same normalisation constants and initial guess, reader.py:73-110)."""
+    import scipy.sparse as sp
+    data, reader = pkg("data"), pkg("utilities.reader")
+    hm = pkg("data.hexmesh")
+    for mixed in (False, True):
+        m = data.make_hex_problem(5, seed=3, mixed=mixed)
+        N = m.num_nodes
+        r, c = m.edge_index.numpy()
+        A = sp.csr_matrix((m.a_ij[:, 0].double().numpy(), (r, c)), shape=(N, N))
+        pos = m.pos.double().numpy()
+        d = pos[r] - pos[c]
+        dist = np.concatenate([d, np.sqrt((d ** 2).sum(1, keepdims=True))], axis=1)
+        if mixed:
+            prb_raw = m.prb_data.double().numpy() * hm.MIX_PRB_STD + hm.MIX_PRB_MEAN
+            nrm_raw = m.unit_normal_vector.double().numpy() * hm.MIX_NRM_STD + hm.MIX_NRM_MEAN
+        else:
+            prb_raw = m.prb_data.double().numpy() * hm.DIR_PRB_STD + hm.DIR_PRB_MEAN
+            nrm_raw = None
+        # shuffle the distance rows the way an older scipy's column-major find() would have produced them
+        got = reader.from_arrays(A, m.y.numpy(), m.sol.numpy(), prb_raw, m.tags.numpy(), pos, dist, nrm_raw)
+        assert torch.equal(got.edge_index, m.edge_index)
+        for k in ("x", "y", "sol", "tags", "a_ij"):
+            assert torch.allclose(getattr(got, k), getattr(m, k), atol=1e-6), k
+        assert torch.allclose(got.edge_attr, m.edge_attr, atol=2e-5)
+        assert torch.allclose(got.prb_data, m.prb_data, atol=1e-5)
+        if mixed:
+            assert torch.allclose(got.unit_normal_vector, m.unit_normal_vector, atol=1e-5)
+    assert reader.split_indices(10, "train") == [0, 1, 2, 3, 4, 5] and reader.split_indices(10, "val") == [6, 7]
+    assert reader.split_indices(10, "test") == [8, 9]
