@@ -444,11 +444,18 @@ __global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tile
     store10(fa.dg + n * D, go);
     store10(fa.xbuf + (int64_t)fa.st[fa.off_nxt] * fa.M + n * D, x);
   }
+  // one partial pair per tile: wave shuffles, then the 4 wave sums through LDS in a fixed order
   sg = wave_sum_f(sg);
   sf = wave_sum_f(sf);
-  if ((tid & 63) == 0 && tid < 256) {
-    fa.part[tile * 4 + (tid >> 6)] = sg;
-    fa.part[fa.npart + tile * 4 + (tid >> 6)] = sf;
+  __shared__ float red[2][4];
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = sg;
+    red[1][tid >> 6] = sf;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    fa.part[tile] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    fa.part[fa.npart + tile] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   }
 }
 
@@ -506,7 +513,7 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
 }
 
 // Fused Broyden step (single-layer models): x_next = x_cur + upd, f(x_next), g/dg/x_next/norm partials.
-// Returns the number of partial entries per norm (n_tiles * 4), or a negative error.
+// Returns the number of partial entries per norm (n_tiles), or a negative error.
 int psignn_f_tile_fused(const psignn_plan* p, const float* W, int nl, float* xbuf, int64_t M, const int32_t* st_words,
                         int off_done, int off_cur, int off_nxt, const float* upd, float* gx, float* dg,
                         const float* h0, const float* prb, const float* nrm, float* part, hipStream_t st) {
@@ -514,7 +521,7 @@ int psignn_f_tile_fused(const psignn_plan* p, const float* W, int nl, float* xbu
   ARG_CHECK(nl == 1 || p->mixed, "fused step supports single-layer evaluation");
   const int chunk = (int)cdiv(p->n_tiles, 8);
   const unsigned grid = (unsigned)(chunk * 8);
-  const int npart = (int)p->n_tiles * 4;
+  const int npart = (int)p->n_tiles;
   FuseArgs fa{upd, gx, dg, xbuf, st_words, off_done, off_cur, off_nxt, M, part, npart};
   if (p->mixed) {
     using L = WLayout<3>;

@@ -67,6 +67,23 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Two per-lane values -> ONE pair per block (wave shuffles, then the 4 wave sums through LDS, fixed order).
+__device__ __forceinline__ void block_pair_store(float a, float b, float* __restrict__ part, int n) {
+  __shared__ float red[2][TB / 64];
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a;
+    red[1][threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    part[n + blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+
 template <int VEC>
 __device__ __forceinline__ void ldv(const float* __restrict__ p, int64_t e0, int64_t M, float* r) {
   if (e0 + VEC <= M) {
@@ -188,13 +205,7 @@ __global__ __launch_bounds__(TB) void k_resid(int64_t M, const Status* __restric
     stv<VEC>(gx, e0, M, x);
     stv<VEC>(dg, e0, M, g);
   }
-  sg = wave_sum(sg);
-  sf = wave_sum(sf);
-  if ((threadIdx.x & 63) == 0) {
-    int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
-    part[w] = sg;
-    part[npart + w] = sf;
-  }
+  block_pair_store(sg, sf, part, npart);
 }
 
 __device__ double block_sum_partials(const float* __restrict__ p, int n, double* sh) {
@@ -406,13 +417,7 @@ __global__ __launch_bounds__(TB) void k_axpy(int64_t M, int k, const Status* __r
     axpy_finish<VEC>(M, k, e0, av, a1, a2, dg, g, U, V, upd, p1, p2);
   }
   if (split) return;
-  p1 = wave_sum(p1);
-  p2 = wave_sum(p2);
-  if ((threadIdx.x & 63) == 0) {
-    int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
-    part[w] = p1;
-    part[npart + w] = p2;
-  }
+  block_pair_store(p1, p2, part, npart);
 }
 
 // second half of a split axpy pass: init terms + the G partial sums, in group order
@@ -450,13 +455,7 @@ __global__ __launch_bounds__(TB) void k_axpy_combine(int64_t M, int k, int G, co
     }
     axpy_finish<VEC>(M, k, e0, av, a1, a2, dg, g, U, V, upd, p1, p2);
   }
-  p1 = wave_sum(p1);
-  p2 = wave_sum(p2);
-  if ((threadIdx.x & 63) == 0) {
-    int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
-    part[w] = p1;
-    part[npart + w] = p2;
-  }
+  block_pair_store(p1, p2, part, npart);
 }
 
 __global__ __launch_bounds__(TB) void k_reduce2(Status* st, const float* __restrict__ part, int npart) {
@@ -632,8 +631,8 @@ static inline int sel_off_nxt() { return offsetof(Status, nxt) / 4; }
 static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, int fused_npart = 0) {
   unsigned g = (unsigned)s->nblk;
   if (!fused_npart)
-    VLAUNCH("k_resid", st, s->vec, k_resid, (g, TB, 0, st), s->M, s->st, s->xbuf, s->fx, s->gx, s->dg, s->part, s->npart);
-  const int np = fused_npart ? fused_npart : s->npart;
+    VLAUNCH("k_resid", st, s->vec, k_resid, (g, TB, 0, st), s->M, s->st, s->xbuf, s->fx, s->gx, s->dg, s->part, s->nblk);
+  const int np = fused_npart ? fused_npart : s->nblk;  // one partial pair per block / per tile
   LAUNCH("k_check", st, (k_check<<<1, TB, 0, st>>>(s->st, s->part, np, s->rel_trace, s->abs_trace, eps, s->thr, s->seq_len, s->keep_trace)));
   if (k >= s->thr) return;  // the threshold stop has fired; no slot left for another pair
   // split of the sweeps over the stored pairs: only when there are enough pairs to share out
@@ -643,10 +642,10 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
     VLAUNCH("k_dots", st, s->vec, k_dots, (dim3(g, G), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->npart, s->thr, js);
     LAUNCH("k_reduce", st, (k_reduce<<<dim3(k, 3), TB, 0, st>>>(s->st, s->part, s->npart, s->thr, s->coef)));
   }
-  VLAUNCH("k_axpy", st, s->vec, k_axpy, (dim3(g, G), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->npart, js, s->jpart);
+  VLAUNCH("k_axpy", st, s->vec, k_axpy, (dim3(g, G), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->nblk, js, s->jpart);
   if (G > 1)
-    VLAUNCH("k_axpy_combine", st, s->vec, k_axpy_combine, (g, TB, 0, st), s->M, k, G, s->st, s->jpart, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->npart);
-  LAUNCH("k_reduce2", st, (k_reduce2<<<1, TB, 0, st>>>(s->st, s->part, s->npart)));
+    VLAUNCH("k_axpy_combine", st, s->vec, k_axpy_combine, (g, TB, 0, st), s->M, k, G, s->st, s->jpart, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->nblk);
+  LAUNCH("k_reduce2", st, (k_reduce2<<<1, TB, 0, st>>>(s->st, s->part, s->nblk)));
   VLAUNCH("k_final", st, s->vec, k_final, (g, TB, 0, st), s->M, k, s->st, s->U, s->upd);
 }
 
