@@ -143,6 +143,11 @@ int psignn_f_vjp(const psignn_plan_t* plan, const float* d_weights, int n_layers
                  const float* d_prb, const float* d_normals, const float* d_w, float* d_out, float* d_work,
                  void* stream);
 
+/* Same with h, prb, w and out in plan order (tiled kernels where the plan has tiles; the form the adjoint solve uses). */
+int psignn_f_vjp_p(const psignn_plan_t* plan, const float* d_weights, int n_layers, const float* d_h,
+                   const float* d_prb, const float* d_normals, const float* d_w, float* d_out, float* d_work,
+                   void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Small dense pieces around the solve.
  * replaces: Encoder / Decoder MLPs (model.py:370-392), residual_loss SpMV (model.py:157-167).

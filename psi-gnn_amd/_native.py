@@ -53,6 +53,7 @@ SIGNATURES = {
     "psignn_phi": (_INT, [_P, _P, _INT, _INT, _INT, _P, _P, _P, _P]),
     "psignn_f_jvp": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P]),
     "psignn_f_vjp": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P]),
+    "psignn_f_vjp_p": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P]),
     "psignn_mlp2": (_INT, [_P, _I64, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P]),
     "psignn_residual": (_INT, [_P, _P, _P, _P, _P]),
     "psignn_broyden_create": (_INT, [C.POINTER(_P), _P, _INT, _INT]),

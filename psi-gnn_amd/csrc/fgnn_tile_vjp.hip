@@ -1,0 +1,418 @@
+// Tiled vector-Jacobian product of f_theta (dirichlet family, single layer), plan order (gfx950).
+//
+// Same mathematics as fgnn_vjp.hip (two gather passes, no atomics; reference: autograd.grad(new_H, H, v),
+// dirichlet/psignn/model.py:210-223,416-452), on the tile structures of the mesh plan:
+//   pass A  (k_vjp_tile_a)  = the forward tile kernel (stage 1: neighbour projections -> LDS; stage 2: pair-merged
+//           slots) that additionally counts, per output, the edges whose pre-activation is positive.  The masked
+//           cotangent sum over a node's OWN edges is then just  dS * count  (dS_to[n] is per node, not per edge),
+//           so no second sweep over the slots is needed.  Backward through LayerNorm, the folded gate / update
+//           MLP; writes the node-local result and B[n] = { Pt[n], Pf[n], dS_to[n], dS_fr[n] } (40 floats).
+//   pass B  (k_vjp_tile_b)  stages B[tile + halo] in LDS (160-byte rows) and, for node u, walks the same slots
+//           from the neighbour's side:  OUT slot (edge u -> n): acc_t += dS_to[n] * 1[Pt[n] + Pjt[u] + At a > 0]
+//                                       IN  slot (edge n -> u): acc_f += dS_fr[n] * 1[Pf[n] + Pjf[u] + Af m(a) > 0]
+//           out[u] += W1j_to^T acc_t + W1j_fr^T acc_f.
+// All tensors in plan order.  Mixed plans use the global-gather kernels of fgnn_vjp.hip.
+#include "fgnn_common.h"
+
+#define SLOT_IN 0x10000u
+#define SLOT_OUT 0x20000u
+#define VT 256
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f splat2(float a) { return (v2f){a, a}; }
+
+// acc[p] += WT[k][2p..2p+1] * x[k]   (transposed weight section: [in k][out o], o fastest)
+template <int K>
+__device__ __forceinline__ void mvf(const float* __restrict__ WT, const float* x, v2f* acc) {
+  const v2f* w = reinterpret_cast<const v2f*>(WT);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const v2f xs = splat2(x[k]);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) acc[p] = __builtin_elementwise_fma(w[k * 5 + p], xs, acc[p]);
+  }
+}
+// acc[p] += W[o*ld + off + 2p..2p+1] * g[o]   (ORIGINAL (out,in) layout = the transposed product, k pairs adjacent)
+template <int NO>
+__device__ __forceinline__ void mvb(const float* __restrict__ W, int ld, int off, const float* g, v2f* acc) {
+#pragma unroll
+  for (int o = 0; o < NO; ++o) {
+    const v2f gs = splat2(g[o]);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      const v2f w = (v2f){W[o * ld + off + 2 * p], W[o * ld + off + 2 * p + 1]};
+      acc[p] = __builtin_elementwise_fma(w, gs, acc[p]);
+    }
+  }
+}
+__device__ __forceinline__ void ldu5(const float* __restrict__ p, v2f* r) {
+  const v2f* q = reinterpret_cast<const v2f*>(p);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) r[i] = q[i];
+}
+__device__ __forceinline__ void row10(const float* __restrict__ row, v2f* pj) {  // 10 floats at a 16-byte aligned LDS address
+  float4 v0 = reinterpret_cast<const float4*>(row)[0], v1 = reinterpret_cast<const float4*>(row)[1];
+  float2 v2 = reinterpret_cast<const float2*>(row)[4];
+  pj[0] = (v2f){v0.x, v0.y}; pj[1] = (v2f){v0.z, v0.w}; pj[2] = (v2f){v1.x, v1.y}; pj[3] = (v2f){v1.z, v1.w};
+  pj[4] = (v2f){v2.x, v2.y};
+}
+__device__ __forceinline__ void row10u(const float* __restrict__ row, v2f* pj) {  // 8-byte aligned start
+  float2 v0 = reinterpret_cast<const float2*>(row)[0];
+  float4 v1 = reinterpret_cast<const float4*>(row + 2)[0], v2 = reinterpret_cast<const float4*>(row + 2)[1];
+  pj[0] = (v2f){v0.x, v0.y}; pj[1] = (v2f){v1.x, v1.y}; pj[2] = (v2f){v1.z, v1.w}; pj[3] = (v2f){v2.x, v2.y};
+  pj[4] = (v2f){v2.z, v2.w};
+}
+
+// ---------------------------------------------------------------------------------------------- pass A
+// forward sum S[o] += relu(z) and cnt[o] += 1[z > 0] over the slots carrying MASK; z = Pi + row[COL..] + AT . a
+template <int RS, int COL, unsigned MASK>
+__device__ __forceinline__ float pass_fwd(const uint4* __restrict__ slots, int nslots, const float* __restrict__ lds,
+                                          const float* __restrict__ AT, const v2f* Pi, v2f* S, v2f* cnt) {
+  float deg = 0.f;
+  v2f wa[15];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) wa[i] = reinterpret_cast<const v2f*>(AT)[i];
+  if (nslots <= 0) return deg;
+  uint4 c0 = slots[0];
+  uint4 c1 = slots[(int64_t)min(1, nslots - 1) * 64];
+  for (int r = 0; r < nslots; ++r) {
+    const uint4 nx = slots[(int64_t)min(r + 2, nslots - 1) * 64];
+    const unsigned w = c0.x;
+    if ((w & 0xFFFFu) != ELL_EMPTY && (w & MASK)) {
+      const v2f a0 = splat2(__uint_as_float(c0.y)), a1 = splat2(__uint_as_float(c0.z)), a2 = splat2(__uint_as_float(c0.w));
+      const float* row = lds + (int)(w & 0xFFFFu) * RS + COL;
+      v2f pj[5], z[5];
+      if (COL % 4 == 0) row10(row, pj); else row10u(row, pj);
+      deg += 1.f;
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = Pi[p] + pj[p];
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[p], a0, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[5 + p], a1, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[10 + p], a2, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) {
+        S[p] += __builtin_elementwise_max(z[p], splat2(0.f));
+        cnt[p] += (v2f){z[p].x > 0.f ? 1.f : 0.f, z[p].y > 0.f ? 1.f : 0.f};
+      }
+    }
+    c0 = c1;
+    c1 = nx;
+  }
+  return deg;
+}
+
+template <int P>
+__global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
+                                                   const int32_t* __restrict__ tile_slice, const int32_t* __restrict__ halo,
+                                                   const int32_t* __restrict__ halo_cnt, const int32_t* __restrict__ slice_off,
+                                                   const uint8_t* __restrict__ slice_deg, const uint4* __restrict__ ell,
+                                                   const uint8_t* __restrict__ flags, const float* __restrict__ W, int lofs,
+                                                   int tofs, const float* __restrict__ h, const float* __restrict__ prb,
+                                                   const float* __restrict__ wv, float* __restrict__ B,
+                                                   float* __restrict__ out) {
+  using L = WLayout<P>;
+  constexpr int RS = 20;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (tile >= n_tiles) return;
+  const int tid = threadIdx.x;
+  const int32_t t0 = tile_ptr[tile];
+  const int n_t = tile_ptr[tile + 1] - t0;
+  const int n_h = halo_cnt[tile];
+  const int32_t* hl = halo + (int64_t)tile * HALO_CAP;
+  const float* T = W + tofs;
+  // ---- stage 1: neighbour-side projections of tile + halo rows -> LDS
+  float x[D];
+  for (int row = tid; row < n_t + n_h; row += VT) {
+    const int64_t node = row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t];
+    float xr[D];
+    load10(h + node * D, xr);
+    if (row == tid) {
+#pragma unroll
+      for (int o = 0; o < D; ++o) x[o] = xr[o];
+    }
+    v2f ta[5], tb[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) ta[p] = tb[p] = splat2(0.f);
+    mvf<D>(T + L::T_W1J_TO, xr, ta);
+    mvf<D>(T + L::T_W1J_FR, xr, tb);
+    float4* q = reinterpret_cast<float4*>(lds + row * RS);
+    q[0] = make_float4(ta[0].x, ta[0].y, ta[1].x, ta[1].y);
+    q[1] = make_float4(ta[2].x, ta[2].y, ta[3].x, ta[3].y);
+    q[2] = make_float4(ta[4].x, ta[4].y, tb[0].x, tb[0].y);
+    q[3] = make_float4(tb[1].x, tb[1].y, tb[2].x, tb[2].y);
+    q[4] = make_float4(tb[3].x, tb[3].y, tb[4].x, tb[4].y);
+  }
+  __syncthreads();
+  if (tid >= n_t) return;
+  const int64_t n = (int64_t)t0 + tid;
+  float4* Bn = reinterpret_cast<float4*>(B + n * 4 * D);
+  if (flags[n] & FLAG_DIRICHLET) {  // constant row: sends nothing
+#pragma unroll
+    for (int i = 0; i < 10; ++i) Bn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float zero[D];
+#pragma unroll
+    for (int o = 0; o < D; ++o) zero[o] = 0.f;
+    store10(out + n * D, zero);
+    return;
+  }
+  const int lane = tid & 63;
+  const int slice = tile_slice[tile] + (tid >> 6);
+  const uint4* slots = ell + (int64_t)slice_off[slice] * 64 + lane;
+  const int nslots = slice_deg[slice];
+  // ---- forward with activity counts
+  v2f Pt[5], Pf[5], S_to[5], S_fr[5], c_to[5], c_fr[5];
+  ldu5(T + L::T_B1_TO, Pt);
+  ldu5(T + L::T_B1_FR, Pf);
+#pragma unroll
+  for (int p = 0; p < 5; ++p) S_to[p] = S_fr[p] = c_to[p] = c_fr[p] = splat2(0.f);
+  mvf<D>(T + L::T_W1I_TO, x, Pt);
+  const float deg_in = pass_fwd<RS, 0, SLOT_IN>(slots, nslots, lds, T + L::T_A_TO, Pt, S_to, c_to);
+  mvf<D>(T + L::T_W1I_FR, x, Pf);
+  const float deg_out = pass_fwd<RS, D, SLOT_OUT>(slots, nslots, lds, T + L::T_A_FR, Pf, S_fr, c_fr);
+  const float* Wf = W + lofs + L::L_FOLD;
+  const float* Wu = W + lofs + L::L_UPD;
+  const float* Wa = W + L::AL_W;
+  const float* sto = reinterpret_cast<const float*>(S_to);
+  const float* sfr = reinterpret_cast<const float*>(S_fr);
+  float pq[P];
+#pragma unroll
+  for (int k = 0; k < P; ++k) pq[k] = prb[n * P + k];
+  float al = fmaf(deg_in, Wf[L::F_ABTO], fmaf(deg_out, Wf[L::F_ABFR], W[L::AL_B]));
+#pragma unroll
+  for (int k = 0; k < D; ++k) al = fmaf(Wa[k], x[k], al);
+#pragma unroll
+  for (int k = 0; k < D; ++k) al = fmaf(Wf[L::F_ATO + k], sto[k], al);
+#pragma unroll
+  for (int k = 0; k < D; ++k) al = fmaf(Wf[L::F_AFR + k], sfr[k], al);
+#pragma unroll
+  for (int k = 0; k < P; ++k) al = fmaf(Wa[3 * D + k], pq[k], al);
+  al = 1.f / (1.f + expf(-al));
+  v2f q2[5], g1[5], g2[5], upd2[5], hid2[5];
+  ldu5(T + L::T_HB, q2);
+  ldu5(T + L::T_gTO, g1);
+  ldu5(T + L::T_gFR, g2);
+#pragma unroll
+  for (int p = 0; p < 5; ++p)
+    q2[p] = __builtin_elementwise_fma(splat2(deg_in), g1[p], __builtin_elementwise_fma(splat2(deg_out), g2[p], q2[p]));
+  mvf<D>(T + L::T_U1H, x, q2);
+  mvf<D>(T + L::T_GTO, sto, q2);
+  mvf<D>(T + L::T_GFR, sfr, q2);
+  mvf<P>(T + L::T_U1P, pq, q2);
+#pragma unroll
+  for (int p = 0; p < 5; ++p) hid2[p] = __builtin_elementwise_max(q2[p], splat2(0.f));
+  ldu5(T + L::T_C2, upd2);
+  mvf<D>(T + L::T_U2, reinterpret_cast<const float*>(hid2), upd2);
+  const float* qf = reinterpret_cast<const float*>(q2);
+  const float* upd = reinterpret_cast<const float*>(upd2);
+  float y[D], mu = 0.f;
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    y[o] = fmaf(al, upd[o], x[o]);
+    mu += y[o];
+  }
+  mu *= (1.f / D);
+  float var = 0.f;
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    float c = y[o] - mu;
+    var = fmaf(c, c, var);
+  }
+  var *= (1.f / D);
+  const float rs = 1.f / sqrtf(var + 1e-5f);
+  // ---- backward: LayerNorm
+  float w[D], dyh[D], dy[D], m1 = 0.f, m2 = 0.f;
+  load10(wv + n * D, w);
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    y[o] = (y[o] - mu) * rs;
+    dyh[o] = w[o] * W[L::LN_G + o];
+    m1 += dyh[o];
+    m2 = fmaf(dyh[o], y[o], m2);
+  }
+  m1 *= (1.f / D);
+  m2 *= (1.f / D);
+  float dal = 0.f, dupd[D];
+  v2f g[5];
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    dy[o] = rs * (dyh[o] - m1 - y[o] * m2);
+    dal = fmaf(dy[o], upd[o], dal);
+    dupd[o] = al * dy[o];
+  }
+#pragma unroll
+  for (int p = 0; p < 5; ++p) g[p] = (v2f){dy[2 * p], dy[2 * p + 1]};  // residual path y = x + ...
+  dal *= al * (1.f - al);
+  // ---- update MLP, gate, folded second Phi layer
+  v2f dq2[5];
+#pragma unroll
+  for (int p = 0; p < 5; ++p) dq2[p] = splat2(0.f);
+  mvb<D>(Wu + L::UPD_W2, D, 0, dupd, dq2);
+  float dq[D];
+#pragma unroll
+  for (int o = 0; o < D; ++o) dq[o] = qf[o] > 0.f ? reinterpret_cast<const float*>(dq2)[o] : 0.f;
+  mvb<D>(Wu + L::UPD_W1, L::CAT, 0, dq, g);
+  v2f dS_to[5], dS_fr[5];
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    g[p] = __builtin_elementwise_fma((v2f){Wa[2 * p], Wa[2 * p + 1]}, splat2(dal), g[p]);
+    dS_to[p] = (v2f){Wf[L::F_ATO + 2 * p], Wf[L::F_ATO + 2 * p + 1]} * splat2(dal);
+    dS_fr[p] = (v2f){Wf[L::F_AFR + 2 * p], Wf[L::F_AFR + 2 * p + 1]} * splat2(dal);
+  }
+  mvb<D>(Wf + L::F_GTO, D, 0, dq, dS_to);   // dS_to[k] = sum_o G_to[o][k] dq[o] + a_to[k] dal
+  mvb<D>(Wf + L::F_GFR, D, 0, dq, dS_fr);
+  Bn[0] = make_float4(Pt[0].x, Pt[0].y, Pt[1].x, Pt[1].y);
+  Bn[1] = make_float4(Pt[2].x, Pt[2].y, Pt[3].x, Pt[3].y);
+  Bn[2] = make_float4(Pt[4].x, Pt[4].y, Pf[0].x, Pf[0].y);
+  Bn[3] = make_float4(Pf[1].x, Pf[1].y, Pf[2].x, Pf[2].y);
+  Bn[4] = make_float4(Pf[3].x, Pf[3].y, Pf[4].x, Pf[4].y);
+  Bn[5] = make_float4(dS_to[0].x, dS_to[0].y, dS_to[1].x, dS_to[1].y);
+  Bn[6] = make_float4(dS_to[2].x, dS_to[2].y, dS_to[3].x, dS_to[3].y);
+  Bn[7] = make_float4(dS_to[4].x, dS_to[4].y, dS_fr[0].x, dS_fr[0].y);
+  Bn[8] = make_float4(dS_fr[1].x, dS_fr[1].y, dS_fr[2].x, dS_fr[2].y);
+  Bn[9] = make_float4(dS_fr[3].x, dS_fr[3].y, dS_fr[4].x, dS_fr[4].y);
+  // ---- the node's own edges: masked cotangent sum = dS * (number of active edges per output)
+  float gt[D], gf[D];
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    const v2f a = dS_to[p] * c_to[p], b = dS_fr[p] * c_fr[p];
+    gt[2 * p] = a.x; gt[2 * p + 1] = a.y;
+    gf[2 * p] = b.x; gf[2 * p + 1] = b.y;
+  }
+  const float* Wto = W + lofs + L::L_TO;
+  const float* Wfr = W + lofs + L::L_FROM;
+  mvb<D>(Wto + L::PHI_W1, L::EIN, 0, gt, g);
+  mvb<D>(Wfr + L::PHI_W1, L::EIN, 0, gf, g);
+  float go[D];
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    go[2 * p] = g[p].x;
+    go[2 * p + 1] = g[p].y;
+  }
+  store10(out + n * D, go);
+}
+
+// ---------------------------------------------------------------------------------------------- pass B
+// acc[o] += 1[Pi[o] + row[PC + o] + AT . (sg a0, sg a1, a2) > 0] * row[DC + o]  over the slots carrying MASK.
+// The transposed attr blocks store rows 0,1 NEGATED for the in-direction (T_A_TO) and plain for T_A_FR; the caller
+// picks `flip` so that the effective attr is the edge's own: OUT slot of u = in-edge of n with attr a (no mirror).
+template <int RS, int PC, int DC, unsigned MASK>
+__device__ __forceinline__ void pass_rev(const uint4* __restrict__ slots, int nslots, const float* __restrict__ lds,
+                                         const float* __restrict__ AT, float flip, const v2f* Pj, v2f* acc) {
+  v2f wa[15];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) wa[i] = reinterpret_cast<const v2f*>(AT)[i];
+  if (nslots <= 0) return;
+  uint4 c0 = slots[0];
+  uint4 c1 = slots[(int64_t)min(1, nslots - 1) * 64];
+  for (int r = 0; r < nslots; ++r) {
+    const uint4 nx = slots[(int64_t)min(r + 2, nslots - 1) * 64];
+    const unsigned w = c0.x;
+    if ((w & 0xFFFFu) != ELL_EMPTY && (w & MASK)) {
+      const v2f a0 = splat2(flip * __uint_as_float(c0.y)), a1 = splat2(flip * __uint_as_float(c0.z));
+      const v2f a2 = splat2(__uint_as_float(c0.w));
+      const float* row = lds + (int)(w & 0xFFFFu) * RS;
+      v2f pi[5], ds[5], z[5];
+      if (PC % 4 == 0) row10(row + PC, pi); else row10u(row + PC, pi);
+      if (DC % 4 == 0) row10(row + DC, ds); else row10u(row + DC, ds);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = pi[p] + Pj[p];
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[p], a0, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[5 + p], a1, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[10 + p], a2, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) acc[p] += (v2f){z[p].x > 0.f ? ds[p].x : 0.f, z[p].y > 0.f ? ds[p].y : 0.f};
+    }
+    c0 = c1;
+    c1 = nx;
+  }
+}
+
+template <int P>
+__global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
+                                                   const int32_t* __restrict__ tile_slice, const int32_t* __restrict__ halo,
+                                                   const int32_t* __restrict__ halo_cnt, const int32_t* __restrict__ slice_off,
+                                                   const uint8_t* __restrict__ slice_deg, const uint4* __restrict__ ell,
+                                                   const float* __restrict__ W, int lofs, int tofs,
+                                                   const float* __restrict__ h, const float* __restrict__ B,
+                                                   float* __restrict__ out) {
+  using L = WLayout<P>;
+  constexpr int RS = 40;  // LDS row = B row: [Pt 10 | Pf 10 | dS_to 10 | dS_fr 10]
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (tile >= n_tiles) return;
+  const int tid = threadIdx.x;
+  const int32_t t0 = tile_ptr[tile];
+  const int n_t = tile_ptr[tile + 1] - t0;
+  const int n_h = halo_cnt[tile];
+  const int32_t* hl = halo + (int64_t)tile * HALO_CAP;
+  const float* T = W + tofs;
+  // ---- stage 1: B rows of tile + halo -> LDS (float4 units: 10 per row)
+  for (int i = tid; i < (n_t + n_h) * 10; i += VT) {
+    const int row = i / 10, c = i - row * 10;
+    const int64_t node = row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t];
+    reinterpret_cast<float4*>(lds)[row * 10 + c] = reinterpret_cast<const float4*>(B + node * 4 * D)[c];
+  }
+  __syncthreads();
+  if (tid >= n_t) return;
+  const int64_t u = (int64_t)t0 + tid;
+  const int lane = tid & 63;
+  const int slice = tile_slice[tile] + (tid >> 6);
+  const uint4* slots = ell + (int64_t)slice_off[slice] * 64 + lane;
+  const int nslots = slice_deg[slice];
+  float x[D];
+  load10(h + u * D, x);
+  v2f Pj[5], at[5], af[5];
+#pragma unroll
+  for (int p = 0; p < 5; ++p) Pj[p] = at[p] = af[p] = splat2(0.f);
+  // OUT slots: edge (u -> n) is an in-edge of n (Phi_to of n): Pt[n] at 0, dS_to[n] at 20, attr = the slot's own
+  // (T_A_TO holds the mirrored rows -> flip = -1 restores the plain attr weights)
+  mvf<D>(T + L::T_W1J_TO, x, Pj);
+  pass_rev<RS, 0, 2 * D, SLOT_OUT>(slots, nslots, lds, T + L::T_A_TO, -1.f, Pj, at);
+  // IN slots: edge (n -> u) is an out-edge of n (Phi_from of n): Pf[n] at 10, dS_fr[n] at 30, attr = mirror of the slot's
+#pragma unroll
+  for (int p = 0; p < 5; ++p) Pj[p] = splat2(0.f);
+  mvf<D>(T + L::T_W1J_FR, x, Pj);
+  pass_rev<RS, D, 3 * D, SLOT_IN>(slots, nslots, lds, T + L::T_A_FR, -1.f, Pj, af);
+  float go[D];
+  load10(out + u * D, go);
+  v2f g[5];
+#pragma unroll
+  for (int p = 0; p < 5; ++p) g[p] = (v2f){go[2 * p], go[2 * p + 1]};
+  const float* Wto = W + lofs + L::L_TO;
+  const float* Wfr = W + lofs + L::L_FROM;
+  mvb<D>(Wto + L::PHI_W1, L::EIN, D, reinterpret_cast<const float*>(at), g);
+  mvb<D>(Wfr + L::PHI_W1, L::EIN, D, reinterpret_cast<const float*>(af), g);
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    go[2 * p] = g[p].x;
+    go[2 * p + 1] = g[p].y;
+  }
+  store10(out + u * D, go);
+}
+
+// ---------------------------------------------------------------------------------------------- host
+// h, prb, w, out in PLAN order; work: (N, 40) floats for B.
+int psignn_f_tile_vjp(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* w,
+                      float* out, float* work, hipStream_t st) {
+  ARG_CHECK(p && p->tiled && !p->mixed && nl == 1, "tiled VJP: dirichlet single-layer plans only");
+  using L = WLayout<2>;
+  const int chunk = (int)cdiv(p->n_tiles, 8);
+  const unsigned grid = (unsigned)(chunk * 8);
+  const size_t lds_a = (size_t)p->max_rows * 20 * 4, lds_b = (size_t)p->max_rows * 40 * 4;
+  ARG_CHECK(lds_b <= 160 * 1024, "tile + halo rows exceed the LDS budget of the tiled VJP");
+  LAUNCH("k_vjp_tile_a", st, (k_vjp_tile_a<2><<<grid, VT, lds_a, st>>>(
+      (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
+      p->flags_p, W, L::layer(0), L::tp_layer(nl, false, 0), h, prb, w, work, out)));
+  LAUNCH("k_vjp_tile_b", st, (k_vjp_tile_b<2><<<grid, VT, lds_b, st>>>(
+      (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell, W,
+      L::layer(0), L::tp_layer(nl, false, 0), h, work, out)));
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}

@@ -401,6 +401,19 @@ static void launch_vjp(const psignn_plan* p, const float* W, int nl, const float
                                                                             p->csc_attr, Pj, B, out)));
 }
 
+int psignn_f_tile_vjp(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* w,
+                      float* out, float* work, hipStream_t st);
+
+// plan-order VJP: tiled kernels where the plan has tiles (dirichlet, single layer), gather kernels otherwise
+extern "C" int psignn_f_vjp_p(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* prb,
+                              const float* nrm, const float* w, float* out, float* work, void* stream) {
+  ARG_CHECK(p && W && h && prb && w && out && work, "NULL argument");
+  ARG_CHECK(out != w && out != h, "out must not alias its inputs");
+  if (p->tiled && !p->mixed && nl == 1) return psignn_f_tile_vjp(p, W, nl, h, prb, w, out, work, (hipStream_t)stream);
+  ARG_CHECK(!p->tiled, "plan-order VJP of a tiled mixed / multi-layer plan is not available: use psignn_f_vjp");
+  return psignn_f_vjp(p, W, nl, h, prb, nrm, w, out, work, stream);
+}
+
 extern "C" int psignn_f_vjp(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* prb,
                             const float* nrm, const float* w, float* out, float* work, void* stream) {
   ARG_CHECK(p && W && h && prb && w && out && work, "NULL argument");
@@ -408,6 +421,21 @@ extern "C" int psignn_f_vjp(const psignn_plan_t* p, const float* W, int nl, cons
   ARG_CHECK(!p->mixed || nrm, "mixed plan needs unit normals");
   ARG_CHECK(out != w && out != h, "out must not alias its inputs");
   hipStream_t st = (hipStream_t)stream;
+  if (p->tiled && !p->mixed && nl == 1) {
+    // caller numbering -> plan order -> tiled kernels -> caller numbering
+    const int64_t N = p->N;
+    float* Bw = work;                 // (N, 40)
+    float* hp = Bw + N * 4 * D;
+    float* wp = hp + N * D;
+    float* op = wp + N * D;
+    float* pp = op + N * D;           // (N, 2)
+    int rc;
+    if ((rc = psignn_plan_permute(p, h, D, hp, 1, stream))) return rc;
+    if ((rc = psignn_plan_permute(p, w, D, wp, 1, stream))) return rc;
+    if ((rc = psignn_plan_permute(p, prb, 2, pp, 1, stream))) return rc;
+    if ((rc = psignn_f_tile_vjp(p, W, nl, hp, pp, wp, op, Bw, st))) return rc;
+    return psignn_plan_permute(p, op, D, out, 0, stream);
+  }
   if (p->mixed)
     launch_vjp<3, true>(p, W, nl, h, prb, nrm, w, out, work, st);
   else

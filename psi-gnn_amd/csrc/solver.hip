@@ -754,6 +754,8 @@ __global__ __launch_bounds__(TB) void k_addv(int64_t M, const Status* __restrict
 
 extern "C" int psignn_f_vjp(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* prb,
                             const float* nrm, const float* w, float* out, float* work, void* stream);
+extern "C" int psignn_f_vjp_p(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* prb,
+                              const float* nrm, const float* w, float* out, float* work, void* stream);
 
 extern "C" int psignn_broyden_solve_adjoint(psignn_broyden_t* s, const float* W, int nl, const float* h_star,
                                             const float* prb, const float* nrm, const float* grad, double eps,
@@ -762,9 +764,23 @@ extern "C" int psignn_broyden_solve_adjoint(psignn_broyden_t* s, const float* W,
   ARG_CHECK(s && s->plan, "solver was not created from a mesh plan");
   ARG_CHECK(W && h_star && prb && grad, "NULL argument");
   hipStream_t st = (hipStream_t)stream;
-  s->plan_order = 0;  // the VJP kernels work in the caller's numbering
+  const psignn_plan* p = s->plan;
+  // tiled dirichlet plans: the whole solve in plan order on the tiled VJP kernels; otherwise the caller's numbering
+  const bool tiled = p->tiled && !p->mixed && nl == 1;
+  s->plan_order = tiled ? 1 : 0;
   if (poll_every <= 0) poll_every = 8;
   unsigned g = (unsigned)s->nblk;
+  int rc;
+  if (tiled) {  // plan-order copies: h* -> fwork tail, prb -> prbp, grad -> dg (free until the first update)
+    float* hs_p = s->fwork + p->N * 4 * D;        // fwork = [B (40N) | h*_p (10N) | grad_p (10N) | ...]
+    float* gr_p = hs_p + p->N * D;
+    if ((rc = psignn_plan_permute(p, h_star, D, hs_p, 1, st))) return rc;
+    if ((rc = psignn_plan_permute(p, grad, D, gr_p, 1, st))) return rc;
+    if ((rc = psignn_plan_permute(p, prb, 2, s->prbp, 1, st))) return rc;
+    h_star = hs_p;
+    grad = gr_p;
+    prb = s->prbp;
+  }
   k_init_status<<<4, TB, 0, st>>>(s->st, s->rel_trace, s->abs_trace, s->thr);
   // y0 = 0, map(y0) = grad  ->  g0 = grad, update = grad  (solver.py:131-136 with f(0) = grad)
   HIP_TRY(hipMemsetAsync(s->h0p, 0, (size_t)s->M * 4, st));
@@ -772,7 +788,8 @@ extern "C" int psignn_broyden_solve_adjoint(psignn_broyden_t* s, const float* W,
   for (int it = 0; it < s->thr; ++it) {
     // x_next = x + update, kept also in h0p (fixed address for the VJP kernels)
     VLAUNCH("k_xnext", st, s->vec, k_xnext, (g, TB, 0, st), s->M, s->st, s->xbuf, s->upd, s->h0p);
-    int rc = psignn_f_vjp(s->plan, W, nl, h_star, prb, nrm, s->h0p, s->fx, s->fwork, st);
+    rc = tiled ? psignn_f_vjp_p(p, W, nl, h_star, prb, nrm, s->h0p, s->fx, s->fwork, st)
+               : psignn_f_vjp(p, W, nl, h_star, prb, nrm, s->h0p, s->fx, s->fwork, st);
     if (rc) return rc;
     VLAUNCH("k_addv", st, s->vec, k_addv, (g, TB, 0, st), s->M, s->st, s->fx, grad);
     launch_update(s, it, eps, st);

@@ -332,6 +332,20 @@ class FixedPointMap:
                       "psignn_f_vjp")
         return out
 
+    def vjp_p(self, Hp, Wp):
+        """vjp with Hp, Wp and the result in plan order (tiled kernels on a tiled single-layer dirichlet plan)."""
+        if self._p is None:
+            self.fp(Hp)
+        _, prbp, nrmp = self._p
+        Hc, Wc = _f32c(Hp), _f32c(Wp)
+        out = torch.empty_like(Hc)
+        with torch.cuda.device(Hc.device):
+            nat.check(nat.lib().psignn_f_vjp_p(self.plan.handle, nat.ptr(self.weights.flat), self.weights.n_layers,
+                                               nat.ptr(Hc), nat.ptr(prbp), nat.ptr(nrmp), nat.ptr(Wc), nat.ptr(out),
+                                               nat.ptr(self.plan.workspace()), nat.stream_ptr(Hc.device)),
+                      "psignn_f_vjp_p")
+        return out
+
     def phi(self, H, which: int, layer: int = 0):
         """One aggregation: 0 Phi_to, 1 Phi_from, 2 Phi_neumann."""
         Hc = _f32c(H)

@@ -40,7 +40,9 @@ print(f"N={plan.N} Ep={plan.Ep} tiled={plan.tiled} tiles={plan.n_tiles} max_rows
 if len(sys.argv) > 5 and sys.argv[5] == "adjoint":
     H = fm.from_plan(x)
     V = torch.randn_like(H)
-    for name, fn in (("jvp", lambda: fm.jvp(H, V)), ("vjp", lambda: fm.vjp(H, V)), ("f (caller order)", lambda: fm(H))):
+    Vp = fm.to_plan(V)
+    for name, fn in (("jvp", lambda: fm.jvp(H, V)), ("vjp", lambda: fm.vjp(H, V)), ("f (caller order)", lambda: fm(H)),
+                     ("vjp_p (plan order)", lambda: fm.vjp_p(x, Vp))):
         fn(); torch.cuda.synchronize()
         t0.record()
         for _ in range(reps):
