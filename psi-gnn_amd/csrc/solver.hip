@@ -58,6 +58,7 @@ struct psignn_broyden {
   Status* h_st = nullptr;   // pinned host mirror
   size_t bytes = 0;
   int ext_iter = 0;
+  int64_t ld = 0;           // row pitch (floats) of U and V
   int plan_order = 1;       // 0 while iterates are kept in the caller's numbering (adjoint solve on the gather kernels)
 };
 
@@ -84,18 +85,25 @@ __device__ __forceinline__ void block_pair_store(float a, float b, float* __rest
 }
 
 
+// Thread -> element mapping of every vector kernel: a wave owns 64*VEC contiguous floats and reads them as VEC/4
+// fully coalesced float4 rows (lane l takes floats [256*i + 4*l, +4) of the wave's span), so one load instruction
+// covers 8 whole 128-byte lines instead of a quarter of 32 lines.  elem0 is the thread's lowest element.
+template <int VEC>
+__device__ __forceinline__ int64_t elem0() {
+  return ((int64_t)blockIdx.x * TB + (threadIdx.x & ~63)) * VEC + (threadIdx.x & 63) * 4;
+}
 template <int VEC>
 __device__ __forceinline__ void ldv(const float* __restrict__ p, int64_t e0, int64_t M, float* r) {
-  if (e0 + VEC <= M) {
-    const float4* q = reinterpret_cast<const float4*>(p + e0);
 #pragma unroll
-    for (int i = 0; i < VEC / 4; ++i) {
-      float4 t = q[i];
+  for (int i = 0; i < VEC / 4; ++i) {
+    const int64_t o = e0 + i * 256;
+    if (o + 4 <= M) {
+      float4 t = *reinterpret_cast<const float4*>(p + o);
       r[4 * i] = t.x; r[4 * i + 1] = t.y; r[4 * i + 2] = t.z; r[4 * i + 3] = t.w;
-    }
-  } else {  // tail
+    } else {  // tail
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) r[i] = (e0 + i < M) ? p[e0 + i] : 0.f;
+      for (int c = 0; c < 4; ++c) r[4 * i + c] = (o + c < M) ? p[o + c] : 0.f;
+    }
   }
 }
 // Loads of the U / V sweeps.  Non-temporal loads were measured and REJECTED: although every byte is read once
@@ -108,11 +116,10 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 template <int VEC>
 __device__ __forceinline__ void ldv_stream(const float* __restrict__ p, int64_t e0, int64_t M, float* r) {
 #if PSIGNN_NT_SWEEPS
-  if (e0 + VEC <= M) {
-    const f4v* q = reinterpret_cast<const f4v*>(p + e0);
+  if (e0 + (VEC / 4 - 1) * 256 + 4 <= M) {
 #pragma unroll
     for (int i = 0; i < VEC / 4; ++i) {
-      f4v t = __builtin_nontemporal_load(q + i);
+      f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p + e0 + i * 256));
       r[4 * i] = t.x; r[4 * i + 1] = t.y; r[4 * i + 2] = t.z; r[4 * i + 3] = t.w;
     }
     return;
@@ -123,14 +130,16 @@ __device__ __forceinline__ void ldv_stream(const float* __restrict__ p, int64_t 
 
 template <int VEC>
 __device__ __forceinline__ void stv(float* __restrict__ p, int64_t e0, int64_t M, const float* r) {
-  if (e0 + VEC <= M) {
-    float4* q = reinterpret_cast<float4*>(p + e0);
 #pragma unroll
-    for (int i = 0; i < VEC / 4; ++i) q[i] = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
-  } else {
+  for (int i = 0; i < VEC / 4; ++i) {
+    const int64_t o = e0 + i * 256;
+    if (o + 4 <= M) {
+      *reinterpret_cast<float4*>(p + o) = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+    } else {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i)
-      if (e0 + i < M) p[e0 + i] = r[i];
+      for (int c = 0; c < 4; ++c)
+        if (o + c < M) p[o + c] = r[4 * i + c];
+    }
   }
 }
 
@@ -150,7 +159,7 @@ __global__ void k_init_status(Status* st, double* rel_trace, double* abs_trace, 
 template <int VEC>
 __global__ __launch_bounds__(TB) void k_begin(int64_t M, const float* __restrict__ x0, const float* __restrict__ fx0,
                                               float* __restrict__ xb, float* __restrict__ gx, float* __restrict__ upd) {
-  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  int64_t e0 = elem0<VEC>();
   if (e0 >= M) return;
   float a[VEC], b[VEC];
   ldv<VEC>(x0, e0, M, a);
@@ -167,7 +176,7 @@ template <int VEC>
 __global__ __launch_bounds__(TB) void k_xnext(int64_t M, const Status* __restrict__ st, float* __restrict__ xb,
                                               const float* __restrict__ upd, float* __restrict__ copy_out) {
   if (st->done) return;
-  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  int64_t e0 = elem0<VEC>();
   if (e0 >= M) return;
   const float* xc = xb + (int64_t)st->cur * M;
   float* xn = xb + (int64_t)st->nxt * M;
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(TB) void k_resid(int64_t M, const Status* __restric
                                               const float* __restrict__ fx, float* __restrict__ gx,
                                               float* __restrict__ dg, float* __restrict__ part, int npart) {
   if (st->done) return;
-  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  int64_t e0 = elem0<VEC>();
   float sg = 0.f, sf = 0.f;
   if (e0 < M) {
     const float* xn = xb + (int64_t)st->nxt * M;
@@ -297,13 +306,13 @@ __global__ __launch_bounds__(TB) void k_dots(int64_t M, int k, const Status* __r
                                              const float* __restrict__ U, const float* __restrict__ V,
                                              const float* __restrict__ dxv, const float* __restrict__ dgv,
                                              const float* __restrict__ gv, float* __restrict__ part, int npart, int thr,
-                                             int jstride) {
+                                             int jstride, int64_t ld) {
   if (st->done) return;
   // blockIdx.y owns the stored pairs [j0, j1): short vectors (small meshes) give few blocks along x, so the
   // sweep is also split over j to cover the 256 CUs (each j still belongs to exactly one block row)
   const int j0 = blockIdx.y * jstride, j1 = min(k, j0 + jstride);
   if (j0 >= j1) return;
-  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  int64_t e0 = elem0<VEC>();
   float dx[VEC], dg[VEC], g[VEC];
   bool act = e0 < M;
   if (act) {
@@ -320,8 +329,8 @@ __global__ __launch_bounds__(TB) void k_dots(int64_t M, int k, const Status* __r
     float u[VEC], v[VEC];
     float sa = 0.f, sc = 0.f, sb = 0.f;
     if (act) {
-      ldv_stream<VEC>(U + (int64_t)j * M, e0, M, u);
-      ldv_stream<VEC>(V + (int64_t)j * M, e0, M, v);
+      ldv_stream<VEC>(U + (int64_t)j * ld, e0, M, u);
+      ldv_stream<VEC>(V + (int64_t)j * ld, e0, M, v);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         sa = fmaf(dx[i], u[i], sa);
@@ -356,15 +365,15 @@ __global__ __launch_bounds__(TB) void k_reduce(const Status* __restrict__ st, co
 template <int VEC>
 __device__ __forceinline__ void axpy_finish(int64_t M, int k, int64_t e0, float* av, float* a1, float* a2, const float* dg,
                                             const float* g, float* __restrict__ U, float* __restrict__ V,
-                                            float* __restrict__ upd, float& p1, float& p2) {
+                                            float* __restrict__ upd, float& p1, float& p2, int64_t ld) {
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     p1 = fmaf(av[i], dg[i], p1);       // with the raw vT, as the reference divides before scrubbing
     av[i] = (av[i] != av[i]) ? 0.f : av[i];
     p2 = fmaf(av[i], g[i], p2);
   }
-  stv<VEC>(V + (int64_t)k * M, e0, M, av);
-  stv<VEC>(U + (int64_t)k * M, e0, M, a1);
+  stv<VEC>(V + (int64_t)k * ld, e0, M, av);
+  stv<VEC>(U + (int64_t)k * ld, e0, M, a1);
   stv<VEC>(upd, e0, M, a2);
 }
 
@@ -373,11 +382,11 @@ __global__ __launch_bounds__(TB) void k_axpy(int64_t M, int k, const Status* __r
                                              float* __restrict__ V, float* __restrict__ upd /* in: dx, out: D2 */,
                                              const float* __restrict__ dgv, const float* __restrict__ gv,
                                              const float* __restrict__ coef, int thr, float* __restrict__ part, int npart,
-                                             int jstride, float* __restrict__ jpart) {
+                                             int jstride, float* __restrict__ jpart, int64_t ld) {
   if (st->done) return;
   const bool split = gridDim.y > 1;
   const int j0 = blockIdx.y * jstride, j1 = min(k, j0 + jstride);
-  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  int64_t e0 = elem0<VEC>();
   float p1 = 0.f, p2 = 0.f;
   if (e0 < M) {
     float av[VEC], a1[VEC], a2[VEC], dg[VEC], g[VEC];
@@ -398,8 +407,8 @@ __global__ __launch_bounds__(TB) void k_axpy(int64_t M, int k, const Status* __r
     for (int j = j0; j < j1; ++j) {
       float u[VEC], v[VEC];
       float ca = coef[j], cc = coef[thr + j], cb = coef[2 * thr + j];
-      ldv_stream<VEC>(U + (int64_t)j * M, e0, M, u);
-      ldv_stream<VEC>(V + (int64_t)j * M, e0, M, v);
+      ldv_stream<VEC>(U + (int64_t)j * ld, e0, M, u);
+      ldv_stream<VEC>(V + (int64_t)j * ld, e0, M, v);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         av[i] = fmaf(ca, v[i], av[i]);
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(TB) void k_axpy(int64_t M, int k, const Status* __r
       stv<VEC>(base + 2 * M, e0, M, a2);
       return;
     }
-    axpy_finish<VEC>(M, k, e0, av, a1, a2, dg, g, U, V, upd, p1, p2);
+    axpy_finish<VEC>(M, k, e0, av, a1, a2, dg, g, U, V, upd, p1, p2, ld);
   }
   if (split) return;
   block_pair_store(p1, p2, part, npart);
@@ -426,9 +435,9 @@ __global__ __launch_bounds__(TB) void k_axpy_combine(int64_t M, int k, int G, co
                                                      const float* __restrict__ jpart, float* __restrict__ U,
                                                      float* __restrict__ V, float* __restrict__ upd,
                                                      const float* __restrict__ dgv, const float* __restrict__ gv,
-                                                     float* __restrict__ part, int npart) {
+                                                     float* __restrict__ part, int npart, int64_t ld) {
   if (st->done) return;
-  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  int64_t e0 = elem0<VEC>();
   float p1 = 0.f, p2 = 0.f;
   if (e0 < M) {
     float av[VEC], a1[VEC], a2[VEC], dg[VEC], g[VEC], t[VEC];
@@ -453,7 +462,7 @@ __global__ __launch_bounds__(TB) void k_axpy_combine(int64_t M, int k, int G, co
 #pragma unroll
       for (int i = 0; i < VEC; ++i) a2[i] += t[i];
     }
-    axpy_finish<VEC>(M, k, e0, av, a1, a2, dg, g, U, V, upd, p1, p2);
+    axpy_finish<VEC>(M, k, e0, av, a1, a2, dg, g, U, V, upd, p1, p2, ld);
   }
   block_pair_store(p1, p2, part, npart);
 }
@@ -472,13 +481,13 @@ __global__ __launch_bounds__(TB) void k_reduce2(Status* st, const float* __restr
 // u = D1 / s (NaN -> 0) -> U[k] ;  update = D2 - u * beta
 template <int VEC>
 __global__ __launch_bounds__(TB) void k_final(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
-                                              float* __restrict__ upd) {
+                                              float* __restrict__ upd, int64_t ld) {
   if (st->done) return;
-  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  int64_t e0 = elem0<VEC>();
   if (e0 >= M) return;
   float s = (float)st->s, beta = (float)st->beta;
   float u[VEC], d2[VEC];
-  float* Uk = U + (int64_t)k * M;
+  float* Uk = U + (int64_t)k * ld;
   ldv<VEC>(Uk, e0, M, u);
   ldv<VEC>(upd, e0, M, d2);
 #pragma unroll
@@ -495,7 +504,7 @@ __global__ __launch_bounds__(TB) void k_final(int64_t M, int k, const Status* __
 template <int VEC>
 __global__ __launch_bounds__(TB) void k_copy_sel(int64_t M, const float* __restrict__ xb, const int32_t* __restrict__ sel,
                                                  int fixed, float* __restrict__ dst) {
-  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  int64_t e0 = elem0<VEC>();
   if (e0 >= M) return;
   int idx = sel ? *sel : fixed;
   float a[VEC];
@@ -529,8 +538,10 @@ static int broyden_alloc(psignn_broyden* s) {
   s->jgroups = s->nblk >= 768 ? 1 : (int)std::min<int64_t>(8, cdiv(768, s->nblk));
   s->npart = s->nblk * (TB / 64);
   size_t nx = s->keep_trace ? thr + 2 : 3;
+  s->ld = (s->M + 63) / 64 * 64;  // row pitch of U and V: every stored vector starts on a 256-byte boundary
+  size_t ld = (size_t)s->ld;
   struct { void** p; size_t n; } allocs[] = {
-      {(void**)&s->U, thr * M * 4},   {(void**)&s->V, thr * M * 4},   {(void**)&s->xbuf, nx * M * 4},
+      {(void**)&s->U, thr * ld * 4},  {(void**)&s->V, thr * ld * 4},   {(void**)&s->xbuf, nx * M * 4},
       {(void**)&s->gx, M * 4},        {(void**)&s->dg, M * 4},        {(void**)&s->upd, M * 4},
       {(void**)&s->fx, M * 4},        {(void**)&s->part, 3 * thr * (size_t)s->npart * 4 + 16},
       {(void**)&s->coef, 3 * thr * 4 + 16}, {(void**)&s->st, sizeof(Status)},
@@ -639,14 +650,14 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
   const int G = (s->jgroups > 1 && k >= 4 * s->jgroups) ? s->jgroups : 1;
   const int js = (int)cdiv(std::max(k, 1), G);
   if (k > 0) {
-    VLAUNCH("k_dots", st, s->vec, k_dots, (dim3(g, G), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->npart, s->thr, js);
+    VLAUNCH("k_dots", st, s->vec, k_dots, (dim3(g, G), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->npart, s->thr, js, s->ld);
     LAUNCH("k_reduce", st, (k_reduce<<<dim3(k, 3), TB, 0, st>>>(s->st, s->part, s->npart, s->thr, s->coef)));
   }
-  VLAUNCH("k_axpy", st, s->vec, k_axpy, (dim3(g, G), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->nblk, js, s->jpart);
+  VLAUNCH("k_axpy", st, s->vec, k_axpy, (dim3(g, G), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->nblk, js, s->jpart, s->ld);
   if (G > 1)
-    VLAUNCH("k_axpy_combine", st, s->vec, k_axpy_combine, (g, TB, 0, st), s->M, k, G, s->st, s->jpart, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->nblk);
+    VLAUNCH("k_axpy_combine", st, s->vec, k_axpy_combine, (g, TB, 0, st), s->M, k, G, s->st, s->jpart, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->nblk, s->ld);
   LAUNCH("k_reduce2", st, (k_reduce2<<<1, TB, 0, st>>>(s->st, s->part, s->nblk)));
-  VLAUNCH("k_final", st, s->vec, k_final, (g, TB, 0, st), s->M, k, s->st, s->U, s->upd);
+  VLAUNCH("k_final", st, s->vec, k_final, (g, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->ld);
 }
 
 static int read_status(psignn_broyden* s, hipStream_t st) {
@@ -742,7 +753,7 @@ template <int VEC>
 __global__ __launch_bounds__(TB) void k_addv(int64_t M, const Status* __restrict__ st, float* __restrict__ a,
                                              const float* __restrict__ b) {
   if (st->done) return;
-  int64_t e0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * VEC;
+  int64_t e0 = elem0<VEC>();
   if (e0 >= M) return;
   float x[VEC], y[VEC];
   ldv<VEC>(a, e0, M, x);
