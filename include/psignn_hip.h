@@ -148,6 +148,26 @@ int psignn_f_vjp_p(const psignn_plan_t* plan, const float* d_weights, int n_laye
                    const float* d_prb, const float* d_normals, const float* d_w, float* d_out, float* d_work,
                    void* stream);
 
+/* Parameter gradient  w^T (d f / d theta)  at h (plan order; tiled single-layer dirichlet plans), together with
+ * w^T (d f / d h) -> d_out_h.  Replaces loss.backward() through new_H = f(H*, H_init, batch) with the hooked
+ * cotangent (dirichlet/psignn/model.py:203-225, training_class.py:150-163).  d_grad receives
+ * psignn_param_grad_size(mixed, n_layers) floats laid out like the leading (un-derived) section of the packed
+ * weights: shared{ln_gamma, ln_beta, alpha_w, alpha_b} | phi_to{W1,b1,W2,b2} | phi_from | update{U1,c1,U2,c2};
+ * derived (fold) slots stay zero.  d_work: psignn_f_param_vjp_workspace_floats(plan) floats. */
+int64_t psignn_param_grad_size(int mixed, int n_layers);
+int64_t psignn_f_param_vjp_workspace_floats(const psignn_plan_t* plan);
+int psignn_f_param_vjp_p(const psignn_plan_t* plan, const float* d_weights, int n_layers, const float* d_h,
+                         const float* d_prb, const float* d_w, float* d_grad, float* d_out_h, float* d_work,
+                         void* stream);
+
+/* Backward of psignn_mlp2 and of psignn_residual: what autograd runs for the autoencoder and residual terms of
+ * the training loss (dirichlet/psignn/model.py:58-99).  d_gflat = gradients of [W1 | b1 | W2 | b2];
+ * d_gx (n, din) may be NULL.  psignn_residual_t: out = A^T r with the caller's a_ij (E floats, edge_index order). */
+int64_t psignn_mlp2_backward_workspace_floats(int64_t n);
+int psignn_mlp2_backward(const float* d_x, const float* d_gy, int64_t n, int din, int hid, int dout, const float* d_w1,
+                         const float* d_b1, const float* d_w2, float* d_gx, float* d_gflat, float* d_work, void* stream);
+int psignn_residual_t(const psignn_plan_t* plan, const float* d_a_ij, const float* d_r, float* d_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Small dense pieces around the solve.
  * replaces: Encoder / Decoder MLPs (model.py:370-392), residual_loss SpMV (model.py:157-167).

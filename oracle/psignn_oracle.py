@@ -337,3 +337,56 @@ def function_vjp(sd, h, h_initial, batch, v):
     hh = h.detach().clone().requires_grad_(True)
     out = function_forward(sd, hh, h_initial, batch)
     return torch.autograd.grad(out, hh, v)[0]
+
+
+# --------------------------------------------------------------------------------------
+# training side (dirichlet/psignn/model.py:58-99,184-225; training_class.py:146-166)
+# --------------------------------------------------------------------------------------
+def function_param_vjp(sd, h, h_initial, batch, v):
+    """What ``loss.backward()`` leaves behind for ``new_H = f(H, H_init)`` with cotangent v: ({deqdss.f.* name: grad},
+    vᵀ∂f/∂H, vᵀ∂f/∂H_init).  Plain autograd on the restated f."""
+    p = {k: (t.detach().clone().requires_grad_(True) if k.startswith("deqdss.f.") else t) for k, t in sd.items()}
+    hh = h.detach().clone().requires_grad_(True)
+    h0 = h_initial.detach().clone().requires_grad_(True)
+    out = function_forward(p, hh, h0, batch)
+    names = [k for k in p if k.startswith("deqdss.f.")]
+    g = torch.autograd.grad(out, [p[k] for k in names] + [hh, h0], v, allow_unused=True)
+    return {k[len("deqdss.f."):]: t for k, t in zip(names, g[:-2])}, g[-2], g[-1]
+
+
+def training_step(sd, batch, solver=broyden, fw_tol=1e-5, fw_thres=500, bw_tol=1e-8, bw_thres=500):
+    """One training forward + ``loss.backward()`` of the dirichlet model, jac_weight = 0 (the reference default,
+    utilities/utils.py:58): returns (loss, loss_dic, {state_dict name: grad}, forward dict, backward dict).
+
+    Restates ``ModelDEQDSS.forward`` (model.py:58-99), ``DeepEquilibrium.forward`` incl. the backward hook that swaps
+    the incoming gradient for the solution of y = Jᵀy + grad (model.py:184-225) and the loss combination of
+    ``TrainModel.train_loop`` (training_class.py:155-159)."""
+    p = {k: t.detach().clone().requires_grad_(True) for k, t in sd.items()}
+    mse = torch.nn.functional.mse_loss
+    h_init = encoder(p, batch.x)
+    with torch.no_grad():
+        out_fw = solver(lambda H: function_forward(p, H, h_init, batch), h_init, threshold=fw_thres, eps=fw_tol)
+    H_star = out_fw["result"].detach().clone().requires_grad_()
+    new_H = function_forward(p, H_star, h_init, batch)
+    state = {}
+
+    def backward_hook(grad):
+        state["hook"].remove()   # the reference removes the hook first so that the VJPs below do not re-enter it
+        out_bw = solver(lambda y: torch.autograd.grad(new_H, H_star, y, retain_graph=True)[0] + grad,
+                        torch.zeros_like(grad), threshold=bw_thres, eps=bw_tol)
+        state["out_bw"] = out_bw
+        return out_bw["result"]
+
+    state["hook"] = new_H.register_hook(backward_hook)
+    u = decoder(p, new_H)
+    loss_dic = {"residual_loss": residual_loss(u, batch)}
+    u_d, h_d = u.detach(), new_H.detach()
+    loss_dic["encoder_loss"] = mse(encoder(p, u_d), h_d)
+    loss_dic["autoencoder_loss"] = mse(decoder(p, encoder(p, u_d).detach()), u_d)
+    loss_dic["mse_loss"] = mse(u, batch.sol)
+    idx = torch.where(batch.tags[:, 0] == 1)[0]
+    loss_dic["mse_dirichlet"] = mse(u[idx, :], batch.x[idx, :])
+    loss = loss_dic["residual_loss"] + loss_dic["encoder_loss"] + loss_dic["autoencoder_loss"]
+    loss.backward()
+    grads = {k: (t.grad if t.grad is not None else torch.zeros_like(t)) for k, t in p.items()}
+    return loss.detach(), {k: v.detach() for k, v in loss_dic.items()}, grads, out_fw, state.get("out_bw")

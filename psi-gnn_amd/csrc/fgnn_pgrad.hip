@@ -1,0 +1,309 @@
+// Parameter gradient of f_theta:  grad_theta = w^T (d f / d theta)  at a fixed point h  (gfx950, dirichlet family,
+// single layer, tiled plan, plan order).
+//
+// Reference: loss.backward() through  new_H = f(H*, H_init, batch)  with the hooked cotangent (the solution of the
+// adjoint system) -- dirichlet/psignn/model.py:203-225, training_class.py:150-163.  Autograd accumulates every
+// weight's gradient with one small GEMM per Linear over the (E', 23) / (N, 32) activations.  Here:
+//   1. the tiled VJP kernels (fgnn_tile_vjp.hip, PG mode) run as usual and, per node, leave a RECORD of 20 groups of
+//      16 floats: the left factors (cotangents at each Linear's output) and right factors (each Linear's input).
+//      Edge-level sums collapse to node-level ones:  sum_e dz_e (x) x_i = gt[n] (x) x[n];  sum_e dz_e (x) x_j regrouped
+//      by the neighbour = acc[u] (x) x[u] (acc = pass B's neighbour-side sums);  sum_e dz_e (x) a_e = dS (.) moments.
+//   2. k_pgrad_outer: every weight gradient is  sum_n A_n (x) B_n  for one (A group, B group) pair -> 16 MFMA
+//      accumulator tiles (v_mfma_f32_16x16x4_f32, 4 nodes per instruction, K = nodes).  fp32 MFMA accumulates in k
+//      order, a wave owns a fixed node range, partials are combined in a fixed order: bitwise reproducible.
+//   3. k_pgrad_reduce: sum of the per-block partial tiles (fp64) and scatter into the flat gradient, laid out like
+//      the base section of the packed weights (WLayout: shared | phi_to | phi_from | update).
+#include "fgnn_common.h"
+
+#define PGREC 320
+#define PG_TILES 16
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+int psignn_f_tile_vjp_rec(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* w,
+                          float* out, float* work, float* rec, hipStream_t st);
+
+// Record tables: accumulator tile t = (A group, B group) of the record; A group -1 = the constant row (column sums).
+struct TabF {  // f_theta: 20 groups (layout in k_vjp_tile_a), 16 tiles
+  static constexpr int NG = 20, NT = 16;
+  __host__ __device__ static constexpr int a(int t) {
+    constexpr int tab[NT] = {6, 6, 6, 7, 8, 9, 10, 11, 12, 13, -1, -1, -1, -1, -1, -1};
+    return tab[t];
+  }
+  __host__ __device__ static constexpr int b(int t) {
+    constexpr int tab[NT] = {0, 1, 2, 0, 0, 3, 4, 5, 0, 0, 14, 15, 16, 17, 18, 19};
+    return tab[t];
+  }
+};
+struct TabM {  // two-layer MLP: groups {x|1, hid|1, d hid, d y}, tiles (d hid) x (x|1), (d y) x (hid|1)
+  static constexpr int NG = 4, NT = 2;
+  __host__ __device__ static constexpr int a(int t) { return t == 0 ? 2 : 3; }
+  __host__ __device__ static constexpr int b(int t) { return t == 0 ? 0 : 1; }
+};
+
+template <class Tab>
+__global__ __launch_bounds__(256) void k_pgrad_outer(int64_t N, int nodes_per_wave, const float* __restrict__ rec,
+                                                     float* __restrict__ part) {
+  constexpr int NG = Tab::NG, NT = Tab::NT, REC = 16 * NG;
+  __shared__ float sh[4 * NT * 256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wv;
+  const int64_t nb = gw * nodes_per_wave, ne = min(N, nb + nodes_per_wave);
+  f4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+  const float one = (lane & 15) == 0 ? 1.f : 0.f;
+  for (int64_t n0 = nb; n0 < ne; n0 += 4) {
+    const int64_t node = n0 + (lane >> 4);
+    const bool ok = node < ne;
+    const float* r = rec + node * REC + (lane & 15);
+    float v[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) v[g] = ok ? r[16 * g] : 0.f;
+    const float on = ok ? one : 0.f;
+    // A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15]: both read the same (node, column) pattern
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Tab::a(t) < 0 ? on : v[Tab::a(t) < 0 ? 0 : Tab::a(t)], v[Tab::b(t)],
+                                                    acc[t], 0, 0, 0);
+  }
+  // D[i = 4 (lane >> 4) + r][j = lane & 15] -> sh[wave][tile][i * 16 + j]
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh[(wv * NT + t) * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[t][r];
+  __syncthreads();
+  for (int i = threadIdx.x; i < NT * 256; i += 256)
+    part[(int64_t)blockIdx.x * NT * 256 + i] = (sh[i] + sh[NT * 256 + i]) + (sh[2 * NT * 256 + i] + sh[3 * NT * 256 + i]);
+}
+
+// flat offset of accumulator entry (tile t, row i, col j) in the base weight layout, or -1
+template <int P>
+__device__ __forceinline__ int pg_offset(int t, int i, int j) {
+  using L = WLayout<P>;
+  constexpr int lo = L::layer(0);
+  constexpr int U1 = lo + L::L_UPD + L::UPD_W1;
+  switch (t) {
+    case 0:  // (dq | ds) x (x | 1)
+      if (i < D) return j < D ? U1 + i * L::CAT + j : (j == D ? lo + L::L_UPD + L::UPD_B1 + i : -1);
+      if (i == D) return j < D ? L::AL_W + j : (j == D ? L::AL_B : -1);
+      return -1;
+    case 1:  // (dq | ds) x (mp_to | prb)
+      if (i < D) return j < D ? U1 + i * L::CAT + D + j : (j < D + P ? U1 + i * L::CAT + 3 * D + (j - D) : -1);
+      if (i == D) return j < D ? L::AL_W + D + j : (j < D + P ? L::AL_W + 3 * D + (j - D) : -1);
+      return -1;
+    case 2:  // (dq | ds) x mp_from
+      if (j >= D) return -1;
+      if (i < D) return U1 + i * L::CAT + 2 * D + j;
+      return i == D ? L::AL_W + 2 * D + j : -1;
+    case 3:
+    case 4: {  // own-edge cotangent sums x (x | 1): W1 x_i block and b1
+      const int ph = lo + (t == 3 ? L::L_TO : L::L_FROM);
+      if (i >= D) return -1;
+      return j < D ? ph + L::PHI_W1 + i * L::EIN + j : (j == D ? ph + L::PHI_B1 + i : -1);
+    }
+    case 5:
+    case 6: {  // d mp x (S | deg): W2 and b2
+      const int ph = lo + (t == 5 ? L::L_TO : L::L_FROM);
+      if (i >= D) return -1;
+      return j < D ? ph + L::PHI_W2 + i * D + j : (j == D ? ph + L::PHI_B2 + i : -1);
+    }
+    case 7:  // d upd0 x (hid | 1): U2 and c2
+      if (i >= D) return -1;
+      return j < D ? lo + L::L_UPD + L::UPD_W2 + i * D + j : (j == D ? lo + L::L_UPD + L::UPD_B2 + i : -1);
+    case 8:
+    case 9: {  // neighbour-side cotangent sums x x: W1 x_j block
+      const int ph = lo + (t == 8 ? L::L_TO : L::L_FROM);
+      return (i < D && j < D) ? ph + L::PHI_W1 + i * L::EIN + D + j : -1;
+    }
+    case 10: return (i == 0 && j < D) ? L::LN_G + j : -1;
+    case 11: return (i == 0 && j < D) ? L::LN_B + j : -1;
+    default: {  // column sums of dS (.) attr moments: index o * 3 + c, to-block then from-block
+      if (i != 0) return -1;
+      const int idx = (t - 12) * 16 + j;
+      if (idx >= 60) return -1;
+      const int ph = lo + (idx < 30 ? L::L_TO : L::L_FROM);
+      const int k = idx < 30 ? idx : idx - 30;
+      return ph + L::PHI_W1 + (k / 3) * L::EIN + 2 * D + (k % 3);
+    }
+  }
+}
+
+struct MapF {  // f_theta, dirichlet
+  __device__ int operator()(int t, int i, int j) const { return pg_offset<2>(t, i, j); }
+};
+struct MapM {  // flat [W1 (hid, din) | b1 | W2 (dout, hid) | b2]
+  int din, hid, dout;
+  __device__ int operator()(int t, int i, int j) const {
+    if (t == 0) return i >= hid ? -1 : (j < din ? i * din + j : (j == din ? hid * din + i : -1));
+    const int o2 = hid * din + hid;
+    return i >= dout ? -1 : (j < hid ? o2 + i * hid + j : (j == hid ? o2 + dout * hid + i : -1));
+  }
+};
+
+// sum of the per-block partial tiles (fixed order, fp64) scattered to the flat gradient
+template <class Map>
+__global__ __launch_bounds__(256) void k_pgrad_reduce(int nblk, int nt, const float* __restrict__ part,
+                                                      float* __restrict__ grad, Map map) {
+  const int e = blockIdx.x * 256 + threadIdx.x;  // < nt * 256
+  const int t = e >> 8, i = (e >> 4) & 15, j = e & 15;
+  const int off = map(t, i, j);
+  if (off < 0) return;
+  double s0 = 0.0, s1 = 0.0;
+  int b = 0;
+  for (; b + 1 < nblk; b += 2) {
+    s0 += (double)part[(int64_t)b * nt * 256 + e];
+    s1 += (double)part[(int64_t)(b + 1) * nt * 256 + e];
+  }
+  if (b < nblk) s0 += (double)part[(int64_t)b * nt * 256 + e];
+  grad[off] = (float)(s0 + s1);
+}
+
+static inline int pgrad_blocks(int64_t N, int* nodes_per_wave) {
+  // a wave owns >= 64 nodes (multiple of 4); at most 1024 blocks of 4 waves
+  int64_t npw = std::max<int64_t>(64, cdiv(cdiv(N, (int64_t)4096), (int64_t)4) * 4);
+  *nodes_per_wave = (int)npw;
+  return (int)cdiv(N, npw * 4);
+}
+
+extern "C" int64_t psignn_f_param_vjp_workspace_floats(const psignn_plan_t* p) {
+  if (!p) return 0;
+  int npw;
+  const int nblk = pgrad_blocks(p->N, &npw);
+  return p->N * (4 * D + PGREC) + (int64_t)nblk * PG_TILES * 256;
+}
+
+extern "C" int64_t psignn_param_grad_size(int mixed, int nl) {
+  return mixed ? WLayout<3>::base_total(nl, true) : WLayout<2>::base_total(nl, false);
+}
+
+// h, prb, w in PLAN order.  d_grad: psignn_param_grad_size floats (fold slots left zero); d_out_h: (N, 10) = w^T df/dh.
+extern "C" int psignn_f_param_vjp_p(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* prb,
+                                    const float* w, float* d_grad, float* d_out_h, float* work, void* stream) {
+  ARG_CHECK(p && W && h && prb && w && d_grad && d_out_h && work, "NULL argument");
+  ARG_CHECK(p->tiled && !p->mixed && nl == 1,
+            "parameter gradients are implemented for tiled single-layer dirichlet plans (mesh positions required)");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t N = p->N;
+  float* B = work;
+  float* rec = B + N * 4 * D;
+  float* part = rec + N * PGREC;
+  int npw;
+  const int nblk = pgrad_blocks(N, &npw);
+  int rc = psignn_f_tile_vjp_rec(p, W, nl, h, prb, w, d_out_h, B, rec, st);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)WLayout<2>::base_total(nl, false) * 4, st));
+  LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabF><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
+  LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabF::NT, 256, 0, st>>>(nblk, TabF::NT, part, d_grad, MapF())));
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the two-layer MLP (Encoder / Decoder, model.py:370-392; y = W2 relu(W1 x + b1) + b2) and the
+// transposed residual SpMV -- what autograd runs for the autoencoder / residual terms of the training loss
+// (dirichlet/psignn/model.py:58-99, 157-167).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mlp2_bwd(int64_t n, int din, int hid, int dout, const float* __restrict__ x,
+                                                  const float* __restrict__ gy, const float* __restrict__ w1,
+                                                  const float* __restrict__ b1, const float* __restrict__ w2,
+                                                  float* __restrict__ gx, float* __restrict__ rec) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  float g[4][16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) g[q][i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (i < din) g[0][i] = x[r * din + i];
+    if (i < dout) g[3][i] = gy[r * dout + i];
+  }
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    if (o < hid) {
+      float s = b1[o];
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (i < din) s = fmaf(w1[o * din + i], g[0][i], s);
+      float d = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (k < dout) d = fmaf(w2[k * hid + o], g[3][k], d);
+      g[1][o] = fmaxf(s, 0.f);
+      g[2][o] = s > 0.f ? d : 0.f;
+    }
+  }
+  if (gx) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i < din) {
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < 16; ++o)
+          if (o < hid) s = fmaf(w1[o * din + i], g[2][o], s);
+        gx[r * din + i] = s;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {  // the constant column of the two right-factor groups
+    if (i == din) g[0][i] = 1.f;
+    if (i == hid) g[1][i] = 1.f;
+  }
+  float4* q = reinterpret_cast<float4*>(rec + r * 64);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[a * 4 + i] = make_float4(g[a][4 * i], g[a][4 * i + 1], g[a][4 * i + 2], g[a][4 * i + 3]);
+}
+
+extern "C" int64_t psignn_mlp2_backward_workspace_floats(int64_t n) {
+  int npw;
+  const int nblk = pgrad_blocks(n, &npw);
+  return n * 64 + (int64_t)nblk * TabM::NT * 256;
+}
+
+// d_gflat: [W1 (hid, din) | b1 (hid) | W2 (dout, hid) | b2 (dout)] gradients; d_gx (n, din) may be NULL.
+extern "C" int psignn_mlp2_backward(const float* x, const float* gy, int64_t n, int din, int hid, int dout, const float* w1,
+                                    const float* b1, const float* w2, float* d_gx, float* d_gflat, float* work,
+                                    void* stream) {
+  ARG_CHECK(x && gy && w1 && b1 && w2 && d_gflat && work, "NULL argument");
+  ARG_CHECK(n >= 0 && din >= 1 && din <= 15 && hid >= 1 && hid <= 15 && dout >= 1 && dout <= 15, "bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(d_gflat, 0, (size_t)(hid * din + hid + dout * hid + dout) * 4, st));
+  if (n == 0) return PSIGNN_OK;
+  float* rec = work;
+  float* part = rec + n * 64;
+  int npw;
+  const int nblk = pgrad_blocks(n, &npw);
+  LAUNCH("k_mlp2_bwd", st, (k_mlp2_bwd<<<(unsigned)cdiv(n, (int64_t)256), 256, 0, st>>>(n, din, hid, dout, x, gy, w1, b1, w2, d_gx, rec)));
+  LAUNCH("k_pgrad_outer_mlp", st, (k_pgrad_outer<TabM><<<nblk, 256, 0, st>>>(n, npw, rec, part)));
+  LAUNCH("k_pgrad_reduce_mlp", st, (k_pgrad_reduce<<<TabM::NT, 256, 0, st>>>(nblk, TabM::NT, part, d_gflat, MapM{din, hid, dout})));
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+
+// out = A^T r  (A = COO(edge_index, a_ij) incl. the diagonal): in-edge lists of the plan + the caller's a_ij
+__global__ __launch_bounds__(256) void k_residual_t(int64_t N, const int32_t* __restrict__ csc_ptr,
+                                                    const int32_t* __restrict__ csc_nbr, const int32_t* __restrict__ csc_eid,
+                                                    const float* __restrict__ a_ij, const int32_t* __restrict__ a_ptr,
+                                                    const int32_t* __restrict__ a_col, const float* __restrict__ a_val,
+                                                    const float* __restrict__ r, float* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int32_t i = csc_ptr[c]; i < csc_ptr[c + 1]; ++i) s = fmaf(a_ij[csc_eid[i]], r[csc_nbr[i]], s);
+  float dg = 0.f;
+  for (int32_t i = a_ptr[c]; i < a_ptr[c + 1]; ++i)
+    if (a_col[i] == (int32_t)c) dg += a_val[i];
+  out[c] = fmaf(dg, r[c], s);
+}
+
+extern "C" int psignn_residual_t(const psignn_plan_t* p, const float* d_a_ij, const float* d_r, float* d_out, void* stream) {
+  ARG_CHECK(p && d_a_ij && d_r && d_out, "NULL argument");
+  k_residual_t<<<(unsigned)cdiv(p->N, (int64_t)256), 256, 0, (hipStream_t)stream>>>(
+      p->N, p->csc_ptr, p->csc_nbr, p->csc_eid, d_a_ij, p->a_ptr, p->a_col, p->a_val, d_r, d_out);
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}

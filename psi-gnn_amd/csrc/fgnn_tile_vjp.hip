@@ -17,6 +17,7 @@
 #define SLOT_IN 0x10000u
 #define SLOT_OUT 0x20000u
 #define VT 256
+#define PGREC 320   // floats per node of a parameter-gradient record: 20 groups of 16 (layout in k_vjp_tile_a)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f splat2(float a) { return (v2f){a, a}; }
@@ -65,9 +66,10 @@ __device__ __forceinline__ void row10u(const float* __restrict__ row, v2f* pj) {
 
 // ---------------------------------------------------------------------------------------------- pass A
 // forward sum S[o] += relu(z) and cnt[o] += 1[z > 0] over the slots carrying MASK; z = Pi + row[COL..] + AT . a
-template <int RS, int COL, unsigned MASK>
+// PG (parameter-gradient mode): also m[c*5 + p] += 1[z > 0] * a_c, the attr moments the W1 attr-block gradient needs.
+template <int RS, int COL, unsigned MASK, bool PG>
 __device__ __forceinline__ float pass_fwd(const uint4* __restrict__ slots, int nslots, const float* __restrict__ lds,
-                                          const float* __restrict__ AT, const v2f* Pi, v2f* S, v2f* cnt) {
+                                          const float* __restrict__ AT, const v2f* Pi, v2f* S, v2f* cnt, v2f* m) {
   float deg = 0.f;
   v2f wa[15];
 #pragma unroll
@@ -95,7 +97,13 @@ __device__ __forceinline__ float pass_fwd(const uint4* __restrict__ slots, int n
 #pragma unroll
       for (int p = 0; p < 5; ++p) {
         S[p] += __builtin_elementwise_max(z[p], splat2(0.f));
-        cnt[p] += (v2f){z[p].x > 0.f ? 1.f : 0.f, z[p].y > 0.f ? 1.f : 0.f};
+        const v2f mk = (v2f){z[p].x > 0.f ? 1.f : 0.f, z[p].y > 0.f ? 1.f : 0.f};
+        cnt[p] += mk;
+        if (PG) {
+          m[p] = __builtin_elementwise_fma(mk, a0, m[p]);
+          m[5 + p] = __builtin_elementwise_fma(mk, a1, m[5 + p]);
+          m[10 + p] = __builtin_elementwise_fma(mk, a2, m[10 + p]);
+        }
       }
     }
     c0 = c1;
@@ -104,7 +112,17 @@ __device__ __forceinline__ float pass_fwd(const uint4* __restrict__ slots, int n
   return deg;
 }
 
-template <int P>
+// one 16-float group of a parameter-gradient record: v[0..n) then `tail`, then zeros
+__device__ __forceinline__ void rec_group(float* __restrict__ g, const float* v, int n, float t0 = 0.f, float t1 = 0.f) {
+  float r[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r[i] = i < n ? v[i] : (i == n ? t0 : (i == n + 1 ? t1 : 0.f));
+  float4* q = reinterpret_cast<float4*>(g);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+}
+
+template <int P, bool PG>
 __global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
                                                    const int32_t* __restrict__ tile_slice, const int32_t* __restrict__ halo,
                                                    const int32_t* __restrict__ halo_cnt, const int32_t* __restrict__ slice_off,
@@ -112,7 +130,7 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const
                                                    const uint8_t* __restrict__ flags, const float* __restrict__ W, int lofs,
                                                    int tofs, const float* __restrict__ h, const float* __restrict__ prb,
                                                    const float* __restrict__ wv, float* __restrict__ B,
-                                                   float* __restrict__ out) {
+                                                   float* __restrict__ out, float* __restrict__ rec) {
   using L = WLayout<P>;
   constexpr int RS = 20;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -157,6 +175,12 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const
 #pragma unroll
     for (int o = 0; o < D; ++o) zero[o] = 0.f;
     store10(out + n * D, zero);
+    if (PG) {  // a constant row still acts as a neighbour: its (x, 1) group feeds the W1j products of pass B
+      float* r = rec + n * PGREC;
+      rec_group(r, x, D, 1.f);
+      for (int gI = 1; gI < PGREC / 16; ++gI)
+        if (gI != 12 && gI != 13) rec_group(r + 16 * gI, zero, 0);
+    }
     return;
   }
   const int lane = tid & 63;
@@ -165,14 +189,19 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const
   const int nslots = slice_deg[slice];
   // ---- forward with activity counts
   v2f Pt[5], Pf[5], S_to[5], S_fr[5], c_to[5], c_fr[5];
+  v2f m_to[PG ? 15 : 1], m_fr[PG ? 15 : 1];
+  if (PG) {
+#pragma unroll
+    for (int i = 0; i < 15; ++i) m_to[PG ? i : 0] = m_fr[PG ? i : 0] = splat2(0.f);
+  }
   ldu5(T + L::T_B1_TO, Pt);
   ldu5(T + L::T_B1_FR, Pf);
 #pragma unroll
   for (int p = 0; p < 5; ++p) S_to[p] = S_fr[p] = c_to[p] = c_fr[p] = splat2(0.f);
   mvf<D>(T + L::T_W1I_TO, x, Pt);
-  const float deg_in = pass_fwd<RS, 0, SLOT_IN>(slots, nslots, lds, T + L::T_A_TO, Pt, S_to, c_to);
+  const float deg_in = pass_fwd<RS, 0, SLOT_IN, PG>(slots, nslots, lds, T + L::T_A_TO, Pt, S_to, c_to, m_to);
   mvf<D>(T + L::T_W1I_FR, x, Pf);
-  const float deg_out = pass_fwd<RS, D, SLOT_OUT>(slots, nslots, lds, T + L::T_A_FR, Pf, S_fr, c_fr);
+  const float deg_out = pass_fwd<RS, D, SLOT_OUT, PG>(slots, nslots, lds, T + L::T_A_FR, Pf, S_fr, c_fr, m_fr);
   const float* Wf = W + lofs + L::L_FOLD;
   const float* Wu = W + lofs + L::L_UPD;
   const float* Wa = W + L::AL_W;
@@ -293,6 +322,59 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const
     go[2 * p + 1] = g[p].y;
   }
   store10(out + n * D, go);
+  if (PG) {
+    // ---- parameter-gradient record (fgnn_pgrad.hip reduces sum_n A_n (x) B_n over these 16-float groups)
+    float* r = rec + n * PGREC;
+    float mp[D], t[D];
+    rec_group(r, x, D, 1.f);                                                   // 0: x, 1
+#pragma unroll
+    for (int o = 0; o < D; ++o) mp[o] = deg_in * Wto[L::PHI_B2 + o];
+    matvec10<D, true>(Wto + L::PHI_W2, D, 0, sto, mp);
+    rec_group(r + 16, mp, D, pq[0], pq[1]);                                    // 1: mp_to, prb
+#pragma unroll
+    for (int o = 0; o < D; ++o) mp[o] = deg_out * Wfr[L::PHI_B2 + o];
+    matvec10<D, true>(Wfr + L::PHI_W2, D, 0, sfr, mp);
+    rec_group(r + 32, mp, D);                                                  // 2: mp_from
+    rec_group(r + 48, sto, D, deg_in);                                         // 3: S_to, deg_in
+    rec_group(r + 64, sfr, D, deg_out);                                        // 4: S_from, deg_out
+    rec_group(r + 80, reinterpret_cast<const float*>(hid2), D, 1.f);           // 5: hid, 1
+    rec_group(r + 96, dq, D, dal);                                             // 6: dq, ds
+    rec_group(r + 112, gt, D);                                                 // 7: sum of masked cotangents, in-edges
+    rec_group(r + 128, gf, D);                                                 // 8: same, out-edges
+    v2f dm[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) dm[p] = (v2f){Wa[D + 2 * p], Wa[D + 2 * p + 1]} * splat2(dal);
+    mvb<D>(Wu + L::UPD_W1, L::CAT, D, dq, dm);
+    rec_group(r + 144, reinterpret_cast<const float*>(dm), D);                 // 9: d mp_to
+#pragma unroll
+    for (int p = 0; p < 5; ++p) dm[p] = (v2f){Wa[2 * D + 2 * p], Wa[2 * D + 2 * p + 1]} * splat2(dal);
+    mvb<D>(Wu + L::UPD_W1, L::CAT, 2 * D, dq, dm);
+    rec_group(r + 160, reinterpret_cast<const float*>(dm), D);                 // 10: d mp_from
+    rec_group(r + 176, dupd, D);                                               // 11: d upd0   (12, 13: pass B)
+#pragma unroll
+    for (int o = 0; o < D; ++o) t[o] = w[o] * y[o];
+    rec_group(r + 224, t, D);                                                  // 14: w * yhat
+    rec_group(r + 240, w, D);                                                  // 15: w
+    // 16..19: dS[o] * (attr moments), index o*3 + c as in the W1 attr block; in-edges carry the mirrored attr
+    float da[64];
+    const float* dst = reinterpret_cast<const float*>(dS_to);
+    const float* dsf = reinterpret_cast<const float*>(dS_fr);
+    const float* mt = reinterpret_cast<const float*>(m_to);
+    const float* mf = reinterpret_cast<const float*>(m_fr);
+#pragma unroll
+    for (int o = 0; o < D; ++o) {
+      da[o * 3] = -dst[o] * mt[o];
+      da[o * 3 + 1] = -dst[o] * mt[10 + o];
+      da[o * 3 + 2] = dst[o] * mt[20 + o];
+      da[30 + o * 3] = dsf[o] * mf[o];
+      da[30 + o * 3 + 1] = dsf[o] * mf[10 + o];
+      da[30 + o * 3 + 2] = dsf[o] * mf[20 + o];
+    }
+    da[60] = da[61] = da[62] = da[63] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      reinterpret_cast<float4*>(r + 256)[i] = make_float4(da[4 * i], da[4 * i + 1], da[4 * i + 2], da[4 * i + 3]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- pass B
@@ -334,14 +416,14 @@ __device__ __forceinline__ void pass_rev(const uint4* __restrict__ slots, int ns
   }
 }
 
-template <int P>
+template <int P, bool PG>
 __global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
                                                    const int32_t* __restrict__ tile_slice, const int32_t* __restrict__ halo,
                                                    const int32_t* __restrict__ halo_cnt, const int32_t* __restrict__ slice_off,
                                                    const uint8_t* __restrict__ slice_deg, const uint4* __restrict__ ell,
                                                    const float* __restrict__ W, int lofs, int tofs,
                                                    const float* __restrict__ h, const float* __restrict__ B,
-                                                   float* __restrict__ out) {
+                                                   float* __restrict__ out, float* __restrict__ rec) {
   using L = WLayout<P>;
   constexpr int RS = 40;  // LDS row = B row: [Pt 10 | Pf 10 | dS_to 10 | dS_fr 10]
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -380,6 +462,10 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const
   for (int p = 0; p < 5; ++p) Pj[p] = splat2(0.f);
   mvf<D>(T + L::T_W1J_FR, x, Pj);
   pass_rev<RS, D, 3 * D, SLOT_IN>(slots, nslots, lds, T + L::T_A_FR, -1.f, Pj, af);
+  if (PG) {  // neighbour-side cotangent sums: W1j gradients are sum_u acc[u] (x) x[u]
+    rec_group(rec + u * PGREC + 192, reinterpret_cast<const float*>(at), D);
+    rec_group(rec + u * PGREC + 208, reinterpret_cast<const float*>(af), D);
+  }
   float go[D];
   load10(out + u * D, go);
   v2f g[5];
@@ -398,21 +484,37 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const
 }
 
 // ---------------------------------------------------------------------------------------------- host
-// h, prb, w, out in PLAN order; work: (N, 40) floats for B.
-int psignn_f_tile_vjp(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* w,
-                      float* out, float* work, hipStream_t st) {
+static int tile_vjp_launch(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* w,
+                           float* out, float* work, float* rec, hipStream_t st) {
   ARG_CHECK(p && p->tiled && !p->mixed && nl == 1, "tiled VJP: dirichlet single-layer plans only");
   using L = WLayout<2>;
   const int chunk = (int)cdiv(p->n_tiles, 8);
   const unsigned grid = (unsigned)(chunk * 8);
   const size_t lds_a = (size_t)p->max_rows * 20 * 4, lds_b = (size_t)p->max_rows * 40 * 4;
   ARG_CHECK(lds_b <= 160 * 1024, "tile + halo rows exceed the LDS budget of the tiled VJP");
-  LAUNCH("k_vjp_tile_a", st, (k_vjp_tile_a<2><<<grid, VT, lds_a, st>>>(
-      (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
-      p->flags_p, W, L::layer(0), L::tp_layer(nl, false, 0), h, prb, w, work, out)));
-  LAUNCH("k_vjp_tile_b", st, (k_vjp_tile_b<2><<<grid, VT, lds_b, st>>>(
-      (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell, W,
-      L::layer(0), L::tp_layer(nl, false, 0), h, work, out)));
+#define VJP_ARGS_A (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, \
+                   p->ell, p->flags_p, W, L::layer(0), L::tp_layer(nl, false, 0), h, prb, w, work, out, rec
+#define VJP_ARGS_B (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, \
+                   p->ell, W, L::layer(0), L::tp_layer(nl, false, 0), h, work, out, rec
+  if (rec) {
+    LAUNCH("k_pgrad_tile_a", st, (k_vjp_tile_a<2, true><<<grid, VT, lds_a, st>>>(VJP_ARGS_A)));
+    LAUNCH("k_pgrad_tile_b", st, (k_vjp_tile_b<2, true><<<grid, VT, lds_b, st>>>(VJP_ARGS_B)));
+  } else {
+    LAUNCH("k_vjp_tile_a", st, (k_vjp_tile_a<2, false><<<grid, VT, lds_a, st>>>(VJP_ARGS_A)));
+    LAUNCH("k_vjp_tile_b", st, (k_vjp_tile_b<2, false><<<grid, VT, lds_b, st>>>(VJP_ARGS_B)));
+  }
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
+}
+
+// h, prb, w, out in PLAN order; work: (N, 40) floats for B.
+int psignn_f_tile_vjp(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* w,
+                      float* out, float* work, hipStream_t st) {
+  return tile_vjp_launch(p, W, nl, h, prb, w, out, work, nullptr, st);
+}
+// same, additionally filling the parameter-gradient records rec: (N, PGREC) floats (fgnn_pgrad.hip)
+int psignn_f_tile_vjp_rec(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* w,
+                          float* out, float* work, float* rec, hipStream_t st) {
+  ARG_CHECK(rec, "NULL record buffer");
+  return tile_vjp_launch(p, W, nl, h, prb, w, out, work, rec, st);
 }

@@ -186,6 +186,7 @@ class MeshPlan:
         self.ell_rows = int(nat.lib().psignn_plan_ell_rows(h))
         self.max_tile_rows = int(nat.lib().psignn_plan_max_tile_rows(h))
         self._work = None
+        self._pwork = None
 
     def export(self, name):
         which, dt = _EXPORT[name]
@@ -209,6 +210,12 @@ class MeshPlan:
             n = int(nat.lib().psignn_f_workspace_floats(self.handle))
             self._work = torch.empty(n, dtype=torch.float32, device=self.device)
         return self._work
+
+    def pgrad_workspace(self):
+        if self._pwork is None:
+            n = int(nat.lib().psignn_f_param_vjp_workspace_floats(self.handle))
+            self._pwork = torch.empty(n, dtype=torch.float32, device=self.device)
+        return self._pwork
 
     def permute(self, t, to_plan=True):
         """Rows of an (N, cols) float tensor between the caller's numbering and plan order."""
@@ -346,6 +353,31 @@ class FixedPointMap:
                       "psignn_f_vjp_p")
         return out
 
+    def param_vjp_p(self, Hp, Wp):
+        """(flat parameter gradient, Wp^T df/dh) at Hp, everything in plan order (tiled dirichlet plans).
+
+        The flat gradient follows the leading section of the packed weights; ``unpack_param_grads`` names it."""
+        if self._p is None:
+            self.fp(Hp)
+        _, prbp, _ = self._p
+        Hc, Wc = _f32c(Hp), _f32c(Wp)
+        l = nat.lib()
+        grad = torch.empty(int(l.psignn_param_grad_size(int(self.weights.mixed), self.weights.n_layers)),
+                           dtype=torch.float32, device=Hc.device)
+        out = torch.empty_like(Hc)
+        work = self.plan.pgrad_workspace()
+        with torch.cuda.device(Hc.device):
+            nat.check(l.psignn_f_param_vjp_p(self.plan.handle, nat.ptr(self.weights.flat), self.weights.n_layers,
+                                             nat.ptr(Hc), nat.ptr(prbp), nat.ptr(Wc), nat.ptr(grad), nat.ptr(out),
+                                             nat.ptr(work), nat.stream_ptr(Hc.device)), "psignn_f_param_vjp_p")
+        return grad, out
+
+    def param_vjp(self, H, Wv):
+        """What ``loss.backward()`` leaves in the ``deqdss.f`` parameters for new_H = f(H) with cotangent Wv
+        (dirichlet/psignn/model.py:203-225): ({name: grad}, Wv^T df/dH) in the caller's numbering."""
+        flat, outp = self.param_vjp_p(self.to_plan(H), self.to_plan(Wv))
+        return unpack_param_grads(flat, self.weights.n_layers, self.weights.mixed), self.from_plan(outp)
+
     def phi(self, H, which: int, layer: int = 0):
         """One aggregation: 0 Phi_to, 1 Phi_from, 2 Phi_neumann."""
         Hc = _f32c(H)
@@ -355,6 +387,104 @@ class FixedPointMap:
                                            layer, which, nat.ptr(Hc), nat.ptr(out), nat.ptr(self.plan.workspace()),
                                            nat.stream_ptr(Hc.device)), "psignn_phi")
         return out
+
+
+def unpack_param_grads(flat, n_layers=1, mixed=False):
+    """Name the entries of a flat parameter gradient (layout = leading section of ``pack_weights``)."""
+    if mixed or n_layers != 1:
+        raise nat.NativeError("parameter gradients are implemented for the single-layer dirichlet block")
+    p, cat, ein = 2, 3 * D + 2, 2 * D + 3
+    out, o = {}, 0
+
+    def take(name, *shape):
+        nonlocal o
+        n = 1
+        for k in shape:
+            n *= k
+        out[name] = flat[o:o + n].reshape(shape)
+        o += n
+    take("laynorm.weight", D)
+    take("laynorm.bias", D)
+    take("alpha.0.weight", 1, cat)
+    take("alpha.0.bias", 1)
+    o = 64
+    for phi in ("phi_to_list", "phi_from_list"):
+        take(f"{phi}.0.mlp.mlp.0.weight", D, ein)
+        take(f"{phi}.0.mlp.mlp.0.bias", D)
+        take(f"{phi}.0.mlp.mlp.2.weight", D, D)
+        take(f"{phi}.0.mlp.mlp.2.bias", D)
+    take("update_list.0.mlp.0.weight", D, cat)
+    take("update_list.0.mlp.0.bias", D)
+    take("update_list.0.mlp.2.weight", D, D)
+    take("update_list.0.mlp.2.bias", D)
+    return out
+
+
+def mlp2_backward(x, gy, w1, b1, w2, need_gx=True):
+    """Backward of ``mlp2``: (gx | None, gW1, gb1, gW2, gb2)."""
+    xc, gc = _f32c(x), _f32c(gy)
+    n, din = xc.shape
+    hid, dout = w1.shape[0], w2.shape[0]
+    l = nat.lib()
+    gx = torch.empty_like(xc) if need_gx else None
+    gflat = torch.empty(hid * din + hid + dout * hid + dout, dtype=torch.float32, device=xc.device)
+    work = torch.empty(int(l.psignn_mlp2_backward_workspace_floats(n)), dtype=torch.float32, device=xc.device)
+    with torch.cuda.device(xc.device):
+        nat.check(l.psignn_mlp2_backward(nat.ptr(xc), nat.ptr(gc), n, din, hid, dout, nat.ptr(_f32c(w1)),
+                                         nat.ptr(_f32c(b1)), nat.ptr(_f32c(w2)), nat.ptr(gx), nat.ptr(gflat),
+                                         nat.ptr(work), nat.stream_ptr(xc.device)), "psignn_mlp2_backward")
+    o1, o2, o3 = hid * din, hid * din + hid, hid * din + hid + dout * hid
+    return gx, gflat[:o1].reshape(hid, din), gflat[o1:o2], gflat[o2:o3].reshape(dout, hid), gflat[o3:]
+
+
+class _MLP2Fn(torch.autograd.Function):
+    """mlp2 with its HIP backward, for the training path (encoder / decoder terms of the loss)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        ctx.save_for_backward(x, w1, b1, w2)
+        return mlp2(x, w1, b1, w2, b2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w1, b1, w2 = ctx.saved_tensors
+        gx, g1, gb1, g2, gb2 = mlp2_backward(x, gy.contiguous(), w1, b1, w2, need_gx=ctx.needs_input_grad[0])
+        return gx, g1, gb1, g2, gb2
+
+
+def mlp2_autograd(x, w1, b1, w2, b2):
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (x, w1, b1, w2, b2)):
+        return _MLP2Fn.apply(x, w1, b1, w2, b2)
+    return mlp2(x, w1, b1, w2, b2)
+
+
+def residual_t(plan: "MeshPlan", a_ij, r):
+    """A^T r (backward of ``residual`` w.r.t. u); a_ij in the caller's edge order."""
+    rc, ac = _f32c(r).reshape(-1), _f32c(a_ij).reshape(-1)
+    if ac.numel() != plan.E:
+        raise nat.NativeError(f"a_ij has {ac.numel()} entries, the plan {plan.E} edges")
+    out = torch.empty_like(rc)
+    with torch.cuda.device(rc.device):
+        nat.check(nat.lib().psignn_residual_t(plan.handle, nat.ptr(ac), nat.ptr(rc), nat.ptr(out),
+                                              nat.stream_ptr(rc.device)), "psignn_residual_t")
+    return out.reshape(-1, 1)
+
+
+class _ResidualFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, y, plan, a_ij):
+        ctx.plan, ctx.a_ij = plan, a_ij
+        return residual(plan, u, y)
+
+    @staticmethod
+    def backward(ctx, gr):
+        return residual_t(ctx.plan, ctx.a_ij, gr.contiguous()), None, None, None
+
+
+def residual_autograd(plan, u, y, a_ij):
+    if torch.is_grad_enabled() and u.requires_grad:
+        return _ResidualFn.apply(u, y, plan, a_ij)
+    return residual(plan, u, y)
 
 
 def mlp2(x, w1, b1, w2, b2):

@@ -17,6 +17,8 @@ SpMV — runs in libpsignn_hip.so.  No torch_geometric / torch_sparse.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -48,7 +50,7 @@ class MLP(nn.Module):
 
     def forward(self, x):
         l0, l2 = self.mlp[0], self.mlp[2]
-        return engine.mlp2(x, l0.weight, l0.bias, l2.weight, l2.bias)
+        return engine.mlp2_autograd(x, l0.weight, l0.bias, l2.weight, l2.bias)
 
 
 class _Phi(nn.Module):
@@ -133,8 +135,49 @@ class Function(nn.Module):
         return self.bind(h_initial, batch)(h)
 
 
+class _DEQFn(torch.autograd.Function):
+    """new_H = f(H*) with H* = solver(f, H_init), differentiable the way the reference's training variant is
+    (dirichlet/psignn/model.py:184-225): the forward solve runs without a graph; backward replaces the incoming
+    gradient by the solution y of  y = J_f(H*)^T y + grad  (the reference's ``backward_hook``) and pushes y through
+    one application of f: parameter gradients from the HIP parameter-VJP kernels, and y on the Dirichlet rows for
+    ``H_init`` (those rows of f are copies of ``H_init``, model.py:298)."""
+
+    @staticmethod
+    def forward(ctx, H_init, deq, batch, names, *params):
+        cfg = deq.config_deq
+        H0 = H_init.detach()
+        fmap = deq.f.bind(H0, batch)
+        out_fw = cfg["solver"](fmap, H0, threshold=cfg["fw_thres"], eps=cfg["fw_tol"])
+        H_star = out_fw["result"]
+        deq.last_forward = out_fw
+        _log(deq.path_logs, "forward_iteration.csv", "\n{} \t {}".format(out_fw["lowest"], out_fw["nstep"]))
+        ctx.deq, ctx.batch, ctx.names, ctx.fmap = deq, batch, names, fmap
+        ctx.save_for_backward(H_star, H0)
+        return fmap(H_star)
+
+    @staticmethod
+    def backward(ctx, grad):
+        H_star, H0 = ctx.saved_tensors
+        deq = ctx.deq
+        out_bw = deq.implicit_backward(H_star, H0, ctx.batch, grad.contiguous())
+        deq.last_backward = out_bw
+        _log(deq.path_logs, "backward_iteration.csv", "\n{} \t {}".format(out_bw["lowest"], out_bw["nstep"]))
+        y = out_bw["result"]
+        grads, _ = ctx.fmap.param_vjp(H_star, y)
+        tags = ctx.batch.tags.reshape(y.shape[0], -1)
+        g_init = torch.where(tags[:, :1] == 1, y, torch.zeros_like(y))
+        return (g_init, None, None, None) + tuple(grads[n] for n in ctx.names)
+
+
+def _log(path_logs, name, line):
+    if path_logs:
+        with open(os.path.join(path_logs, name), "a") as f:
+            f.write(line)
+
+
 class DeepEquilibrium(nn.Module):
-    """Inference variant (tests/model_psignn.py:216-243): one solver call, returns the solver dict."""
+    """Inference variant (tests/model_psignn.py:216-243): one solver call, returns the solver dict; plus the
+    training variant's differentiable forward (dirichlet/psignn/model.py:184-243) as ``train_forward``."""
 
     def __init__(self, function=None, config_deq=None):
         super().__init__()
@@ -147,6 +190,29 @@ class DeepEquilibrium(nn.Module):
                                          threshold=self.config_deq["fw_thres"], eps=self.config_deq["fw_tol"])
 
     inference = forward  # dirichlet/psignn/model.py:245-253
+
+    def train_forward(self, H_init, batch, generator=None):
+        """(new_H_star, jacobian_loss) of the training variant.  With gradients enabled new_H_star carries the
+        implicit-function backward; without (validation) the spectral radius is logged like the reference does.
+        The Jacobian regulariser is returned as a value only (``jac_weight`` defaults to 0 in the reference,
+        utilities/utils.py:58; its second-order gradient is not implemented)."""
+        if torch.is_grad_enabled():
+            if self.f.mixed or self.f.n_layers != 1:
+                raise nat.NativeError("the training path is implemented for the single-layer dirichlet block")
+            named = list(self.f.named_parameters())
+            new_H = _DEQFn.apply(H_init, self, batch, tuple(n for n, _ in named), *[p for _, p in named])
+            H_star = self.last_forward["result"]
+        else:
+            out_fw = self.forward(H_init, batch)
+            self.last_forward = out_fw
+            H_star = out_fw["result"]
+            new_H = self.f.bind(H_init, batch)(H_star)
+        with torch.no_grad():
+            jac_loss = self.jac_loss_estimate(H_star, H_init.detach(), batch, vecs=1, generator=generator)
+            if not torch.is_grad_enabled() and self.path_logs:
+                _, sradius = self.power_method(H_star, H_init.detach(), batch, n_iters=150, generator=generator)
+                _log(self.path_logs, "spectral_radius.csv", "\n{}".format(sradius.item()))
+        return new_H, jac_loss
 
     # ---- adjoint side of the reference's training variant (dirichlet/psignn/model.py:204-241), on the VJP kernel
     def implicit_backward(self, H_star, H_init, batch, grad):
@@ -213,7 +279,7 @@ class _Base(nn.Module):
 
     def residual_loss(self, u, batch):
         """mean((A u - y)^2), A incl. the diagonal (model.py:157-167)."""
-        r = engine.residual(engine.plan_for(batch), u, batch.y)
+        r = engine.residual_autograd(engine.plan_for(batch), u, batch.y, batch.a_ij)
         return torch.mean(r ** 2)
 
     @torch.no_grad()
@@ -288,16 +354,38 @@ class ModelPSIGNNIterative(_Base):
 
 
 class ModelDEQDSS(_Base):
-    """Inference surface of dirichlet/psignn/model.py:28-167 (``forward`` diagnostics without the training-only
-    Jacobian regulariser / backward hook, ``inference``, ``iterative_inference``)."""
+    """dirichlet/psignn/model.py:28-167: ``forward`` (training: differentiable, implicit backward; eval: diagnostics),
+    ``inference``, ``iterative_inference``."""
 
-    @torch.no_grad()
     def forward(self, batch):
-        _, out = self._solve(batch)
-        h_final = out["result"]
-        u_final = self.autoencoder.decoder(h_final)
-        loss_dic = self._diagnostics(u_final, h_final, batch, "mse_dirichlet")
-        loss_dic["jacobian_loss"] = torch.zeros((), device=u_final.device)  # training-only term (model.py:207)
+        if self.training and torch.is_grad_enabled():
+            return self._train_forward(batch)
+        with torch.no_grad():  # validation branch of DeepEquilibrium.forward (model.py:227-241): one more f on H*
+            nat.require_cuda(batch.x, "batch.x")
+            h_initial = self.autoencoder.encoder(batch.x)
+            h_final, jacobian_loss = self.deqdss.train_forward(h_initial, batch)
+            u_final = self.autoencoder.decoder(h_final)
+            loss_dic = self._diagnostics(u_final, h_final, batch, "mse_dirichlet")
+            loss_dic["jacobian_loss"] = jacobian_loss
+            return u_final, loss_dic
+
+    def _train_forward(self, batch):
+        """dirichlet/psignn/model.py:58-99.  Every term carries the gradient it has in the reference: residual_loss
+        through decoder, implicit DEQ backward, f parameters and encoder; encoder_loss into the encoder;
+        autoencoder_loss into the decoder only (the encoder output is detached there)."""
+        nat.require_cuda(batch.x, "batch.x")
+        ae = self.autoencoder
+        h_initial = ae.encoder(batch.x)
+        h_final, jacobian_loss = self.deqdss.train_forward(h_initial, batch)
+        u_final = ae.decoder(h_final)
+        residual_loss = self.residual_loss(u_final, batch)
+        u_d, h_d = u_final.detach(), h_final.detach()
+        encoder_loss = self.mse_loss(ae.encoder(u_d), h_d)
+        autoencoder_loss = self.mse_loss(ae.decoder(ae.encoder(u_d).detach()), u_d)
+        idx = self._dirichlet_index(batch)
+        loss_dic = {"residual_loss": residual_loss, "jacobian_loss": jacobian_loss, "encoder_loss": encoder_loss,
+                    "autoencoder_loss": autoencoder_loss, "mse_loss": self.mse_loss(u_final, batch.sol),
+                    "mse_dirichlet": self.mse_loss(u_final[idx, :], batch.x[idx, :])}
         return u_final, loss_dic
 
     def iterative_inference(self, batch):

@@ -1,0 +1,204 @@
+"""Training loop with the reference's surface (dirichlet/psignn/training_class.py): ``TrainModel(config)`` with the
+same config keys, two Adam optimisers (DEQ block / autoencoder) with ReduceLROnPlateau, gradient clipping, the same
+loss combination, history dictionaries and checkpoint dictionary keys.
+
+What is different by design (MI355X-first):
+  * the model step is the HIP path (device Broyden forward, on-device adjoint solve, parameter-VJP kernels); there is
+    no ``torch_geometric.nn.DataParallel`` wrapper -- ``self.model`` is the module itself;
+  * data parallelism is one process per GPU: each rank steps through its own shard of the loader and the gradients
+    are averaged with ONE all-reduce of a flat buffer per step (1 444 floats; RCCL on GPUs, gloo in the CPU tests) --
+    the only collective of the training path;
+  * plotting (matplotlib figures of the reference) is not part of the path and is left out.
+"""
+from __future__ import annotations
+
+import os
+import time
+from math import ceil
+
+import torch
+import torch.distributed as dist
+
+from . import _native as nat
+
+_KEYS = ("loss", "residual_loss", "jacobian_loss", "encoder_loss", "autoencoder_loss", "mse_loss")
+
+
+def allreduce_mean_grads(params, group=None):
+    """Average ``p.grad`` over the ranks with a single all-reduce of one flat buffer.  No-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    ps = [p for p in params if p.grad is not None]
+    if not ps:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= dist.get_world_size(group)
+    o = 0
+    for p in ps:
+        n = p.grad.numel()
+        p.grad.copy_(flat[o:o + n].reshape(p.grad.shape))
+        o += n
+
+
+class TrainModel:
+    def __init__(self, config):
+        self.loader_train = config["loader_train"]
+        self.loader_val = config["loader_val"]
+        self.model = config["model"]
+        self.config_model = config["config_model"]
+        self.lr_deq, self.lr_ae = config["lr_deq"], config["lr_ae"]
+        self.sched_step_deq, self.sched_step_ae = config["sched_step_deq"], config["sched_step_ae"]
+        self.path_ckpt = config["path_ckpt"]
+        self.path_logs = self.config_model.get("path_logs")
+        self.min_loss_save = config["min_loss_save"]
+        self.max_epochs = config["max_epochs"]
+        self.gradient_clip = config["gradient_clip"]
+        self.sup_weight = config.get("sup_weight", 0.0)
+        self.jac_weight = config.get("jac_weight", 0.0)
+        if self.jac_weight != 0.0:
+            raise nat.NativeError("jac_weight != 0 needs the second-order gradient of the Jacobian regulariser, which "
+                                  "the HIP path does not implement (the reference's default is 0)")
+        self.training_time = 0
+        self.hist_train = {k: [] for k in _KEYS}
+        self.hist_val = {k: [] for k in _KEYS}
+        self.createOptimizerAndScheduler()
+
+    def createOptimizerAndScheduler(self):
+        self.opt_deq = torch.optim.Adam(self.model.deqdss.parameters(), lr=self.lr_deq)
+        self.sched_deq = torch.optim.lr_scheduler.ReduceLROnPlateau(self.opt_deq, mode="min", factor=self.sched_step_deq)
+        self.opt_ae = torch.optim.Adam(self.model.autoencoder.parameters(), lr=self.lr_ae)
+        self.sched_ae = torch.optim.lr_scheduler.ReduceLROnPlateau(self.opt_ae, mode="min", factor=self.sched_step_ae)
+
+    # ---- checkpoints: same dictionary keys as the reference ------------------------------------------------------
+    def checkpoint(self, epoch):
+        return {"epoch": epoch, "hyperparameters": self.config_model, "state_dict": self.model.state_dict(),
+                "hist_train": self.hist_train, "hist_val": self.hist_val, "opt_deq": self.opt_deq.state_dict(),
+                "opt_ae": self.opt_ae.state_dict(), "sched_deq": self.sched_deq.state_dict(),
+                "sched_ae": self.sched_ae.state_dict(), "training_time": self.training_time,
+                "min_loss_save": self.min_loss_save}
+
+    def save_model(self, state, dirName=None, model_name=None):
+        with open(os.path.join(dirName, "{}.pt".format(model_name)), mode="wb") as f:
+            torch.save(state, f)
+
+    def load_model(self, path):
+        """Resume from a checkpoint of this class or of the reference's (same keys).  Loaded with
+        ``weights_only=True``: tensors, plain containers and the solver function by name; nothing from the file runs."""
+        from .utilities import solver
+        fns = [getattr(solver, n) for n in ("broyden", "anderson", "forward_iteration", "newton")]
+        torch.serialization.add_safe_globals(fns + [(f, f"utilities.solver.{f.__name__}") for f in fns])
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        self.model.load_state_dict(ck["state_dict"])
+        self.opt_deq.load_state_dict(ck["opt_deq"])
+        self.opt_ae.load_state_dict(ck["opt_ae"])
+        self.sched_deq.load_state_dict(ck["sched_deq"])
+        self.sched_ae.load_state_dict(ck["sched_ae"])
+        self.min_loss_save = ck.get("min_loss_save", self.min_loss_save)
+        self.hist_train, self.hist_val = ck["hist_train"], ck["hist_val"]
+        self.training_time = ck["training_time"]
+
+    # ---- one optimisation step (training_class.py:146-166) ---------------------------------------------------------
+    def total_loss(self, loss_dic):
+        return (loss_dic["residual_loss"].mean() + self.jac_weight * loss_dic["jacobian_loss"].mean()
+                + loss_dic["encoder_loss"].mean() + loss_dic["autoencoder_loss"].mean())
+
+    def train_step(self, batch):
+        self.opt_ae.zero_grad()
+        self.opt_deq.zero_grad()
+        _, loss_dic = self.model(batch)
+        loss = self.total_loss(loss_dic)
+        loss.backward()
+        allreduce_mean_grads(self.model.parameters())
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.gradient_clip)
+        self.opt_deq.step()
+        self.opt_ae.step()
+        return loss, loss_dic
+
+    def _write(self, text):
+        if self.path_logs and self._rank() == 0:
+            with open(os.path.join(self.path_logs, "train_metrics.csv"), "a") as f:
+                f.write(text)
+
+    @staticmethod
+    def _rank():
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+    @staticmethod
+    def _mean_over_ranks(vals):
+        """Epoch statistics: mean over the ranks' shards (one small all-reduce per epoch)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return vals
+        t = torch.tensor(vals, dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t)
+        return (t / dist.get_world_size()).tolist()
+
+    def train_loop(self, current_epoch):
+        self.model.train()
+        n = len(self.loader_train)
+        cumul = dict.fromkeys(_KEYS, 0.0)
+        run = dict.fromkeys(_KEYS, 0.0)
+        cnt = 0
+        marks = {ceil(0.25 * n), ceil(0.5 * n), ceil(0.75 * n)}
+        for i, batch in enumerate(self.loader_train):
+            loss, loss_dic = self.train_step(batch)
+            vals = {"loss": loss.item(), **{k: loss_dic[k].mean().item() for k in _KEYS[1:]}}
+            for k in _KEYS:
+                cumul[k] += vals[k]
+                run[k] += vals[k]
+            cnt += 1
+            if i in marks:
+                self._write("\nEpoch {}, {:d}% \t Loss : {:.4e} \t Res : {:.4e} \t Jac : {:.4e} \t Enc : {:.4e} \t AEnc : {:.4e} "
+                            "\t MSE : {:.4e}".format(current_epoch, int(i * 100 / n), *[run[k] / cnt for k in _KEYS]))
+                run = dict.fromkeys(_KEYS, 0.0)
+                cnt = 0
+        means = self._mean_over_ranks([cumul[k] / max(n, 1) for k in _KEYS])
+        for k, v in zip(_KEYS, means):
+            self.hist_train[k].append(v)
+        self._write("\nTraining Epoch {} : \t Train : {:.5e} \t Res : {:.5e} \t Jac : {:.5e} \t Enc : {:.5e} \t AE : {:.5e} "
+                    "\t MSE : {:.5e}".format(current_epoch, *means))
+
+    def validation_loop(self, current_epoch):
+        self.model.eval()
+        n = len(self.loader_val)
+        cumul = dict.fromkeys(_KEYS, 0.0)
+        with torch.no_grad():
+            for batch in self.loader_val:
+                _, loss_dic = self.model(batch)
+                cumul["loss"] += self.total_loss(loss_dic).item()
+                for k in _KEYS[1:]:
+                    cumul[k] += loss_dic[k].mean().item()
+        means = self._mean_over_ranks([cumul[k] / max(n, 1) for k in _KEYS])
+        for k, v in zip(_KEYS, means):
+            self.hist_val[k].append(v)
+        self._write("\nValidation Epoch {} : \t Train : {:.5e} \t Res : {:.5e} \t Jac : {:.5e} \t Enc : {:.5e} \t AE : {:.5e} "
+                    "\t MSE : {:.5e}".format(current_epoch, *means))
+
+    def train_model(self):
+        for epoch in range(self.max_epochs):
+            t0 = time.time()
+            self.train_loop(epoch)
+            self.validation_loop(epoch)
+            self.sched_deq.step(self.hist_val["loss"][-1])
+            self.sched_ae.step(self.hist_val["loss"][-1])
+            self.training_time += time.time() - t0
+            if self.opt_deq.param_groups[0]["lr"] <= 1.e-7 and self.opt_ae.param_groups[0]["lr"] <= 1.e-7:
+                self._write("\nTraining exit because both learning rates too low !")
+                break
+            saved = False
+            if self._rank() == 0 and self.path_ckpt:
+                ck = self.checkpoint(epoch)
+                self.save_model(ck, dirName=self.path_ckpt, model_name="running_model")
+                if self.hist_val["residual_loss"][-1] <= self.min_loss_save:
+                    self.min_loss_save = self.hist_val["residual_loss"][-1]
+                    ck["min_loss_save"] = self.min_loss_save
+                    self.save_model(ck, dirName=self.path_ckpt, model_name="best_model")
+                    saved = True
+            self._write("\nTraining Epoch {} finished, took current epoch {:.2f}s, cumulative time {:.2f}s".format(
+                epoch, time.time() - t0, self.training_time))
+            self._write("\nCurrent Learning rate DEQ : {}".format(self.opt_deq.param_groups[0]["lr"]))
+            self._write("\nCurrent Learning rate AUTOENC : {}".format(self.opt_ae.param_groups[0]["lr"]))
+            if saved:
+                self._write("\nMODEL SAVED")

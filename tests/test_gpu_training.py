@@ -1,0 +1,167 @@
+"""GPU parity of the training path: parameter-VJP kernels, MLP / residual backward, one full training
+step and the trainer loop, against autograd on the CPU oracle's restatement of the reference
+(dirichlet/psignn/model.py:58-99,184-225; training_class.py:146-166).
+
+Tolerances: a single parameter-VJP (no solve involved) <= 2e-5 relative to each tensor's own norm (fp32 sums over
+N nodes / E' edges, re-associated); gradients of a whole training step <= 5e-3 (measured 1e-3 .. 4e-3) -- both sides
+stop their forward and adjoint Broyden solves at rel <= 1e-7, and with rho(J) ~ 0.99 the adjoint system amplifies what
+is left of either solve by ~1/(1 - rho).  Tensors whose gradient is ~0 (saturated alpha gate) are compared on the scale of
+the largest gradient."""
+import os
+
+import pytest
+import torch
+
+from conftest import load_case, load_weights, pkg, rel_l2
+from oracle import psignn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp(got, want, tol, floor_scale):
+    """max over tensors of ||got - want|| / max(||want||, 1e-4 * floor_scale)"""
+    worst, name = 0.0, None
+    for k, w in want.items():
+        e = float((got[k].detach().cpu().double() - w.double()).norm()) / max(float(w.double().norm()), 1e-4 * floor_scale)
+        if e > worst:
+            worst, name = e, k
+    assert worst < tol, (name, worst)
+    return worst
+
+
+def _bind(name, dev):
+    g, mesh = load_case(name)
+    sd = load_weights("dirichlet")
+    eng = pkg("engine")
+    md = mesh.to(dev)
+    w = eng.PackedWeights(sd, dev)
+    h0 = torch.from_numpy(g["h0"]).to(dev)
+    fmap = eng.FixedPointMap(eng.plan_for(md), w, h0, md.prb_data, None)
+    return g, mesh, md, sd, fmap
+
+
+@pytest.mark.parametrize("name", ["original_dirichlet_s0", "hex13_dirichlet_s0", "hex26_dirichlet_s0"])
+def test_param_vjp_parity(name, dev):
+    g, mesh, md, sd, fmap = _bind(name, dev)
+    h = torch.from_numpy(g["f1"])
+    v = torch.randn(h.shape, generator=torch.Generator().manual_seed(21))
+    grads, out_h = fmap.param_vjp(h.to(dev), v.to(dev))
+    want, want_h, want_h0 = orc.function_param_vjp(sd, h, torch.from_numpy(g["h0"]), mesh, v)
+    assert set(grads) == set(want)
+    scale = max(float(t.norm()) for t in want.values())
+    _cmp(grads, want, 2e-5, scale)
+    assert rel_l2(out_h, want_h) < 2e-5
+    # same call again: bitwise identical (fixed reduction order, no atomics)
+    g2, _ = fmap.param_vjp(h.to(dev), v.to(dev))
+    assert all(torch.equal(grads[k], g2[k]) for k in grads)
+    # gradient w.r.t. H_init = the cotangent on the Dirichlet rows (model.py:298)
+    mask = (mesh.tags.reshape(h.shape[0], -1)[:, :1] == 1)
+    assert torch.equal(want_h0, torch.where(mask, v, torch.zeros_like(v)))
+
+
+def test_param_vjp_other_tile_sizes(dev):
+    g, mesh, md, sd, fmap = _bind("hex26_dirichlet_s0", dev)
+    eng = pkg("engine")
+    h = torch.from_numpy(g["f1"]).to(dev)
+    v = torch.randn(h.shape, generator=torch.Generator().manual_seed(22)).to(dev)
+    base, _ = fmap.param_vjp(h, v)
+    scale = max(float(t.norm()) for t in base.values())
+    for tt in (32, 100):
+        fm = eng.FixedPointMap(eng.MeshPlan(md, tile_target=tt), fmap.weights, fmap.h0, md.prb_data, None)
+        got, _ = fm.param_vjp(h, v)
+        _cmp(got, {k: t.cpu() for k, t in base.items()}, 1e-5, scale)
+    flat = eng.FixedPointMap(eng.MeshPlan(md, tile_target=-1), fmap.weights, fmap.h0, md.prb_data, None)
+    with pytest.raises(pkg("_native").NativeError):
+        flat.param_vjp(h, v)   # untiled plans: no silent fallback
+
+
+@pytest.mark.parametrize("dims", [(1, 10, 10), (10, 10, 1), (3, 7, 5)])
+def test_mlp2_backward(dims, dev):
+    eng = pkg("engine")
+    din, hid, dout = dims
+    gen = torch.Generator().manual_seed(3)
+    n = 1237
+    x = torch.randn(n, din, generator=gen)
+    w1, b1 = torch.randn(hid, din, generator=gen), torch.randn(hid, generator=gen)
+    w2, b2 = torch.randn(dout, hid, generator=gen), torch.randn(dout, generator=gen)
+    gy = torch.randn(n, dout, generator=gen)
+    leaves = [t.clone().double().requires_grad_() for t in (x, w1, b1, w2, b2)]
+    y = torch.relu(leaves[0] @ leaves[1].t() + leaves[2]) @ leaves[3].t() + leaves[4]
+    want = torch.autograd.grad(y, leaves, gy.double())
+    dl = [t.to(dev).requires_grad_() for t in (x, w1, b1, w2, b2)]
+    out = eng.mlp2_autograd(*dl)
+    assert rel_l2(out, y.detach()) < 1e-6
+    got = torch.autograd.grad(out, dl, gy.to(dev))
+    for a, b in zip(got, want):
+        assert rel_l2(a, b) < 1e-5
+
+
+def test_residual_backward(dev):
+    g, mesh, md, sd, fmap = _bind("hex13_dirichlet_s0", dev)
+    eng = pkg("engine")
+    u = torch.randn(mesh.x.shape, generator=torch.Generator().manual_seed(4))
+    uc = u.clone().requires_grad_()
+    orc.residual_loss(uc, mesh).backward()
+    ud = u.to(dev).requires_grad_()
+    r = eng.residual_autograd(fmap.plan, ud, md.y, md.a_ij)
+    torch.mean(r ** 2).backward()
+    assert rel_l2(ud.grad, uc.grad) < 1e-5
+
+
+def _model(sd, dev, **kw):
+    solver = pkg("utilities.solver")
+    cfg = dict(latent_dim=10, n_layers=1, solver=solver.broyden, fw_tol=1e-6, fw_thres=400, bw_tol=1e-7, bw_thres=400)
+    cfg.update(kw)
+    net = pkg("model_psignn").ModelDEQDSS(cfg)
+    net.load_state_dict(sd)
+    return net.to(dev)
+
+
+@pytest.mark.parametrize("name", ["hex13_dirichlet_s0", "original_dirichlet_s0"])
+def test_training_step_gradients(name, dev):
+    """loss.backward() through the HIP model vs the oracle's restated training step: losses and all 24 gradients."""
+    g, mesh = load_case(name)
+    sd = load_weights("dirichlet")
+    net = _model(sd, dev, fw_tol=1e-7, fw_thres=600).train()
+    md = mesh.to(dev)
+    u, ld = net(md)
+    loss = ld["residual_loss"] + ld["encoder_loss"] + ld["autoencoder_loss"]
+    loss.backward()
+    wl, wld, wg, fw, bw = orc.training_step(sd, mesh, fw_tol=1e-7, fw_thres=600, bw_tol=1e-7, bw_thres=400)
+    print("loss", float(loss), float(wl), {k: (float(ld[k]), float(wld[k])) for k in wld})
+    assert abs(float(loss) - float(wl)) < 5e-3 * float(wl)
+    for k in ("residual_loss", "encoder_loss", "autoencoder_loss", "mse_loss", "mse_dirichlet"):
+        assert abs(float(ld[k]) - float(wld[k])) < 5e-3 * abs(float(wld[k])) + 1e-9, k
+    assert net.deqdss.last_backward["lowest"] < 1e-7 and bw["lowest"] < 1e-7
+    got = {k: p.grad for k, p in net.named_parameters()}
+    assert all(v is not None for v in got.values())
+    scale = max(float(t.norm()) for t in wg.values())
+    print("worst gradient error", _cmp(got, wg, 5e-3, scale))
+
+
+def test_trainer_steps_and_checkpoint(dev, tmp_path):
+    """TrainModel (training_class.py surface): a few optimisation steps on two meshes lower the training loss;
+    checkpoints carry the reference's keys and resume."""
+    TrainModel = pkg("training_class").TrainModel
+    sd = load_weights("dirichlet")
+    meshes = [load_case(n)[1].to(dev) for n in ("hex13_dirichlet_s0", "original_dirichlet_s0")]
+    net = _model(sd, dev, fw_tol=1e-5, fw_thres=300, bw_tol=1e-6, bw_thres=300, path_logs=str(tmp_path))
+    cfg = dict(loader_train=meshes, loader_val=meshes[:1], model=net, config_model=net.config, lr_deq=1e-4, lr_ae=1e-4,
+               sched_step_deq=0.5, sched_step_ae=0.5, path_ckpt=str(tmp_path), min_loss_save=1e9, max_epochs=3,
+               gradient_clip=1e-2, sup_weight=0.0, jac_weight=0.0)
+    tr = TrainModel(cfg)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    tr.train_model()
+    assert len(tr.hist_train["loss"]) == 3 and len(tr.hist_val["loss"]) == 3
+    assert all(torch.isfinite(torch.tensor(tr.hist_train["loss"])))
+    assert tr.hist_train["loss"][-1] < tr.hist_train["loss"][0]
+    assert any(not torch.equal(before[k], v) for k, v in net.state_dict().items())
+    for f in ("running_model.pt", "best_model.pt", "train_metrics.csv", "forward_iteration.csv", "backward_iteration.csv",
+              "spectral_radius.csv"):
+        assert os.path.exists(tmp_path / f), f
+    tr2 = TrainModel(dict(cfg, model=_model(sd, dev)))
+    tr2.load_model(str(tmp_path / "running_model.pt"))
+    assert tr2.hist_train == tr.hist_train
+    assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(tr2.model.state_dict().values(), net.state_dict().values()))
+    with pytest.raises(pkg("_native").NativeError):
+        TrainModel(dict(cfg, jac_weight=0.1))

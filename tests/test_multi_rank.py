@@ -66,3 +66,36 @@ def test_two_ranks_gloo():
     assert abs(mean0["residual_loss"] - want) < 1e-6 and mean0 == mean1
     assert abs(mean0["mse_loss"] - 0.5) < 1e-6
     assert t0 == t1 == 0.2  # max over ranks
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tc = pkg("training_class")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 1))   # same init on both ranks
+    for i, p in enumerate(net.parameters()):
+        p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
+    tc.allreduce_mean_grads(net.parameters())
+    stats = tc.TrainModel._mean_over_ranks([float(rank), 10.0 * (rank + 1)])
+    q.put((rank, [float(p.grad.flatten()[0]) for p in net.parameters()], stats))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_two_ranks_gloo():
+    """The training path's only collective: one flat all-reduce of the gradients per step (mean over ranks)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, s0), (_, g1, s1) = res
+    assert g0 == g1 == [1.5 * (i + 1) for i in range(4)]
+    assert s0 == s1 == [0.5, 15.0]
