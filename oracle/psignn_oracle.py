@@ -390,3 +390,40 @@ def training_step(sd, batch, solver=broyden, fw_tol=1e-5, fw_thres=500, bw_tol=1
     loss.backward()
     grads = {k: (t.grad if t.grad is not None else torch.zeros_like(t)) for k, t in p.items()}
     return loss.detach(), {k: v.detach() for k, v in loss_dic.items()}, grads, out_fw, state.get("out_bw")
+
+
+# --------------------------------------------------------------------------------------
+# DS-GPS: the unrolled recurrent baseline (dirichlet/dsgps/model.py:28-163), SURVEY §8f-4
+# --------------------------------------------------------------------------------------
+def dsgps_step(sd, h, h0, batch):
+    """One update of ``ModelDSGPS.inference`` (dirichlet/dsgps/model.py:141-155): the same two message passes as
+    PSI-GNN, then a GRU-style node update with three Linear(32, 10) gates; Dirichlet rows <- H['0'] rows."""
+    mess_to = phi(sd, "phi_to", h, batch.edge_index, batch.edge_attr, "source_to_target")
+    mess_from = phi(sd, "phi_from", h, batch.edge_index, batch.edge_attr, "target_to_source")
+    cat = torch.cat([h, mess_to, mess_from, batch.prb_data], dim=1)
+    alpha = torch.sigmoid(F.linear(cat, sd["z_k.mlp.0.weight"], sd["z_k.mlp.0.bias"]))
+    reset = torch.sigmoid(F.linear(cat, sd["r_k.mlp.0.weight"], sd["r_k.mlp.0.bias"]))
+    cat2 = torch.cat([reset * h, mess_to, mess_from, batch.prb_data], dim=1)
+    corr = torch.tanh(F.linear(cat2, sd["correction.mlp.0.weight"], sd["correction.mlp.0.bias"]))
+    h_next = h + alpha * corr
+    idx_d = torch.where(batch.tags == 1)[0]
+    h_next[idx_d, :] = h0[idx_d, :]
+    return h_next
+
+
+def dsgps_inference(sd, batch, k, trace=False):
+    """``ModelDSGPS.inference`` (model.py:130-163): U_k = decoder(H_k) after k updates from H_0 = encoder(x).
+    With ``trace`` also the per-step diagnostics ``forward`` records (model.py:64-66,93-97,113): residual / mse of
+    every decoded iterate."""
+    with torch.no_grad():
+        h0 = encoder(sd, batch.x)
+        h = h0
+        res, mse = [float(residual_loss(batch.x, batch))], [float(F.mse_loss(batch.x, batch.sol))]
+        for _ in range(k):
+            h = dsgps_step(sd, h, h0, batch)
+            if trace:
+                u = decoder(sd, h)
+                res.append(float(residual_loss(u, batch)))
+                mse.append(float(F.mse_loss(u, batch.sol)))
+        u = decoder(sd, h)
+    return (u, h, res, mse) if trace else (u, h)

@@ -1,0 +1,96 @@
+// Device helpers shared by the tile kernels (fgnn_tile.hip, dsgps_tile.hip): packed-fp32 matvecs on the transposed
+// weight blocks and the pair-merged slot walk of one edge direction (gfx950).
+#pragma once
+#include "fgnn_common.h"
+
+#define SLOT_IN 0x10000u
+#define SLOT_OUT 0x20000u
+
+// Packed fp32: CDNA issues one VALU instruction per wave every 4 cycles; v_pk_fma_f32 / v_pk_add_f32 carry two
+// floats per lane in that slot, so the FP32 peak (and this kernel, which is VALU-issue bound) needs them.  All
+// matrices are read from the transposed weight section ([in k][out o], o fastest): the outputs (2p, 2p+1) of one
+// input k sit in one SGPR pair.  Each output is still the same k-ordered fma chain as in fgnn.hip.
+// Workgroup = 4 waves = TILE_MAX lanes.  (A fifth wave that only helps with the halo rows of stage 1 was tried:
+// 79 us instead of 67 us per 1M-node evaluation -- it costs a wave slot per workgroup for the whole residency.)
+#define TILE_THREADS 256
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
+
+// acc[p] += WT[k][2p..2p+1] * x[k],  p < 5, k < K
+template <int K>
+__device__ __forceinline__ void mv2(const float* __restrict__ WT, const float* x, v2f* acc) {
+  const v2f* w = reinterpret_cast<const v2f*>(WT);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const v2f xs = splat(x[k]);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) acc[p] = __builtin_elementwise_fma(w[k * 5 + p], xs, acc[p]);
+  }
+}
+__device__ __forceinline__ void ld5(const float* __restrict__ p, v2f* r) {  // 10 wave-uniform floats (8-byte aligned)
+  const v2f* q = reinterpret_cast<const v2f*>(p);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) r[i] = q[i];
+}
+
+// One direction of the neighbour sum for this lane's node:
+//   S[o] += relu(Pi[o] + row[COL + o] + AT[:, o] . (a0, a1, a2))   over the slots that carry `MASK`
+// (AT = W1[:, 20:23]^T; for in-edges its first two rows are stored negated, because an in-edge's attr is the
+// mirror (-a0, -a1, a2) of the slot's attr).  The two directions are separate passes on purpose: one pass needs
+// 30 wave-uniform weights, which stay in SGPRs across the loop; with 60 the compiler re-issues the scalar loads
+// and their waits in every iteration.  The second pass re-reads the 16-byte slots from L1/L2.
+template <int RS, int COL, unsigned MASK>
+__device__ __forceinline__ float edge_pass(const uint4* __restrict__ slots, int nslots, const float* __restrict__ lds,
+                                           const float* __restrict__ AT, const v2f* Pi, v2f* S) {
+  float deg = 0.f;
+  v2f wa[15];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) wa[i] = reinterpret_cast<const v2f*>(AT)[i];
+  auto one = [&](const uint4 s) {
+    const unsigned w = s.x;
+    if ((w & 0xFFFFu) != ELL_EMPTY && (w & MASK)) {
+      const v2f a0 = splat(__uint_as_float(s.y)), a1 = splat(__uint_as_float(s.z)), a2 = splat(__uint_as_float(s.w));
+      const float* row = lds + (int)(w & 0xFFFFu) * RS + COL;
+      v2f pj[5];
+      if (COL % 4 == 0) {  // 16-byte aligned start: b128, b128, b64
+        float4 v0 = reinterpret_cast<const float4*>(row)[0], v1 = reinterpret_cast<const float4*>(row)[1];
+        float2 v2 = reinterpret_cast<const float2*>(row)[4];
+        pj[0] = (v2f){v0.x, v0.y}; pj[1] = (v2f){v0.z, v0.w}; pj[2] = (v2f){v1.x, v1.y}; pj[3] = (v2f){v1.z, v1.w};
+        pj[4] = (v2f){v2.x, v2.y};
+      } else {             // start at 8 mod 16: b64, b128, b128
+        float2 v0 = reinterpret_cast<const float2*>(row)[0];
+        float4 v1 = reinterpret_cast<const float4*>(row + 2)[0], v2 = reinterpret_cast<const float4*>(row + 2)[1];
+        pj[0] = (v2f){v0.x, v0.y}; pj[1] = (v2f){v1.x, v1.y}; pj[2] = (v2f){v1.z, v1.w}; pj[3] = (v2f){v2.x, v2.y};
+        pj[4] = (v2f){v2.z, v2.w};
+      }
+      deg += 1.f;
+      // five independent chains, written stage by stage so that dependent packed ops are never back to back
+      v2f z[5];
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = Pi[p] + pj[p];
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[p], a0, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[5 + p], a1, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[10 + p], a2, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) S[p] += __builtin_elementwise_max(z[p], splat(0.f));
+    }
+  };
+  // software pipeline, distance 2: the 16-byte slot loads are unconditional (index clamped, never branched
+  // on) so the compiler keeps them whole and places their waits one iteration later
+  if (nslots <= 0) return deg;
+  uint4 c0 = slots[0];
+  uint4 c1 = slots[(int64_t)min(1, nslots - 1) * 64];
+  for (int r = 0; r < nslots; ++r) {
+    const uint4 nx = slots[(int64_t)min(r + 2, nslots - 1) * 64];
+    one(c0);
+    c0 = c1;
+    c1 = nx;
+  }
+  return deg;
+}
+

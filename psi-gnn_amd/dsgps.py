@@ -1,0 +1,97 @@
+"""DS-GPS, the reference's unrolled recurrent baseline (dirichlet/dsgps/model.py:28-176), on the HIP tile kernels.
+
+``ModelDSGPS(config)`` takes the reference's config (``latent_dim, k, alpha, gamma, path_logs``), has the reference's
+module tree -- so ``load_state_dict(ckpt["state_dict"])`` of ``dirichlet/dsgps/results/**/best_model.pt`` works
+unchanged -- and the reference's two entry points:
+
+* ``inference(batch) -> U_k``                                   (model.py:130-163)
+* ``forward(batch) -> (U, loss_dic)``: every decoded iterate ``U['0'..'k']`` and the per-step loss dictionaries
+  (``residual_loss, encoder_loss, autoencoder_loss, mse_dirichlet, mse_loss`` keyed '0'..'k', ``train_loss``) as
+  diagnostics (model.py:48-128).  Back-propagation through the k unrolled steps (training DS-GPS) is not implemented:
+  ``forward`` runs without a graph.
+
+Same gather -> edge MLP -> segment-sum kernels as PSI-GNN's f; k launches back to back, no solver.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _native as nat
+from . import engine
+from .model_psignn import MLP, Autoencoder, Phi_from, Phi_to, initialize_weights_xavier
+
+
+class MLPActivation(nn.Module):
+    """Linear + activation (dirichlet/dsgps/model.py:209-225); single layer, as every instance in the reference."""
+
+    def __init__(self, hidden_channels=None, activation=None):
+        super().__init__()
+        if len(hidden_channels) != 2:
+            raise nat.NativeError("the HIP path implements the reference's single-layer gate blocks only")
+        self.mlp = nn.Sequential(nn.Linear(hidden_channels[0], hidden_channels[1]), activation).apply(initialize_weights_xavier)
+
+
+class ModelDSGPS(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = dict(config)
+        d = self.config["latent_dim"]
+        if d != engine.D:
+            raise nat.NativeError(f"HIP kernels are built for latent_dim = {engine.D}")
+        self.laynorm = nn.LayerNorm(d)   # declared (and checkpointed) by the reference, unused in its forward
+        self.phi_to = Phi_to([2 * d + 3, d, d], nn.ReLU())
+        self.phi_from = Phi_from([2 * d + 3, d, d], nn.ReLU())
+        self.z_k = MLPActivation([3 * d + 2, d], nn.Sigmoid())
+        self.r_k = MLPActivation([3 * d + 2, d], nn.Sigmoid())
+        self.correction = MLPActivation([3 * d + 2, d], nn.Tanh())
+        self.autoencoder = Autoencoder([1, d, d], nn.ReLU())
+        self.mse_loss = nn.MSELoss()
+        self._packed, self._packed_key = None, None
+
+    def packed(self, device):
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed_key != key:
+            self._packed = engine.pack_dsgps(self.state_dict(), device)
+            self._packed_key = key
+        return self._packed
+
+    def residual_loss(self, u, batch):
+        r = engine.residual(engine.plan_for(batch), u, batch.y)
+        return torch.mean(r ** 2)
+
+    @torch.no_grad()
+    def inference(self, batch):
+        nat.require_cuda(batch.x, "batch.x")
+        h0 = self.autoencoder.encoder(batch.x)
+        hk = engine.dsgps_forward(engine.plan_for(batch), self.packed(h0.device), h0, batch.prb_data, self.config["k"])
+        return self.autoencoder.decoder(hk)
+
+    @torch.no_grad()
+    def forward(self, batch):
+        nat.require_cuda(batch.x, "batch.x")
+        ae, k, gamma = self.autoencoder, self.config["k"], self.config["gamma"]
+        plan = engine.plan_for(batch)
+        w = self.packed(batch.x.device)
+        idx = torch.where(batch.tags.reshape(batch.tags.shape[0], -1)[:, 0] == 1)[0]
+        U = {"0": batch.x}
+        res, mse = {"0": self.residual_loss(batch.x, batch)}, {"0": self.mse_loss(batch.x, batch.sol)}
+        enc, aenc, msd = {}, {}, {}
+        h0 = ae.encoder(batch.x)
+        h0p, prbp = plan.permute(h0, True), plan.permute(batch.prb_data, True)
+        hp = h0p
+        total = None
+        for t in range(k):
+            hp = engine.dsgps_step_p(plan, w, hp, h0p, prbp)
+            h = plan.permute(hp, False)
+            u = ae.decoder(h)
+            s = str(t + 1)
+            U[s] = u
+            res[s], mse[s] = self.residual_loss(u, batch), self.mse_loss(u, batch.sol)
+            enc[s] = self.mse_loss(ae(h, sens="latent"), h)
+            aenc[s] = self.mse_loss(ae(u, sens="physics"), u)
+            msd[s] = self.mse_loss(u[idx, :], batch.sol[idx, :])
+            term = res[s] * gamma ** (k - t - 1) + enc[s] + aenc[s]
+            total = term if total is None else total + term
+        return U, {"train_loss": total, "residual_loss": res, "encoder_loss": enc, "autoencoder_loss": aenc,
+                   "mse_dirichlet": msd, "mse_loss": mse}

@@ -389,6 +389,50 @@ class FixedPointMap:
         return out
 
 
+def pack_dsgps(sd, device=None) -> torch.Tensor:
+    """Flat weight buffer of the DS-GPS kernels from a ``ModelDSGPS`` state_dict (dirichlet/dsgps/model.py:35-45;
+    layout in csrc/dsgps_tile.hip): every matrix transposed to [in k][out o]."""
+    m = lambda k: sd[k].detach().to("cpu", torch.float32)
+    if m("phi_to.mlp.mlp.0.weight").shape != (D, 2 * D + 3) or m("z_k.mlp.0.weight").shape != (D, 3 * D + 2):
+        raise nat.NativeError("DS-GPS kernels are built for latent_dim = 10, 3 edge features, 2 problem features")
+    t = lambda a: a.t().contiguous().reshape(-1)
+    Wt, Wf = m("phi_to.mlp.mlp.0.weight"), m("phi_from.mlp.mlp.0.weight")
+    mir = torch.tensor([-1.0, -1.0, 1.0])[:, None]
+    parts = [t(Wt[:, D:2 * D]), t(Wf[:, D:2 * D]), t(Wt[:, :D]), t(Wf[:, :D]),
+             (Wt[:, 2 * D:].t() * mir).reshape(-1), t(Wf[:, 2 * D:]),
+             m("phi_to.mlp.mlp.0.bias"), m("phi_from.mlp.mlp.0.bias"),
+             t(m("phi_to.mlp.mlp.2.weight")), m("phi_to.mlp.mlp.2.bias"),
+             t(m("phi_from.mlp.mlp.2.weight")), m("phi_from.mlp.mlp.2.bias")]
+    for g in ("z_k", "r_k", "correction"):
+        parts += [t(m(f"{g}.mlp.0.weight")), m(f"{g}.mlp.0.bias")]
+    flat = torch.cat([p.reshape(-1) for p in parts]).contiguous()
+    if flat.numel() != int(nat.lib().psignn_dsgps_weights_size()):
+        raise nat.NativeError(f"packed DS-GPS weight length {flat.numel()} != native layout")
+    return flat if device is None else flat.to(device)
+
+
+def dsgps_forward(plan: "MeshPlan", wflat, h0, prb, k: int):
+    """H_k of ``ModelDSGPS.inference`` (model.py:141-155): k recurrent updates from the encoder state h0."""
+    nat.require_cuda(h0, "h0")
+    hc, pc = _f32c(h0), _f32c(prb)
+    out = torch.empty_like(hc)
+    work = torch.empty(4 * plan.N * D, dtype=torch.float32, device=hc.device)
+    with torch.cuda.device(hc.device):
+        nat.check(nat.lib().psignn_dsgps_forward(plan.handle, nat.ptr(wflat), int(k), nat.ptr(hc), nat.ptr(pc),
+                                                 nat.ptr(out), nat.ptr(work), nat.stream_ptr(hc.device)),
+                  "psignn_dsgps_forward")
+    return out
+
+
+def dsgps_step_p(plan: "MeshPlan", wflat, hp, h0p, prbp):
+    """One DS-GPS update, node tensors in plan order."""
+    out = torch.empty_like(hp)
+    with torch.cuda.device(hp.device):
+        nat.check(nat.lib().psignn_dsgps_step_p(plan.handle, nat.ptr(wflat), nat.ptr(_f32c(hp)), nat.ptr(h0p), nat.ptr(prbp),
+                                                nat.ptr(out), nat.stream_ptr(hp.device)), "psignn_dsgps_step_p")
+    return out
+
+
 def unpack_param_grads(flat, n_layers=1, mixed=False):
     """Name the entries of a flat parameter gradient (layout = leading section of ``pack_weights``)."""
     if mixed or n_layers != 1:

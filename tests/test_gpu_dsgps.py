@@ -1,0 +1,79 @@
+"""GPU parity of the DS-GPS baseline (dirichlet/dsgps/model.py:28-176) with the reference's trained
+checkpoint (30 steps, gamma 0.9): HIP tile kernels vs the CPU oracle and the committed golden vectors.
+Tolerance: k = 30 recurrent fp32 steps, each re-associated like f (<= 2e-6 per step) -> <= 1e-5 rel-L2 on H_k / U_k."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_case, pkg, rel_l2
+from oracle import psignn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(dev, k=None):
+    w = np.load(os.path.join(GOLDEN, "weights_dsgps.npz"))
+    sd = {n: torch.from_numpy(w[n]) for n in w.files if n != "k"}
+    net = pkg("dsgps").ModelDSGPS(dict(latent_dim=10, k=int(w["k"]) if k is None else k, alpha=1e-3, gamma=0.9, path_logs=None))
+    net.load_state_dict(sd)
+    return sd, net.to(dev).eval()
+
+
+@pytest.mark.parametrize("name", ["original_dirichlet_s0", "hex13_dirichlet_s0", "hex26_dirichlet_s0"])
+def test_dsgps_inference_parity(name, dev):
+    sd, net = _net(dev)
+    _, mesh = load_case(name)
+    g = np.load(os.path.join(GOLDEN, f"dsgps_{name}.npz"))
+    md = mesh.to(dev)
+    u = net.inference(md)
+    assert u.shape == (mesh.num_nodes, 1) and u.is_cuda
+    assert rel_l2(u, g["u_k"]) < 1e-5 and rel_l2(u, g["u_k64"]) < 1e-5
+    eng = pkg("engine")
+    h0 = net.autoencoder.encoder(md.x)
+    w = net.packed(dev)
+    plan = eng.plan_for(md)
+    assert plan.tiled
+    # a single update against the oracle and the golden vector, the whole recurrence against fp32 and fp64 goldens
+    assert rel_l2(eng.dsgps_forward(plan, w, h0, md.prb_data, 1), g["h_1"]) < 2e-6
+    hk = eng.dsgps_forward(plan, w, h0, md.prb_data, net.config["k"])
+    assert rel_l2(hk, g["h_k"]) < 1e-5 and rel_l2(hk, g["h_k64"]) < 1e-5
+    assert torch.equal(eng.dsgps_forward(plan, w, h0, md.prb_data, 0), h0)
+    assert torch.equal(hk, eng.dsgps_forward(plan, w, h0, md.prb_data, net.config["k"]))   # reproducible
+    # Dirichlet rows are the encoder rows of every iterate (model.py:152)
+    idx = torch.where(md.tags.reshape(-1) == 1)[0]
+    assert torch.equal(hk[idx], h0[idx])
+
+
+def test_dsgps_forward_diagnostics(dev):
+    """ModelDSGPS.forward: every decoded iterate and the per-step loss dictionaries (model.py:48-128)."""
+    sd, net = _net(dev)
+    _, mesh = load_case("original_dirichlet_s0")
+    g = np.load(os.path.join(GOLDEN, "dsgps_original_dirichlet_s0.npz"))
+    U, ld = net(mesh.to(dev))
+    k = net.config["k"]
+    assert list(U) == [str(i) for i in range(k + 1)]
+    assert set(ld) == {"train_loss", "residual_loss", "encoder_loss", "autoencoder_loss", "mse_dirichlet", "mse_loss"}
+    assert rel_l2(U[str(k)], g["u_k"]) < 1e-5
+    res = np.array([float(ld["residual_loss"][str(i)]) for i in range(k + 1)])
+    mse = np.array([float(ld["mse_loss"][str(i)]) for i in range(k + 1)])
+    assert np.allclose(res, g["res_trace"], rtol=2e-3) and np.allclose(mse, g["mse_trace"], rtol=1e-4)
+    assert abs(float(ld["mse_dirichlet"][str(k)]) - float(g["mse_dirichlet"])) < 1e-3 * float(g["mse_dirichlet"])
+    assert torch.isfinite(ld["train_loss"])
+
+
+def test_dsgps_more_steps_and_other_tiles(dev):
+    """k beyond the trained horizon (the reference evaluates k = 150 / 200 with the same weights) and other tile sizes."""
+    sd, net = _net(dev, k=100)
+    _, mesh = load_case("hex13_dirichlet_s0")
+    md = mesh.to(dev)
+    u, h = orc.dsgps_inference(sd, mesh, 100)
+    assert rel_l2(net.inference(md), u) < 5e-5
+    eng = pkg("engine")
+    h0 = net.autoencoder.encoder(md.x)
+    base = eng.dsgps_forward(eng.plan_for(md), net.packed(dev), h0, md.prb_data, 30)
+    for tt in (32, 100):
+        assert torch.equal(eng.dsgps_forward(eng.MeshPlan(md, tile_target=tt), net.packed(dev), h0, md.prb_data, 30), base)
+    with pytest.raises(pkg("_native").NativeError):
+        eng.dsgps_forward(eng.MeshPlan(md, tile_target=-1), net.packed(dev), h0, md.prb_data, 1)

@@ -156,3 +156,18 @@ def test_reader_reproduces_the_reference_schema():
             assert torch.allclose(got.unit_normal_vector, m.unit_normal_vector, atol=1e-5)
     assert reader.split_indices(10, "train") == [0, 1, 2, 3, 4, 5] and reader.split_indices(10, "val") == [6, 7]
     assert reader.split_indices(10, "test") == [8, 9]
+
+
+def test_dsgps_state_dict_and_packing():
+    """ModelDSGPS has the reference's module tree (dirichlet/dsgps/model.py:28-45) and packs to the kernel layout."""
+    w = np.load(os.path.join(os.path.dirname(__file__), "golden", "weights_dsgps.npz"))
+    sd = {k: torch.from_numpy(w[k]) for k in w.files if k != "k"}
+    net = pkg("dsgps").ModelDSGPS(dict(latent_dim=10, k=int(w["k"]), alpha=1e-3, gamma=0.9, path_logs=None))
+    assert set(net.state_dict()) == set(sd)
+    net.load_state_dict(sd)
+    flat = pkg("engine").pack_dsgps(net.state_dict())
+    assert flat.numel() == 1690
+    Wz = sd["z_k.mlp.0.weight"]
+    assert torch.equal(flat[700:1020].reshape(32, 10), Wz.t())
+    At = sd["phi_to.mlp.mlp.0.weight"][:, 20:23]
+    assert torch.equal(flat[400:430].reshape(3, 10), At.t() * torch.tensor([-1.0, -1.0, 1.0])[:, None])
