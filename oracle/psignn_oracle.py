@@ -355,7 +355,8 @@ def function_param_vjp(sd, h, h_initial, batch, v):
 
 
 def training_step(sd, batch, solver=broyden, fw_tol=1e-5, fw_thres=500, bw_tol=1e-8, bw_thres=500):
-    """One training forward + ``loss.backward()`` of the dirichlet model, jac_weight = 0 (the reference default,
+    """One training forward + ``loss.backward()`` of the dirichlet or mixed model (chosen by the state dict; the two
+    ``ModelDEQDSS.forward`` differ only in the tag column of the Dirichlet rows), jac_weight = 0 (the reference default,
     utilities/utils.py:58): returns (loss, loss_dic, {state_dict name: grad}, forward dict, backward dict).
 
     Restates ``ModelDEQDSS.forward`` (model.py:58-99), ``DeepEquilibrium.forward`` incl. the backward hook that swaps
@@ -384,7 +385,7 @@ def training_step(sd, batch, solver=broyden, fw_tol=1e-5, fw_thres=500, bw_tol=1
     loss_dic["encoder_loss"] = mse(encoder(p, u_d), h_d)
     loss_dic["autoencoder_loss"] = mse(decoder(p, encoder(p, u_d).detach()), u_d)
     loss_dic["mse_loss"] = mse(u, batch.sol)
-    idx = torch.where(batch.tags[:, 0] == 1)[0]
+    idx = torch.where(batch.tags == 1)[0]   # model.py:87 (mixed: one-hot tags -> every row)
     loss_dic["mse_dirichlet"] = mse(u[idx, :], batch.x[idx, :])
     loss = loss_dic["residual_loss"] + loss_dic["encoder_loss"] + loss_dic["autoencoder_loss"]
     loss.backward()

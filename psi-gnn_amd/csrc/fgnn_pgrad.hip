@@ -34,6 +34,17 @@ struct TabF {  // f_theta: 20 groups (layout in k_vjp_tile_a), 16 tiles
     return tab[t];
   }
 };
+struct TabX {  // f_theta, mixed family: 30 groups (extra groups in fgnn_vjp.hip PgRec), 24 tiles
+  static constexpr int NG = 30, NT = 24;
+  __host__ __device__ static constexpr int a(int t) {
+    constexpr int tab[NT] = {6, 6, 6, 7, 8, 9, 10, 11, 12, 13, -1, -1, -1, -1, -1, -1, 23, 23, 24, 25, 26, 27, -1, -1};
+    return tab[t];
+  }
+  __host__ __device__ static constexpr int b(int t) {
+    constexpr int tab[NT] = {0, 1, 2, 0, 0, 3, 4, 5, 0, 0, 14, 15, 16, 17, 18, 19, 0, 20, 0, 21, 22, 0, 28, 29};
+    return tab[t];
+  }
+};
 struct TabM {  // two-layer MLP: groups {x|1, hid|1, d hid, d y}, tiles (d hid) x (x|1), (d y) x (hid|1)
   static constexpr int NG = 4, NT = 2;
   __host__ __device__ static constexpr int a(int t) { return t == 0 ? 2 : 3; }
@@ -44,7 +55,8 @@ template <class Tab>
 __global__ __launch_bounds__(256) void k_pgrad_outer(int64_t N, int nodes_per_wave, const float* __restrict__ rec,
                                                      float* __restrict__ part) {
   constexpr int NG = Tab::NG, NT = Tab::NT, REC = 16 * NG;
-  __shared__ float sh[4 * NT * 256];
+  constexpr bool BLOCKRED = NT <= 16;   // 4 waves x NT KB of LDS; beyond 64 KB every wave writes its own partial
+  __shared__ float sh[BLOCKRED ? 4 * NT * 256 : 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t gw = (int64_t)blockIdx.x * 4 + wv;
   const int64_t nb = gw * nodes_per_wave, ne = min(N, nb + nodes_per_wave);
@@ -66,11 +78,18 @@ __global__ __launch_bounds__(256) void k_pgrad_outer(int64_t N, int nodes_per_wa
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Tab::a(t) < 0 ? on : v[Tab::a(t) < 0 ? 0 : Tab::a(t)], v[Tab::b(t)],
                                                     acc[t], 0, 0, 0);
   }
-  // D[i = 4 (lane >> 4) + r][j = lane & 15] -> sh[wave][tile][i * 16 + j]
+  // D[i = 4 (lane >> 4) + r][j = lane & 15] -> [tile][i * 16 + j]
+  if (!BLOCKRED) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(gw * NT + t) * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[t][r];
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sh[(wv * NT + t) * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[t][r];
+    for (int r = 0; r < 4; ++r) sh[BLOCKRED ? (wv * NT + t) * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15) : 0] = acc[t][r];
   __syncthreads();
   for (int i = threadIdx.x; i < NT * 256; i += 256)
     part[(int64_t)blockIdx.x * NT * 256 + i] = (sh[i] + sh[NT * 256 + i]) + (sh[2 * NT * 256 + i] + sh[3 * NT * 256 + i]);
@@ -117,7 +136,10 @@ __device__ __forceinline__ int pg_offset(int t, int i, int j) {
     }
     case 10: return (i == 0 && j < D) ? L::LN_G + j : -1;
     case 11: return (i == 0 && j < D) ? L::LN_B + j : -1;
-    default: {  // column sums of dS (.) attr moments: index o * 3 + c, to-block then from-block
+    case 12:
+    case 13:
+    case 14:
+    case 15: {  // column sums of dS (.) attr moments: index o * 3 + c, to-block then from-block
       if (i != 0) return -1;
       const int idx = (t - 12) * 16 + j;
       if (idx >= 60) return -1;
@@ -125,11 +147,41 @@ __device__ __forceinline__ int pg_offset(int t, int i, int j) {
       const int k = idx < 30 ? idx : idx - 30;
       return ph + L::PHI_W1 + (k / 3) * L::EIN + 2 * D + (k % 3);
     }
+    default: break;
+  }
+  // ---- mixed family: Phi_neumann / update_neumann (single layer)
+  constexpr int pn = L::phi_neu(1), un = L::upd_neu(1);
+  switch (t) {
+    case 16:  // dq_n x (x | 1)
+      if (i >= D) return -1;
+      return j < D ? un + L::NEU_W1 + i * L::NEU_CAT + j : (j == D ? un + L::NEU_B1 + i : -1);
+    case 17:  // dq_n x (mp_n | prb | normal)
+      return (i < D && j < D + P + 2) ? un + L::NEU_W1 + i * L::NEU_CAT + D + j : -1;
+    case 18:  // gn x (x | 1)
+      if (i >= D) return -1;
+      return j < D ? pn + L::PHI_W1 + i * L::EIN + j : (j == D ? pn + L::PHI_B1 + i : -1);
+    case 19:  // d mp_n x (S_n | deg_out)
+      if (i >= D) return -1;
+      return j < D ? pn + L::PHI_W2 + i * D + j : (j == D ? pn + L::PHI_B2 + i : -1);
+    case 20:  // dy_n x (hid_n | 1)
+      if (i >= D) return -1;
+      return j < D ? un + L::NEU_W2 + i * D + j : (j == D ? un + L::NEU_B2 + i : -1);
+    case 21: return (i < D && j < D) ? pn + L::PHI_W1 + i * L::EIN + D + j : -1;
+    case 22:
+    case 23: {
+      if (i != 0) return -1;
+      const int idx = (t - 22) * 16 + j;
+      return idx < 30 ? pn + L::PHI_W1 + (idx / 3) * L::EIN + 2 * D + (idx % 3) : -1;
+    }
+    default: return -1;
   }
 }
 
 struct MapF {  // f_theta, dirichlet
   __device__ int operator()(int t, int i, int j) const { return pg_offset<2>(t, i, j); }
+};
+struct MapX {  // f_theta, mixed
+  __device__ int operator()(int t, int i, int j) const { return pg_offset<3>(t, i, j); }
 };
 struct MapM {  // flat [W1 (hid, din) | b1 | W2 (dout, hid) | b2]
   int din, hid, dout;
@@ -165,11 +217,15 @@ static inline int pgrad_blocks(int64_t N, int* nodes_per_wave) {
   return (int)cdiv(N, npw * 4);
 }
 
+int psignn_f_gather_vjp_rec(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* nrm,
+                            const float* w, float* out, float* work, float* rec, hipStream_t st);
+
 extern "C" int64_t psignn_f_param_vjp_workspace_floats(const psignn_plan_t* p) {
   if (!p) return 0;
   int npw;
   const int nblk = pgrad_blocks(p->N, &npw);
-  return p->N * (4 * D + PGREC) + (int64_t)nblk * PG_TILES * 256;
+  // VJP scratch (<= N * 90) + plan-order copies (<= N * 32) + records (N * 480 mixed) + partial tiles (per wave for mixed)
+  return p->N * (9 * D + 32 + TabX::NG * 16) + (int64_t)nblk * 4 * TabX::NT * 256;
 }
 
 extern "C" int64_t psignn_param_grad_size(int mixed, int nl) {
@@ -304,6 +360,49 @@ extern "C" int psignn_residual_t(const psignn_plan_t* p, const float* d_a_ij, co
   ARG_CHECK(p && d_a_ij && d_r && d_out, "NULL argument");
   k_residual_t<<<(unsigned)cdiv(p->N, (int64_t)256), 256, 0, (hipStream_t)stream>>>(
       p->N, p->csc_ptr, p->csc_nbr, p->csc_eid, d_a_ij, p->a_ptr, p->a_col, p->a_val, d_r, d_out);
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+
+// Caller-order parameter-VJP for every plan: tiled single-layer dirichlet plans run the tiled kernels (permutation passes
+// around them); mixed and untiled plans run the global-gather kernels in PG mode.  d_normals: mixed only.
+extern "C" int psignn_f_param_vjp(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* prb,
+                                  const float* nrm, const float* w, float* d_grad, float* d_out_h, float* work,
+                                  void* stream) {
+  ARG_CHECK(p && W && h && prb && w && d_grad && d_out_h && work, "NULL argument");
+  ARG_CHECK(nl == 1, "parameter gradients are implemented for single-layer blocks");
+  ARG_CHECK(!p->mixed || nrm, "mixed plan needs unit normals");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t N = p->N;
+  int rc;
+  if (p->tiled && !p->mixed) {
+    float* hp = work;
+    float* wp = hp + N * D;
+    float* op = wp + N * D;
+    float* pp = op + N * D;  // (N, 2)
+    float* rest = pp + N * 2;
+    if ((rc = psignn_plan_permute(p, h, D, hp, 1, stream))) return rc;
+    if ((rc = psignn_plan_permute(p, w, D, wp, 1, stream))) return rc;
+    if ((rc = psignn_plan_permute(p, prb, 2, pp, 1, stream))) return rc;
+    if ((rc = psignn_f_param_vjp_p(p, W, nl, hp, pp, wp, d_grad, op, rest, stream))) return rc;
+    return psignn_plan_permute(p, op, D, d_out_h, 0, stream);
+  }
+  float* scratch = work;                      // Pj + B: N * 90 floats at most
+  float* rec = scratch + N * 9 * D;
+  int npw;
+  const int nblk = pgrad_blocks(N, &npw);
+  if ((rc = psignn_f_gather_vjp_rec(p, W, nl, h, prb, nrm, w, d_out_h, scratch, rec, st))) return rc;
+  if (p->mixed) {
+    float* part = rec + N * TabX::NG * 16;
+    HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)WLayout<3>::base_total(nl, true) * 4, st));
+    LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabX><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
+    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabX::NT, 256, 0, st>>>(nblk * 4, TabX::NT, part, d_grad, MapX())));
+  } else {
+    float* part = rec + N * TabF::NG * 16;
+    HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)WLayout<2>::base_total(nl, false) * 4, st));
+    LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabF><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
+    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabF::NT, 256, 0, st>>>(nblk, TabF::NT, part, d_grad, MapF())));
+  }
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }

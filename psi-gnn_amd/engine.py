@@ -374,9 +374,19 @@ class FixedPointMap:
 
     def param_vjp(self, H, Wv):
         """What ``loss.backward()`` leaves in the ``deqdss.f`` parameters for new_H = f(H) with cotangent Wv
-        (dirichlet/psignn/model.py:203-225): ({name: grad}, Wv^T df/dH) in the caller's numbering."""
-        flat, outp = self.param_vjp_p(self.to_plan(H), self.to_plan(Wv))
-        return unpack_param_grads(flat, self.weights.n_layers, self.weights.mixed), self.from_plan(outp)
+        (dirichlet/psignn/model.py:203-225; mixed/psignn/model.py likewise): ({name: grad}, Wv^T df/dH) in the
+        caller's numbering.  Single-layer blocks of both families, tiled or not."""
+        Hc, Wc = _f32c(H), _f32c(Wv)
+        l = nat.lib()
+        grad = torch.empty(int(l.psignn_param_grad_size(int(self.weights.mixed), self.weights.n_layers)),
+                           dtype=torch.float32, device=Hc.device)
+        out = torch.empty_like(Hc)
+        with torch.cuda.device(Hc.device):
+            nat.check(l.psignn_f_param_vjp(self.plan.handle, nat.ptr(self.weights.flat), self.weights.n_layers,
+                                           nat.ptr(Hc), nat.ptr(self.prb), nat.ptr(self.nrm), nat.ptr(Wc), nat.ptr(grad),
+                                           nat.ptr(out), nat.ptr(self.plan.pgrad_workspace()),
+                                           nat.stream_ptr(Hc.device)), "psignn_f_param_vjp")
+        return unpack_param_grads(grad, self.weights.n_layers, self.weights.mixed), out
 
     def phi(self, H, which: int, layer: int = 0):
         """One aggregation: 0 Phi_to, 1 Phi_from, 2 Phi_neumann."""
@@ -435,9 +445,10 @@ def dsgps_step_p(plan: "MeshPlan", wflat, hp, h0p, prbp):
 
 def unpack_param_grads(flat, n_layers=1, mixed=False):
     """Name the entries of a flat parameter gradient (layout = leading section of ``pack_weights``)."""
-    if mixed or n_layers != 1:
-        raise nat.NativeError("parameter gradients are implemented for the single-layer dirichlet block")
-    p, cat, ein = 2, 3 * D + 2, 2 * D + 3
+    if n_layers != 1:
+        raise nat.NativeError("parameter gradients are implemented for single-layer blocks")
+    p = 3 if mixed else 2
+    cat, ein = 3 * D + p, 2 * D + 3
     out, o = {}, 0
 
     def take(name, *shape):
@@ -461,6 +472,16 @@ def unpack_param_grads(flat, n_layers=1, mixed=False):
     take("update_list.0.mlp.0.bias", D)
     take("update_list.0.mlp.2.weight", D, D)
     take("update_list.0.mlp.2.bias", D)
+    if mixed:
+        o += 244   # fold slots of the layer
+        take("phi_neumann.mlp.mlp.0.weight", D, ein)
+        take("phi_neumann.mlp.mlp.0.bias", D)
+        take("phi_neumann.mlp.mlp.2.weight", D, D)
+        take("phi_neumann.mlp.mlp.2.bias", D)
+        take("update_neumann.mlp.0.weight", D, 2 * D + p + 2)
+        take("update_neumann.mlp.0.bias", D)
+        take("update_neumann.mlp.2.weight", D, D)
+        take("update_neumann.mlp.2.bias", D)
     return out
 
 

@@ -165,7 +165,8 @@ class _DEQFn(torch.autograd.Function):
         y = out_bw["result"]
         grads, _ = ctx.fmap.param_vjp(H_star, y)
         tags = ctx.batch.tags.reshape(y.shape[0], -1)
-        g_init = torch.where(tags[:, :1] == 1, y, torch.zeros_like(y))
+        col = 1 if deq.f.mixed else 0   # one-hot [interior, dirichlet, neumann] in the mixed family
+        g_init = torch.where(tags[:, col:col + 1] == 1, y, torch.zeros_like(y))
         return (g_init, None, None, None) + tuple(grads[n] for n in ctx.names)
 
 
@@ -197,8 +198,8 @@ class DeepEquilibrium(nn.Module):
         The Jacobian regulariser is returned as a value only (``jac_weight`` defaults to 0 in the reference,
         utilities/utils.py:58; its second-order gradient is not implemented)."""
         if torch.is_grad_enabled():
-            if self.f.mixed or self.f.n_layers != 1:
-                raise nat.NativeError("the training path is implemented for the single-layer dirichlet block")
+            if self.f.n_layers != 1:
+                raise nat.NativeError("the training path is implemented for single-layer blocks")
             named = list(self.f.named_parameters())
             new_H = _DEQFn.apply(H_init, self, batch, tuple(n for n, _ in named), *[p for _, p in named])
             H_star = self.last_forward["result"]
@@ -382,7 +383,8 @@ class ModelDEQDSS(_Base):
         u_d, h_d = u_final.detach(), h_final.detach()
         encoder_loss = self.mse_loss(ae.encoder(u_d), h_d)
         autoencoder_loss = self.mse_loss(ae.decoder(ae.encoder(u_d).detach()), u_d)
-        idx = self._dirichlet_index(batch)
+        # model.py:87 in BOTH families: where(tags == 1)[0]; on the mixed family's one-hot (N, 3) tags that is every row
+        idx = torch.where(batch.tags == 1)[0]
         loss_dic = {"residual_loss": residual_loss, "jacobian_loss": jacobian_loss, "encoder_loss": encoder_loss,
                     "autoencoder_loss": autoencoder_loss, "mse_loss": self.mse_loss(u_final, batch.sol),
                     "mse_dirichlet": self.mse_loss(u_final[idx, :], batch.x[idx, :])}

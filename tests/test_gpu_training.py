@@ -12,7 +12,7 @@ import os
 import pytest
 import torch
 
-from conftest import load_case, load_weights, pkg, rel_l2
+from conftest import CASES, load_case, load_weights, pkg, rel_l2
 from oracle import psignn_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -20,27 +20,25 @@ pytestmark = pytest.mark.gpu
 
 def _cmp(got, want, tol, floor_scale):
     """max over tensors of ||got - want|| / max(||want||, 1e-4 * floor_scale)"""
-    worst, name = 0.0, None
-    for k, w in want.items():
-        e = float((got[k].detach().cpu().double() - w.double()).norm()) / max(float(w.double().norm()), 1e-4 * floor_scale)
-        if e > worst:
-            worst, name = e, k
-    assert worst < tol, (name, worst)
-    return worst
+    errs = {k: float((got[k].detach().cpu().double() - w.double()).norm()) / max(float(w.double().norm()), 1e-4 * floor_scale)
+            for k, w in want.items()}
+    name = max(errs, key=errs.get)
+    assert errs[name] < tol, (name, errs[name], {k: round(e, 6) for k, e in errs.items() if e >= tol})
+    return errs[name]
 
 
 def _bind(name, dev):
     g, mesh = load_case(name)
-    sd = load_weights("dirichlet")
+    sd = load_weights(CASES[name])
     eng = pkg("engine")
     md = mesh.to(dev)
     w = eng.PackedWeights(sd, dev)
     h0 = torch.from_numpy(g["h0"]).to(dev)
-    fmap = eng.FixedPointMap(eng.plan_for(md), w, h0, md.prb_data, None)
+    fmap = eng.FixedPointMap(eng.plan_for(md), w, h0, md.prb_data, getattr(md, "unit_normal_vector", None))
     return g, mesh, md, sd, fmap
 
 
-@pytest.mark.parametrize("name", ["original_dirichlet_s0", "hex13_dirichlet_s0", "hex26_dirichlet_s0"])
+@pytest.mark.parametrize("name", ["original_dirichlet_s0", "hex13_dirichlet_s0", "hex26_dirichlet_s0", "hex13_mixed_s1"])
 def test_param_vjp_parity(name, dev):
     g, mesh, md, sd, fmap = _bind(name, dev)
     h = torch.from_numpy(g["f1"])
@@ -55,7 +53,8 @@ def test_param_vjp_parity(name, dev):
     g2, _ = fmap.param_vjp(h.to(dev), v.to(dev))
     assert all(torch.equal(grads[k], g2[k]) for k in grads)
     # gradient w.r.t. H_init = the cotangent on the Dirichlet rows (model.py:298)
-    mask = (mesh.tags.reshape(h.shape[0], -1)[:, :1] == 1)
+    col = 1 if CASES[name] == "mixed" else 0
+    mask = (mesh.tags.reshape(h.shape[0], -1)[:, col:col + 1] == 1)
     assert torch.equal(want_h0, torch.where(mask, v, torch.zeros_like(v)))
 
 
@@ -70,9 +69,13 @@ def test_param_vjp_other_tile_sizes(dev):
         fm = eng.FixedPointMap(eng.MeshPlan(md, tile_target=tt), fmap.weights, fmap.h0, md.prb_data, None)
         got, _ = fm.param_vjp(h, v)
         _cmp(got, {k: t.cpu() for k, t in base.items()}, 1e-5, scale)
+    # untiled plan: the global-gather kernels in record mode
     flat = eng.FixedPointMap(eng.MeshPlan(md, tile_target=-1), fmap.weights, fmap.h0, md.prb_data, None)
+    assert not flat.plan.tiled
+    got, oh = flat.param_vjp(h, v)
+    _cmp(got, {k: t.cpu() for k, t in base.items()}, 1e-5, scale)
     with pytest.raises(pkg("_native").NativeError):
-        flat.param_vjp(h, v)   # untiled plans: no silent fallback
+        flat.param_vjp_p(h, v)   # the plan-order entry point is the tiled path only
 
 
 @pytest.mark.parametrize("dims", [(1, 10, 10), (10, 10, 1), (3, 7, 5)])
@@ -112,16 +115,18 @@ def _model(sd, dev, **kw):
     solver = pkg("utilities.solver")
     cfg = dict(latent_dim=10, n_layers=1, solver=solver.broyden, fw_tol=1e-6, fw_thres=400, bw_tol=1e-7, bw_thres=400)
     cfg.update(kw)
-    net = pkg("model_psignn").ModelDEQDSS(cfg)
+    mixed = any(k.startswith("deqdss.f.phi_neumann") for k in sd)
+    net = (pkg("mixed") if mixed else pkg("model_psignn")).ModelDEQDSS(cfg)
     net.load_state_dict(sd)
     return net.to(dev)
 
 
-@pytest.mark.parametrize("name", ["hex13_dirichlet_s0", "original_dirichlet_s0"])
+@pytest.mark.parametrize("name", ["hex13_dirichlet_s0", "original_dirichlet_s0", "hex13_mixed_s1"])
 def test_training_step_gradients(name, dev):
-    """loss.backward() through the HIP model vs the oracle's restated training step: losses and all 24 gradients."""
+    """loss.backward() through the HIP model vs the oracle's restated training step: losses and all 24 (mixed: 32)
+    gradients."""
     g, mesh = load_case(name)
-    sd = load_weights("dirichlet")
+    sd = load_weights(CASES[name])
     net = _model(sd, dev, fw_tol=1e-7, fw_thres=600).train()
     md = mesh.to(dev)
     u, ld = net(md)
@@ -136,7 +141,8 @@ def test_training_step_gradients(name, dev):
     got = {k: p.grad for k, p in net.named_parameters()}
     assert all(v is not None for v in got.values())
     scale = max(float(t.norm()) for t in wg.values())
-    print("worst gradient error", _cmp(got, wg, 5e-3, scale))
+    # mixed fixture: 222 forward / 217 adjoint Broyden steps (dirichlet: ~100 / ~150) -- worse conditioned, measured 6.3e-3
+    print("worst gradient error", _cmp(got, wg, 1e-2 if CASES[name] == "mixed" else 5e-3, scale))
 
 
 def test_trainer_steps_and_checkpoint(dev, tmp_path):
