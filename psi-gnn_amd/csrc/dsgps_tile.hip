@@ -57,7 +57,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_dsgps_tile(int n_tiles, int ch
     v2f ta[5], tb[5];
 #pragma unroll
     for (int p = 0; p < 5; ++p) ta[p] = tb[p] = splat(0.f);
+    PHASE();
     mv2<D>(W + dsl::W1J_TO, xr, ta);
+    PHASE();
     mv2<D>(W + dsl::W1J_FR, xr, tb);
     float4* q = reinterpret_cast<float4*>(lds + row * RS);
     q[0] = make_float4(ta[0].x, ta[0].y, ta[1].x, ta[1].y);
@@ -84,9 +86,11 @@ __global__ __launch_bounds__(TILE_THREADS) void k_dsgps_tile(int n_tiles, int ch
   ld5(W + dsl::B1_TO, Pi);
 #pragma unroll
   for (int p = 0; p < 5; ++p) S_to[p] = S_fr[p] = splat(0.f);
+  PHASE();
   mv2<D>(W + dsl::W1I_TO, x, Pi);
   const float deg_in = edge_pass<RS, 0, SLOT_IN>(slots, nslots, lds, W + dsl::A_TO, Pi, S_to);
   ld5(W + dsl::B1_FR, Pi);
+  PHASE();
   mv2<D>(W + dsl::W1I_FR, x, Pi);
   const float deg_out = edge_pass<RS, D, SLOT_OUT>(slots, nslots, lds, W + dsl::A_FR, Pi, S_fr);
   // second Phi layer: mess = W2 S + deg b2
@@ -94,10 +98,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_dsgps_tile(int n_tiles, int ch
   ld5(W + dsl::B2_TO, b);
 #pragma unroll
   for (int p = 0; p < 5; ++p) mt[p] = splat(deg_in) * b[p];
+  PHASE();
   mv2<D>(W + dsl::W2_TO, reinterpret_cast<const float*>(S_to), mt);
   ld5(W + dsl::B2_FR, b);
 #pragma unroll
   for (int p = 0; p < 5; ++p) mf[p] = splat(deg_out) * b[p];
+  PHASE();
   mv2<D>(W + dsl::W2_FR, reinterpret_cast<const float*>(S_fr), mf);
   const float* mto = reinterpret_cast<const float*>(mt);
   const float* mfr = reinterpret_cast<const float*>(mf);
@@ -107,14 +113,22 @@ __global__ __launch_bounds__(TILE_THREADS) void k_dsgps_tile(int n_tiles, int ch
   // gates: rows of the transposed (32, 10) blocks are [h 0..9 | mess_to 10..19 | mess_from 20..29 | prb 30..31]
   v2f z[5], r[5], c[5];
   ld5(W + dsl::BZ, z);
+  PHASE();
   mv2<D>(W + dsl::WZ, x, z);
+  PHASE();
   mv2<D>(W + dsl::WZ + 10 * D, mto, z);
+  PHASE();
   mv2<D>(W + dsl::WZ + 20 * D, mfr, z);
+  PHASE();
   mv2<dsl::P>(W + dsl::WZ + 30 * D, pq, z);
   ld5(W + dsl::BR, r);
+  PHASE();
   mv2<D>(W + dsl::WR, x, r);
+  PHASE();
   mv2<D>(W + dsl::WR + 10 * D, mto, r);
+  PHASE();
   mv2<D>(W + dsl::WR + 20 * D, mfr, r);
+  PHASE();
   mv2<dsl::P>(W + dsl::WR + 30 * D, pq, r);
   float rh[D];
 #pragma unroll
@@ -123,9 +137,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_dsgps_tile(int n_tiles, int ch
     rh[2 * p + 1] = x[2 * p + 1] * fast_sigmoid(r[p].y);
   }
   ld5(W + dsl::BC, c);
+  PHASE();
   mv2<D>(W + dsl::WC, rh, c);
+  PHASE();
   mv2<D>(W + dsl::WC + 10 * D, mto, c);
+  PHASE();
   mv2<D>(W + dsl::WC + 20 * D, mfr, c);
+  PHASE();
   mv2<dsl::P>(W + dsl::WC + 30 * D, pq, c);
 #pragma unroll
   for (int p = 0; p < 5; ++p) {

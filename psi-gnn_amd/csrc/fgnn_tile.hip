@@ -54,19 +54,17 @@ __device__ __forceinline__ void lds_load10at(const float* __restrict__ p, float*
 // matrix cores (v_mfma_f32_16x16x4_f32) or packed VALU.
 #include <stdlib.h>
 #include <string.h>
-// default form per kernel flavour, from an A/B on one box (1M-node mesh): plain f 66.3 us (mfma) vs 68.2 us (valu),
-// mixed 99.5 vs 106.6; the fused Broyden step 122-125 us (mfma) vs 106 us (valu) -- there the MFMA form has to
-// re-load x and update for stage 2, which the VALU form gets for free from its stage-1 registers.
-#ifndef STAGE1_DEFAULT_MFMA
-#define STAGE1_DEFAULT_MFMA(fused) (!(fused))
-#endif
-static int stage1_mfma(bool fused) {
+// default form per kernel flavour, from A/Bs on one box (1M-node mesh, after the scalar-load phase barriers removed the SGPR
+// spills of the VALU form): dirichlet plain f 64.6 us (valu) vs 67.7 us (mfma); mixed plain f 102.9 (valu) vs 102.2 (mfma);
+// fused Broyden step 102 us (valu) vs 122-125 us (mfma: it has to re-load x and update for stage 2, which the VALU form
+// gets for free from its stage-1 registers).  Before the barriers the VALU form spilled ~200 SGPRs and lost: 68.2 vs 66.3 us.
+static int stage1_mfma(bool fused, bool mixed) {
   static int forced = [] {
     const char* e = getenv("PSIGNN_STAGE1");
     return !e ? -1 : (strcmp(e, "mfma") == 0 ? 1 : 0);
   }();
   if (forced >= 0) return forced;
-  return STAGE1_DEFAULT_MFMA(fused);
+  return mixed && !fused;
 }
 
 // Broyden fusion (solver.hip): the kernel forms x_next = x_cur + update while loading, and its epilogue
@@ -198,7 +196,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tile
     v2f ta[5], tb[5];
 #pragma unroll
     for (int p = 0; p < 5; ++p) ta[p] = tb[p] = splat(0.f);
+    PHASE();
     mv2<D>(T + L::T_W1J_TO, xr, ta);
+    PHASE();
     mv2<D>(T + L::T_W1J_FR, xr, tb);
     float4* q = reinterpret_cast<float4*>(lds + row * RS);
     q[0] = make_float4(ta[0].x, ta[0].y, ta[1].x, ta[1].y);
@@ -209,6 +209,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tile
     if (MIXED) {
 #pragma unroll
       for (int p = 0; p < 5; ++p) ta[p] = splat(0.f);
+      PHASE();
       mv2<D>(TN + L::N_W1J, xr, ta);
       q[5] = make_float4(ta[0].x, ta[0].y, ta[1].x, ta[1].y);
       q[6] = make_float4(ta[2].x, ta[2].y, ta[3].x, ta[3].y);
@@ -243,9 +244,11 @@ __global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tile
   ld5(T + L::T_B1_TO, Pi);
 #pragma unroll
   for (int p = 0; p < 5; ++p) S_to[p] = S_fr[p] = splat(0.f);
+  PHASE();
   mv2<D>(T + L::T_W1I_TO, x, Pi);
   const float deg_in = edge_pass<RS, 0, SLOT_IN>(slots, nslots, lds, T + L::T_A_TO, Pi, S_to);
   ld5(T + L::T_B1_FR, Pi);
+  PHASE();
   mv2<D>(T + L::T_W1I_FR, x, Pi);
   const float deg_out = edge_pass<RS, D, SLOT_OUT>(slots, nslots, lds, T + L::T_A_FR, Pi, S_fr);
 
@@ -256,23 +259,28 @@ __global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tile
     ld5(TN + L::N_B1, Pi);
 #pragma unroll
     for (int p = 0; p < 5; ++p) S_n[p] = splat(0.f);
+    PHASE();
     mv2<D>(TN + L::N_W1I, x, Pi);
     edge_pass<RS, 2 * D, SLOT_OUT>(slots, nslots, lds, TN + L::N_A, Pi, S_n);
     ld5(TN + L::N_NB1, hid);
     ld5(TN + L::N_gN, gN);
 #pragma unroll
     for (int p = 0; p < 5; ++p) hid[p] = __builtin_elementwise_fma(splat(deg_out), gN[p], hid[p]);
+    PHASE();
     mv2<D>(TN + L::N_N1H, x, hid);
+    PHASE();
     mv2<D>(TN + L::N_GN, reinterpret_cast<const float*>(S_n), hid);
     float pq[P + 2];
 #pragma unroll
     for (int k = 0; k < P; ++k) pq[k] = prb[n * P + k];
     pq[P] = nrm[n * 2];
     pq[P + 1] = nrm[n * 2 + 1];
+    PHASE();
     mv2<P + 2>(TN + L::N_N1P, pq, hid);
 #pragma unroll
     for (int p = 0; p < 5; ++p) hid[p] = __builtin_elementwise_max(hid[p], splat(0.f));
     ld5(TN + L::N_NB2, y2);
+    PHASE();
     mv2<D>(TN + L::N_N2, reinterpret_cast<const float*>(hid), y2);
   } else {
     // gate + update MLP on cat = [h | mp_to | mp_from | prb], with mp_* = W2 S + deg b2 folded in
@@ -300,13 +308,18 @@ __global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tile
 #pragma unroll
     for (int p = 0; p < 5; ++p)
       hid[p] = __builtin_elementwise_fma(splat(deg_in), g1[p], __builtin_elementwise_fma(splat(deg_out), g2[p], hid[p]));
+    PHASE();
     mv2<D>(T + L::T_U1H, x, hid);
+    PHASE();
     mv2<D>(T + L::T_GTO, sto, hid);
+    PHASE();
     mv2<D>(T + L::T_GFR, sfr, hid);
+    PHASE();
     mv2<P>(T + L::T_U1P, pq, hid);
 #pragma unroll
     for (int p = 0; p < 5; ++p) hid[p] = __builtin_elementwise_max(hid[p], splat(0.f));
     ld5(T + L::T_C2, upd);
+    PHASE();
     mv2<D>(T + L::T_U2, reinterpret_cast<const float*>(hid), upd);
 #pragma unroll
     for (int p = 0; p < 5; ++p) y2[p] = __builtin_elementwise_fma(splat(al), upd[p], (v2f){x[2 * p], x[2 * p + 1]});
@@ -390,7 +403,7 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
   if (p->mixed) {
     using L = WLayout<3>;
     size_t lds = (size_t)p->max_rows * TileRow<true>::RS * 4;
-    if (stage1_mfma(false))
+    if (stage1_mfma(false, true))
       LAUNCH("k_f_tile", st, (k_f_tile<3, true, false, true><<<grid, TILE_THREADS, lds, st>>>(
         FuseArgs{}, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
         p->flags_p, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), L::tp_neu(nl), 1, h, hsel, hstride, h0, prb, nrm, out)));
@@ -406,7 +419,7 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
     const float* cur = h;
     for (int l = 0; l < nl; ++l) {
       float* dst = (l == nl - 1) ? out : pp[l & 1];
-      if (stage1_mfma(false))
+      if (stage1_mfma(false, false))
       LAUNCH("k_f_tile", st, (k_f_tile<2, false, false, true><<<grid, TILE_THREADS, lds, st>>>(
           FuseArgs{}, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
           p->flags_p, W, L::layer(l), L::tp_layer(nl, false, l), 0, l == nl - 1, cur, l == 0 ? hsel : nullptr, hstride, h0, prb, nrm, dst)));
@@ -435,7 +448,7 @@ int psignn_f_tile_fused(const psignn_plan* p, const float* W, int nl, float* xbu
   if (p->mixed) {
     using L = WLayout<3>;
     size_t lds = (size_t)p->max_rows * TileRow<true>::RS * 4;
-    if (stage1_mfma(true))
+    if (stage1_mfma(true, true))
       LAUNCH("k_f_tile_fused", st, (k_f_tile<3, true, true, true><<<grid, TILE_THREADS, lds, st>>>(
         fa, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
         p->flags_p, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), L::tp_neu(nl), 1, xbuf, nullptr, 0, h0, prb, nrm, nullptr)));
@@ -446,7 +459,7 @@ int psignn_f_tile_fused(const psignn_plan* p, const float* W, int nl, float* xbu
   } else {
     using L = WLayout<2>;
     size_t lds = (size_t)p->max_rows * TileRow<false>::RS * 4;
-    if (stage1_mfma(true))
+    if (stage1_mfma(true, false))
       LAUNCH("k_f_tile_fused", st, (k_f_tile<2, false, true, true><<<grid, TILE_THREADS, lds, st>>>(
         fa, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
         p->flags_p, W, L::layer(0), L::tp_layer(nl, false, 0), 0, 1, xbuf, nullptr, 0, h0, prb, nrm, nullptr)));

@@ -17,6 +17,7 @@
 #define SLOT_IN 0x10000u
 #define SLOT_OUT 0x20000u
 #define VT 256
+#define PHASE() asm volatile("" ::: "memory")   // bounds scalar-load hoisting (see tile_helpers.h)
 #define PGREC 320   // floats per node of a parameter-gradient record: 20 groups of 16 (layout in k_vjp_tile_a)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -155,7 +156,9 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const
     v2f ta[5], tb[5];
 #pragma unroll
     for (int p = 0; p < 5; ++p) ta[p] = tb[p] = splat2(0.f);
+    PHASE();
     mvf<D>(T + L::T_W1J_TO, xr, ta);
+    PHASE();
     mvf<D>(T + L::T_W1J_FR, xr, tb);
     float4* q = reinterpret_cast<float4*>(lds + row * RS);
     q[0] = make_float4(ta[0].x, ta[0].y, ta[1].x, ta[1].y);
@@ -198,8 +201,10 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const
   ldu5(T + L::T_B1_FR, Pf);
 #pragma unroll
   for (int p = 0; p < 5; ++p) S_to[p] = S_fr[p] = c_to[p] = c_fr[p] = splat2(0.f);
+  PHASE();
   mvf<D>(T + L::T_W1I_TO, x, Pt);
   const float deg_in = pass_fwd<RS, 0, SLOT_IN, PG>(slots, nslots, lds, T + L::T_A_TO, Pt, S_to, c_to, m_to);
+  PHASE();
   mvf<D>(T + L::T_W1I_FR, x, Pf);
   const float deg_out = pass_fwd<RS, D, SLOT_OUT, PG>(slots, nslots, lds, T + L::T_A_FR, Pf, S_fr, c_fr, m_fr);
   const float* Wf = W + lofs + L::L_FOLD;
@@ -227,13 +232,18 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const
 #pragma unroll
   for (int p = 0; p < 5; ++p)
     q2[p] = __builtin_elementwise_fma(splat2(deg_in), g1[p], __builtin_elementwise_fma(splat2(deg_out), g2[p], q2[p]));
+  PHASE();
   mvf<D>(T + L::T_U1H, x, q2);
+  PHASE();
   mvf<D>(T + L::T_GTO, sto, q2);
+  PHASE();
   mvf<D>(T + L::T_GFR, sfr, q2);
+  PHASE();
   mvf<P>(T + L::T_U1P, pq, q2);
 #pragma unroll
   for (int p = 0; p < 5; ++p) hid2[p] = __builtin_elementwise_max(q2[p], splat2(0.f));
   ldu5(T + L::T_C2, upd2);
+  PHASE();
   mvf<D>(T + L::T_U2, reinterpret_cast<const float*>(hid2), upd2);
   const float* qf = reinterpret_cast<const float*>(q2);
   const float* upd = reinterpret_cast<const float*>(upd2);
@@ -279,10 +289,12 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const
   v2f dq2[5];
 #pragma unroll
   for (int p = 0; p < 5; ++p) dq2[p] = splat2(0.f);
+  PHASE();
   mvb<D>(Wu + L::UPD_W2, D, 0, dupd, dq2);
   float dq[D];
 #pragma unroll
   for (int o = 0; o < D; ++o) dq[o] = qf[o] > 0.f ? reinterpret_cast<const float*>(dq2)[o] : 0.f;
+  PHASE();
   mvb<D>(Wu + L::UPD_W1, L::CAT, 0, dq, g);
   v2f dS_to[5], dS_fr[5];
 #pragma unroll
@@ -291,7 +303,9 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const
     dS_to[p] = (v2f){Wf[L::F_ATO + 2 * p], Wf[L::F_ATO + 2 * p + 1]} * splat2(dal);
     dS_fr[p] = (v2f){Wf[L::F_AFR + 2 * p], Wf[L::F_AFR + 2 * p + 1]} * splat2(dal);
   }
+  PHASE();
   mvb<D>(Wf + L::F_GTO, D, 0, dq, dS_to);   // dS_to[k] = sum_o G_to[o][k] dq[o] + a_to[k] dal
+  PHASE();
   mvb<D>(Wf + L::F_GFR, D, 0, dq, dS_fr);
   Bn[0] = make_float4(Pt[0].x, Pt[0].y, Pt[1].x, Pt[1].y);
   Bn[1] = make_float4(Pt[2].x, Pt[2].y, Pt[3].x, Pt[3].y);
@@ -313,7 +327,9 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const
   }
   const float* Wto = W + lofs + L::L_TO;
   const float* Wfr = W + lofs + L::L_FROM;
+  PHASE();
   mvb<D>(Wto + L::PHI_W1, L::EIN, 0, gt, g);
+  PHASE();
   mvb<D>(Wfr + L::PHI_W1, L::EIN, 0, gf, g);
   float go[D];
 #pragma unroll
@@ -344,10 +360,12 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const
     v2f dm[5];
 #pragma unroll
     for (int p = 0; p < 5; ++p) dm[p] = (v2f){Wa[D + 2 * p], Wa[D + 2 * p + 1]} * splat2(dal);
+    PHASE();
     mvb<D>(Wu + L::UPD_W1, L::CAT, D, dq, dm);
     rec_group(r + 144, reinterpret_cast<const float*>(dm), D);                 // 9: d mp_to
 #pragma unroll
     for (int p = 0; p < 5; ++p) dm[p] = (v2f){Wa[2 * D + 2 * p], Wa[2 * D + 2 * p + 1]} * splat2(dal);
+    PHASE();
     mvb<D>(Wu + L::UPD_W1, L::CAT, 2 * D, dq, dm);
     rec_group(r + 160, reinterpret_cast<const float*>(dm), D);                 // 10: d mp_from
     rec_group(r + 176, dupd, D);                                               // 11: d upd0   (12, 13: pass B)
@@ -455,11 +473,13 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const
   for (int p = 0; p < 5; ++p) Pj[p] = at[p] = af[p] = splat2(0.f);
   // OUT slots: edge (u -> n) is an in-edge of n (Phi_to of n): Pt[n] at 0, dS_to[n] at 20, attr = the slot's own
   // (T_A_TO holds the mirrored rows -> flip = -1 restores the plain attr weights)
+  PHASE();
   mvf<D>(T + L::T_W1J_TO, x, Pj);
   pass_rev<RS, 0, 2 * D, SLOT_OUT>(slots, nslots, lds, T + L::T_A_TO, -1.f, Pj, at);
   // IN slots: edge (n -> u) is an out-edge of n (Phi_from of n): Pf[n] at 10, dS_fr[n] at 30, attr = mirror of the slot's
 #pragma unroll
   for (int p = 0; p < 5; ++p) Pj[p] = splat2(0.f);
+  PHASE();
   mvf<D>(T + L::T_W1J_FR, x, Pj);
   pass_rev<RS, D, 3 * D, SLOT_IN>(slots, nslots, lds, T + L::T_A_FR, -1.f, Pj, af);
   if (PG) {  // neighbour-side cotangent sums: W1j gradients are sum_u acc[u] (x) x[u]
@@ -473,7 +493,9 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const
   for (int p = 0; p < 5; ++p) g[p] = (v2f){go[2 * p], go[2 * p + 1]};
   const float* Wto = W + lofs + L::L_TO;
   const float* Wfr = W + lofs + L::L_FROM;
+  PHASE();
   mvb<D>(Wto + L::PHI_W1, L::EIN, D, reinterpret_cast<const float*>(at), g);
+  PHASE();
   mvb<D>(Wfr + L::PHI_W1, L::EIN, D, reinterpret_cast<const float*>(af), g);
 #pragma unroll
   for (int p = 0; p < 5; ++p) {

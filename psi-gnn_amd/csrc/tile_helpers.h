@@ -14,6 +14,12 @@
 // 79 us instead of 67 us per 1M-node evaluation -- it costs a wave slot per workgroup for the whole residency.)
 #define TILE_THREADS 256
 
+// Compiler-level memory barrier between the phases of a kernel.  The tile kernels read > 1 000 wave-uniform weights;
+// fully unrolled, the compiler hoists all their scalar loads to the top and then spills hundreds of SGPRs into VGPR
+// lanes (v_writelane / v_readlane = VALU issue slots in VALU-issue-bound kernels).  The barrier keeps each phase's
+// scalar loads next to their use.
+#define PHASE() asm volatile("" ::: "memory")
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
