@@ -185,6 +185,14 @@ int psignn_dsgps_forward(const psignn_plan_t* plan, const float* d_weights, int 
 int psignn_dsgps_step_p(const psignn_plan_t* plan, const float* d_weights, const float* d_h, const float* d_h0,
                         const float* d_prb, float* d_out, void* stream);
 
+/* DSS, the Deep Statistical Solver baseline (dirichlet/dss/model.py:97-120): k updates with per-step weights
+ *   h <- h + alpha * Psi_t([h | Phi_to_t(h) | Phi_from_t(h) | b'_norm]),  H_0 = 0,
+ * on a tiled plan created with edge_attr = (0, 0, a_ij_norm) (the scalar edge feature of DSS).  d_weights:
+ * psignn_dss_weights_size(k) floats (layout in csrc/dss_tile.hip, built by engine.pack_dss); d_work: N * 23 floats. */
+int64_t psignn_dss_weights_size(int k);
+int psignn_dss_forward(const psignn_plan_t* plan, const float* d_weights, int k, float alpha, const float* d_bprime_norm,
+                       float* d_out, float* d_work, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Small dense pieces around the solve.
  * replaces: Encoder / Decoder MLPs (model.py:370-392), residual_loss SpMV (model.py:157-167).

@@ -428,3 +428,56 @@ def dsgps_inference(sd, batch, k, trace=False):
                 mse.append(float(F.mse_loss(u, batch.sol)))
         u = decoder(sd, h)
     return (u, h, res, mse) if trace else (u, h)
+
+
+# --------------------------------------------------------------------------------------
+# DSS: Deep Statistical Solver baseline (dirichlet/dss/model.py:25-147), SURVEY §8f-4
+# --------------------------------------------------------------------------------------
+def dss_batch(mesh):
+    """The DSS view of a Poisson problem (dirichlet/dataset/generate_data.py:100-128 + dss/utilities/reader.py:61-92):
+    graph = off-diagonal entries of A (Dirichlet rows are identity rows -> no out-edges), scalar edge feature a_ij
+    normalised with the reference constants, node input b' = (b, 0, 0) on interior rows / (0, 1, g) on Dirichlet rows."""
+    ei = mesh.edge_index
+    keep = ei[0] != ei[1]
+    a = mesh.a_ij.reshape(-1, 1)[keep]
+    diri = (mesh.tags.reshape(-1) == 1)
+    b = mesh.y.reshape(-1)
+    bp = torch.stack([torch.where(diri, torch.zeros_like(b), b), diri.to(b.dtype),
+                      torch.where(diri, b, torch.zeros_like(b))], dim=1)
+    mean = torch.tensor([0.0002, 0.1435, -0.0006], dtype=b.dtype)
+    std = torch.tensor([0.0507, 0.3506, 3.2935], dtype=b.dtype)
+    out = type(mesh)(x=mesh.sol, sol=mesh.sol, edge_index=ei[:, keep], a_ij=a, a_ij_norm=(a + 0.5838) / 0.0924,
+                     b_prime=bp, b_prime_norm=(bp - mean) / std, pos=mesh.pos, tags=mesh.tags)
+    return out
+
+
+def dss_residual_loss(U, edge_index, a_ij, y):
+    """dirichlet/dss/model.py:122-139."""
+    B0, B1, B2 = y[:, 0:1], y[:, 1:2], y[:, 2:3]
+    p1 = (1 - B1) * (-B0) + B1 * (U - B2)
+    fbar = a_ij * (U.index_select(0, edge_index[1]) - U.index_select(0, edge_index[0]))
+    s = torch.zeros_like(U).index_add_(0, edge_index[0], fbar)
+    return torch.mean((p1 + s) ** 2)
+
+
+def dss_step(sd, t, h, batch, alpha):
+    """Update t of ``DeepStatisticalSolver.inference`` (model.py:107-117): per-step Phi_to / Phi_from (edge input
+    [x_i | x_j | a_ij_norm], 21 wide) and Psi MLP on [h | mess_to | mess_from | b'_norm] (33 wide)."""
+    mess_to = phi(sd, f"phi_to_list.{t}", h, batch.edge_index, batch.a_ij_norm, "source_to_target")
+    mess_from = phi(sd, f"phi_from_list.{t}", h, batch.edge_index, batch.a_ij_norm, "target_to_source")
+    cat = torch.cat([h, mess_to, mess_from, batch.b_prime_norm], dim=1)
+    return h + alpha * _mlp(sd, f"psi_list.{t}.mlp", cat)
+
+
+def dss_inference(sd, batch, k, alpha, trace=False):
+    """``DeepStatisticalSolver.inference`` (model.py:97-120): H_0 = 0, k updates with per-step weights, U_k from the
+    k-th decoder."""
+    with torch.no_grad():
+        h = torch.zeros(batch.x.shape[0], sd["phi_to_list.0.mlp.mlp.2.bias"].numel(), dtype=batch.x.dtype)
+        res = []
+        for t in range(k):
+            h = dss_step(sd, t, h, batch, alpha)
+            if trace:
+                res.append(float(dss_residual_loss(_mlp(sd, f"decoder_list.{t}.mlp", h), batch.edge_index, batch.a_ij, batch.b_prime)))
+        u = _mlp(sd, f"decoder_list.{k - 1}.mlp", h)
+    return (u, h, res) if trace else (u, h)

@@ -1,0 +1,106 @@
+"""DSS, the Deep Statistical Solver baseline of the reference (dirichlet/dss/model.py:25-147), on the HIP tile kernels.
+
+``DeepStatisticalSolver(config)`` takes the reference's config (``latent_dim, k, alpha, gamma, path_logs``) and has the
+reference's module tree (``phi_to_list / phi_from_list / psi_list / decoder_list``, one set of weights per update), so
+``load_state_dict(ckpt["state_dict"])`` of ``dirichlet/dss/results/dss_results/ckpt/best_model.pt`` works unchanged.
+
+* ``inference(batch) -> U_k``   (model.py:97-120)
+* ``residual_loss(U, edge_index, a_ij, b_prime)``   (model.py:122-139), diagnostics only.
+
+``batch`` carries the DSS schema of ``dirichlet/dss/utilities/reader.py:61-92`` (``edge_index`` without self loops,
+``a_ij``, ``a_ij_norm``, ``b_prime``, ``b_prime_norm``, ``pos``); ``to_dss_batch(mesh)`` derives it from a PSI-GNN
+``MeshData`` the way ``dirichlet/dataset/generate_data.py:100-128`` derives ``A_prime / b_prime`` from ``A / b``.
+Training DSS (back-propagation through the k updates) is not implemented.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _native as nat
+from . import engine
+from .data.meshdata import MeshData
+from .model_psignn import MLP, Decoder, Phi_from, Phi_to
+
+AIJ_MEAN, AIJ_STD = -0.5838, 0.0924                      # reader.py:63-64
+B_MEAN, B_STD = (0.0002, 0.1435, -0.0006), (0.0507, 0.3506, 3.2935)   # reader.py:66-67
+
+
+def to_dss_batch(mesh) -> MeshData:
+    """A' = A without its diagonal (Dirichlet rows are identity rows: they keep no edge), b' = (b, 0, 0) on interior rows
+    and (0, 1, g) on Dirichlet rows, both normalised with the reference's constants."""
+    ei = mesh.edge_index
+    keep = ei[0] != ei[1]
+    a = mesh.a_ij.reshape(-1, 1)[keep]
+    diri = mesh.tags.reshape(mesh.tags.shape[0], -1)[:, 0] == 1
+    b = mesh.y.reshape(-1)
+    zero = torch.zeros_like(b)
+    bp = torch.stack([torch.where(diri, zero, b), diri.to(b.dtype), torch.where(diri, b, zero)], dim=1)
+    mean = torch.tensor(B_MEAN, dtype=b.dtype, device=b.device)
+    std = torch.tensor(B_STD, dtype=b.dtype, device=b.device)
+    return MeshData(x=mesh.sol, sol=mesh.sol, edge_index=ei[:, keep], a_ij=a, a_ij_norm=(a - AIJ_MEAN) / AIJ_STD,
+                    b_prime=bp, b_prime_norm=(bp - mean) / std, pos=mesh.pos, tags=mesh.tags)
+
+
+class Psi(nn.Module):
+    def __init__(self, hidden_channels=None, activation=None):
+        super().__init__()
+        self.mlp = MLP(hidden_channels, activation)
+
+
+class DeepStatisticalSolver(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = dict(config)
+        d, k = self.config["latent_dim"], self.config["k"]
+        if d != engine.D:
+            raise nat.NativeError(f"HIP kernels are built for latent_dim = {engine.D}")
+        self.phi_to_list = nn.ModuleList([Phi_to([2 * d + 1, d, d], nn.ReLU()) for _ in range(k)])
+        self.phi_from_list = nn.ModuleList([Phi_from([2 * d + 1, d, d], nn.ReLU()) for _ in range(k)])
+        self.psi_list = nn.ModuleList([Psi([3 * d + 3, d, d], nn.ReLU()) for _ in range(k)])
+        self.decoder_list = nn.ModuleList([Decoder([d, d, 1], nn.ReLU()) for _ in range(k)])
+        self.mse_loss = nn.MSELoss()
+        self._packed, self._packed_key = None, None
+
+    def packed(self, device):
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed_key != key:
+            self._packed = engine.pack_dss(self.state_dict(), self.config["k"], device)
+            self._packed_key = key
+        return self._packed
+
+    @staticmethod
+    def _plan(batch):
+        """Mesh plan of the DSS graph: the scalar edge feature rides in the third edge_attr column."""
+        plan = getattr(batch, "_dss_plan", None)
+        if plan is None:
+            z = torch.zeros((batch.a_ij_norm.shape[0], 2), dtype=torch.float32, device=batch.a_ij_norm.device)
+            view = MeshData(x=batch.x, edge_index=batch.edge_index, a_ij=batch.a_ij,
+                            edge_attr=torch.cat([z, batch.a_ij_norm.reshape(-1, 1).float()], dim=1).contiguous(),
+                            tags=torch.zeros((batch.x.shape[0], 1), dtype=torch.float32, device=batch.x.device),
+                            pos=batch.pos)
+            plan = engine.MeshPlan(view)
+            batch._dss_plan = plan
+        return plan
+
+    @torch.no_grad()
+    def latent(self, batch, k=None):
+        nat.require_cuda(batch.x, "batch.x")
+        k = self.config["k"] if k is None else k
+        if not 1 <= k <= self.config["k"]:
+            raise nat.NativeError("DSS has one set of weights per update: 1 <= k <= config['k']")
+        return engine.dss_forward(self._plan(batch), self.packed(batch.x.device), batch.b_prime_norm, k, self.config["alpha"])
+
+    @torch.no_grad()
+    def inference(self, batch):
+        k = self.config["k"]
+        return self.decoder_list[k - 1](self.latent(batch, k))
+
+    @torch.no_grad()
+    def residual_loss(self, U, edge_index, a_ij, y):
+        """model.py:122-139: mean(((1 - B1)(-B0) + B1 (U - B2) + sum_j a_ij (U_j - U_i))^2)."""
+        B0, B1, B2 = y[:, 0:1], y[:, 1:2], y[:, 2:3]
+        p1 = (1 - B1) * (-B0) + B1 * (U - B2)
+        fbar = a_ij * (U.index_select(0, edge_index[1]) - U.index_select(0, edge_index[0]))
+        s = torch.zeros_like(U).index_add_(0, edge_index[0], fbar)
+        return torch.mean((p1 + s) ** 2)

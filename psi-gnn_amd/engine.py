@@ -443,6 +443,42 @@ def dsgps_step_p(plan: "MeshPlan", wflat, hp, h0p, prbp):
     return out
 
 
+def pack_dss(sd, k, device=None) -> torch.Tensor:
+    """Flat per-step weight buffer of the DSS kernels from a ``DeepStatisticalSolver`` state_dict
+    (dirichlet/dss/model.py:33-55; layout in csrc/dss_tile.hip)."""
+    m = lambda n: sd[n].detach().to("cpu", torch.float32)
+    t = lambda a: a.t().contiguous().reshape(-1)
+    z20 = torch.zeros(2 * D)
+    steps = []
+    for s in range(k):
+        Wt, Wf = m(f"phi_to_list.{s}.mlp.mlp.0.weight"), m(f"phi_from_list.{s}.mlp.mlp.0.weight")
+        if Wt.shape != (D, 2 * D + 1) or m(f"psi_list.{s}.mlp.mlp.0.weight").shape != (D, 3 * D + 3):
+            raise nat.NativeError("DSS kernels are built for latent_dim = 10, a scalar edge feature and a 3-wide node input")
+        steps += [t(Wt[:, D:2 * D]), t(Wf[:, D:2 * D]), t(Wt[:, :D]), t(Wf[:, :D]),
+                  z20, Wt[:, 2 * D], z20, Wf[:, 2 * D],
+                  m(f"phi_to_list.{s}.mlp.mlp.0.bias"), m(f"phi_from_list.{s}.mlp.mlp.0.bias"),
+                  t(m(f"phi_to_list.{s}.mlp.mlp.2.weight")), m(f"phi_to_list.{s}.mlp.mlp.2.bias"),
+                  t(m(f"phi_from_list.{s}.mlp.mlp.2.weight")), m(f"phi_from_list.{s}.mlp.mlp.2.bias"),
+                  t(m(f"psi_list.{s}.mlp.mlp.0.weight")), m(f"psi_list.{s}.mlp.mlp.0.bias"),
+                  t(m(f"psi_list.{s}.mlp.mlp.2.weight")), m(f"psi_list.{s}.mlp.mlp.2.bias")]
+    flat = torch.cat([p.reshape(-1) for p in steps]).contiguous()
+    if flat.numel() != int(nat.lib().psignn_dss_weights_size(int(k))):
+        raise nat.NativeError(f"packed DSS weight length {flat.numel()} != native layout")
+    return flat if device is None else flat.to(device)
+
+
+def dss_forward(plan: "MeshPlan", wflat, bprime_norm, k: int, alpha: float):
+    """H_k of ``DeepStatisticalSolver.inference`` (model.py:97-120) from H_0 = 0."""
+    nat.require_cuda(bprime_norm, "b_prime_norm")
+    bc = _f32c(bprime_norm)
+    out = torch.empty((plan.N, D), dtype=torch.float32, device=bc.device)
+    work = torch.empty(23 * plan.N, dtype=torch.float32, device=bc.device)
+    with torch.cuda.device(bc.device):
+        nat.check(nat.lib().psignn_dss_forward(plan.handle, nat.ptr(wflat), int(k), float(alpha), nat.ptr(bc), nat.ptr(out),
+                                               nat.ptr(work), nat.stream_ptr(bc.device)), "psignn_dss_forward")
+    return out
+
+
 def unpack_param_grads(flat, n_layers=1, mixed=False):
     """Name the entries of a flat parameter gradient (layout = leading section of ``pack_weights``)."""
     if n_layers != 1:
