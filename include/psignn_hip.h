@@ -143,6 +143,10 @@ int psignn_f_vjp(const psignn_plan_t* plan, const float* d_weights, int n_layers
                  const float* d_prb, const float* d_normals, const float* d_w, float* d_out, float* d_work,
                  void* stream);
 
+/* JVP with h, prb, v and out in plan order (tiled single-layer dirichlet plans; the tiled LDS-staged kernel). */
+int psignn_f_jvp_p(const psignn_plan_t* plan, const float* d_weights, int n_layers, const float* d_h, const float* d_prb,
+                   const float* d_v, float* d_out, void* stream);
+
 /* Same with h, prb, w and out in plan order (tiled kernels where the plan has tiles; the form the adjoint solve uses). */
 int psignn_f_vjp_p(const psignn_plan_t* plan, const float* d_weights, int n_layers, const float* d_h,
                    const float* d_prb, const float* d_normals, const float* d_w, float* d_out, float* d_work,

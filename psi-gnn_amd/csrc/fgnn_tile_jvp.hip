@@ -1,0 +1,258 @@
+// Tiled Jacobian-vector product of f_theta (dirichlet family, single layer), plan order (gfx950).
+//
+// out = J_f(h) v: what the Newton-Krylov solver of BASELINE configs[4] needs once per inner iteration (the reference only
+// imports scipy's newton_krylov, utilities/solver.py:6; its finite-difference JVPs do not converge in fp32).
+// Same mathematics as the global-gather JVP of fgnn.hip (k_project / k_node with JVP = true) on the tile structures:
+//   stage 1  projects BOTH the state row and the tangent row of every tile + halo node with the neighbour-side weights
+//            -> 160-byte LDS row [Pj_to | Pj_from | dPj_to | dPj_from];
+//   stage 2  per node and direction, one walk over the pair-merged slots:  z = Pi + Pj + A a,  S += relu(z),
+//            dS += 1[z > 0] (dPi + dPj);  then the tangent of the folded gate / update MLP and of LayerNorm.
+// Dirichlet rows of f are constants: their tangent is 0.
+#include "tile_helpers.h"
+
+__device__ __forceinline__ void lds_row10(const float* __restrict__ row, v2f* r) {  // 16-byte aligned
+  float4 v0 = reinterpret_cast<const float4*>(row)[0], v1 = reinterpret_cast<const float4*>(row)[1];
+  float2 v2 = reinterpret_cast<const float2*>(row)[4];
+  r[0] = (v2f){v0.x, v0.y}; r[1] = (v2f){v0.z, v0.w}; r[2] = (v2f){v1.x, v1.y}; r[3] = (v2f){v1.z, v1.w};
+  r[4] = (v2f){v2.x, v2.y};
+}
+__device__ __forceinline__ void lds_row10u(const float* __restrict__ row, v2f* r) {  // 8 mod 16
+  float2 v0 = reinterpret_cast<const float2*>(row)[0];
+  float4 v1 = reinterpret_cast<const float4*>(row + 2)[0], v2 = reinterpret_cast<const float4*>(row + 2)[1];
+  r[0] = (v2f){v0.x, v0.y}; r[1] = (v2f){v1.x, v1.y}; r[2] = (v2f){v1.z, v1.w}; r[3] = (v2f){v2.x, v2.y};
+  r[4] = (v2f){v2.z, v2.w};
+}
+
+// S[o] += relu(z), dS[o] += 1[z > 0] (dPi[o] + row[DCOL + o]) over the slots carrying MASK; z = Pi + row[COL..] + AT . a
+template <int RS, int COL, int DCOL, unsigned MASK>
+__device__ __forceinline__ float edge_pass_jvp(const uint4* __restrict__ slots, int nslots, const float* __restrict__ lds,
+                                               const float* __restrict__ AT, const v2f* Pi, const v2f* dPi, v2f* S, v2f* dS) {
+  float deg = 0.f;
+  v2f wa[15];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) wa[i] = reinterpret_cast<const v2f*>(AT)[i];
+  if (nslots <= 0) return deg;
+  uint4 c0 = slots[0];
+  uint4 c1 = slots[(int64_t)min(1, nslots - 1) * 64];
+  for (int r = 0; r < nslots; ++r) {
+    const uint4 nx = slots[(int64_t)min(r + 2, nslots - 1) * 64];
+    const unsigned w = c0.x;
+    if ((w & 0xFFFFu) != ELL_EMPTY && (w & MASK)) {
+      const v2f a0 = splat(__uint_as_float(c0.y)), a1 = splat(__uint_as_float(c0.z)), a2 = splat(__uint_as_float(c0.w));
+      const float* row = lds + (int)(w & 0xFFFFu) * RS;
+      v2f pj[5], dpj[5], z[5];
+      if (COL % 4 == 0) lds_row10(row + COL, pj); else lds_row10u(row + COL, pj);
+      if (DCOL % 4 == 0) lds_row10(row + DCOL, dpj); else lds_row10u(row + DCOL, dpj);
+      deg += 1.f;
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = Pi[p] + pj[p];
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[p], a0, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[5 + p], a1, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[10 + p], a2, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) {
+        S[p] += __builtin_elementwise_max(z[p], splat(0.f));
+        const v2f t = dPi[p] + dpj[p];
+        dS[p] += (v2f){z[p].x > 0.f ? t.x : 0.f, z[p].y > 0.f ? t.y : 0.f};
+      }
+    }
+    c0 = c1;
+    c1 = nx;
+  }
+  return deg;
+}
+
+template <int P>
+__global__ __launch_bounds__(TILE_THREADS) void k_jvp_tile(int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
+                                                           const int32_t* __restrict__ tile_slice,
+                                                           const int32_t* __restrict__ halo, const int32_t* __restrict__ halo_cnt,
+                                                           const int32_t* __restrict__ slice_off,
+                                                           const uint8_t* __restrict__ slice_deg, const uint4* __restrict__ ell,
+                                                           const uint8_t* __restrict__ flags, const float* __restrict__ W, int lofs,
+                                                           int tofs, const float* __restrict__ h, const float* __restrict__ prb,
+                                                           const float* __restrict__ tv, float* __restrict__ out) {
+  using L = WLayout<P>;
+  constexpr int RS = 40;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (tile >= n_tiles) return;
+  const int tid = threadIdx.x;
+  const int32_t t0 = tile_ptr[tile];
+  const int n_t = tile_ptr[tile + 1] - t0;
+  const int n_h = halo_cnt[tile];
+  const int32_t* hl = halo + (int64_t)tile * HALO_CAP;
+  const float* T = W + tofs;
+  // ---- stage 1
+  float x[D], dx[D];
+  for (int row = tid; row < n_t + n_h; row += TILE_THREADS) {
+    const int64_t node = row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t];
+    float xr[D], vr[D];
+    load10(h + node * D, xr);
+    load10(tv + node * D, vr);
+    if (row == tid) {
+#pragma unroll
+      for (int o = 0; o < D; ++o) {
+        x[o] = xr[o];
+        dx[o] = vr[o];
+      }
+    }
+    v2f ta[5], tb[5], da[5], db[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) ta[p] = tb[p] = da[p] = db[p] = splat(0.f);
+    PHASE();
+    mv2<D>(T + L::T_W1J_TO, xr, ta);
+    mv2<D>(T + L::T_W1J_TO, vr, da);
+    PHASE();
+    mv2<D>(T + L::T_W1J_FR, xr, tb);
+    mv2<D>(T + L::T_W1J_FR, vr, db);
+    float4* q = reinterpret_cast<float4*>(lds + row * RS);
+    q[0] = make_float4(ta[0].x, ta[0].y, ta[1].x, ta[1].y);
+    q[1] = make_float4(ta[2].x, ta[2].y, ta[3].x, ta[3].y);
+    q[2] = make_float4(ta[4].x, ta[4].y, tb[0].x, tb[0].y);
+    q[3] = make_float4(tb[1].x, tb[1].y, tb[2].x, tb[2].y);
+    q[4] = make_float4(tb[3].x, tb[3].y, tb[4].x, tb[4].y);
+    q[5] = make_float4(da[0].x, da[0].y, da[1].x, da[1].y);
+    q[6] = make_float4(da[2].x, da[2].y, da[3].x, da[3].y);
+    q[7] = make_float4(da[4].x, da[4].y, db[0].x, db[0].y);
+    q[8] = make_float4(db[1].x, db[1].y, db[2].x, db[2].y);
+    q[9] = make_float4(db[3].x, db[3].y, db[4].x, db[4].y);
+  }
+  __syncthreads();
+  if (tid >= n_t) return;
+  const int64_t n = (int64_t)t0 + tid;
+  float dy[D];
+  if (flags[n] & FLAG_DIRICHLET) {
+#pragma unroll
+    for (int o = 0; o < D; ++o) dy[o] = 0.f;
+    store10(out + n * D, dy);
+    return;
+  }
+  const int lane = tid & 63;
+  const int slice = tile_slice[tile] + (tid >> 6);
+  const uint4* slots = ell + (int64_t)slice_off[slice] * 64 + lane;
+  const int nslots = slice_deg[slice];
+  // ---- stage 2: neighbour sums and their tangents
+  v2f Pi[5], dPi[5], S_to[5], S_fr[5], dS_to[5], dS_fr[5];
+  ld5(T + L::T_B1_TO, Pi);
+#pragma unroll
+  for (int p = 0; p < 5; ++p) S_to[p] = S_fr[p] = dS_to[p] = dS_fr[p] = dPi[p] = splat(0.f);
+  PHASE();
+  mv2<D>(T + L::T_W1I_TO, x, Pi);
+  mv2<D>(T + L::T_W1I_TO, dx, dPi);
+  const float deg_in = edge_pass_jvp<RS, 0, 2 * D, SLOT_IN>(slots, nslots, lds, T + L::T_A_TO, Pi, dPi, S_to, dS_to);
+  ld5(T + L::T_B1_FR, Pi);
+#pragma unroll
+  for (int p = 0; p < 5; ++p) dPi[p] = splat(0.f);
+  PHASE();
+  mv2<D>(T + L::T_W1I_FR, x, Pi);
+  mv2<D>(T + L::T_W1I_FR, dx, dPi);
+  const float deg_out = edge_pass_jvp<RS, D, 3 * D, SLOT_OUT>(slots, nslots, lds, T + L::T_A_FR, Pi, dPi, S_fr, dS_fr);
+  // ---- gate and update MLP (second Phi layer folded), values and tangents
+  const float* Wf = W + lofs + L::L_FOLD;
+  const float* Wa = W + L::AL_W;
+  const float* sto = reinterpret_cast<const float*>(S_to);
+  const float* sfr = reinterpret_cast<const float*>(S_fr);
+  const float* dsto = reinterpret_cast<const float*>(dS_to);
+  const float* dsfr = reinterpret_cast<const float*>(dS_fr);
+  float pq[P];
+#pragma unroll
+  for (int k = 0; k < P; ++k) pq[k] = prb[n * P + k];
+  PHASE();
+  float al = fmaf(deg_in, Wf[L::F_ABTO], fmaf(deg_out, Wf[L::F_ABFR], W[L::AL_B])), dal = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    al = fmaf(Wa[k], x[k], al);
+    dal = fmaf(Wa[k], dx[k], dal);
+  }
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    al = fmaf(Wf[L::F_ATO + k], sto[k], al);
+    dal = fmaf(Wf[L::F_ATO + k], dsto[k], dal);
+  }
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    al = fmaf(Wf[L::F_AFR + k], sfr[k], al);
+    dal = fmaf(Wf[L::F_AFR + k], dsfr[k], dal);
+  }
+#pragma unroll
+  for (int k = 0; k < P; ++k) al = fmaf(Wa[3 * D + k], pq[k], al);
+  al = 1.f / (1.f + expf(-al));
+  dal *= al * (1.f - al);
+  v2f q[5], dq[5], g1[5], g2[5], upd[5], dupd[5];
+  ld5(T + L::T_HB, q);
+  ld5(T + L::T_gTO, g1);
+  ld5(T + L::T_gFR, g2);
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    q[p] = __builtin_elementwise_fma(splat(deg_in), g1[p], __builtin_elementwise_fma(splat(deg_out), g2[p], q[p]));
+    dq[p] = dupd[p] = splat(0.f);
+  }
+  PHASE();
+  mv2<D>(T + L::T_U1H, x, q);
+  mv2<D>(T + L::T_U1H, dx, dq);
+  PHASE();
+  mv2<D>(T + L::T_GTO, sto, q);
+  mv2<D>(T + L::T_GTO, dsto, dq);
+  PHASE();
+  mv2<D>(T + L::T_GFR, sfr, q);
+  mv2<D>(T + L::T_GFR, dsfr, dq);
+  mv2<P>(T + L::T_U1P, pq, q);
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    dq[p] = (v2f){q[p].x > 0.f ? dq[p].x : 0.f, q[p].y > 0.f ? dq[p].y : 0.f};
+    q[p] = __builtin_elementwise_max(q[p], splat(0.f));
+  }
+  ld5(T + L::T_C2, upd);
+  PHASE();
+  mv2<D>(T + L::T_U2, reinterpret_cast<const float*>(q), upd);
+  mv2<D>(T + L::T_U2, reinterpret_cast<const float*>(dq), dupd);
+  const float* u = reinterpret_cast<const float*>(upd);
+  const float* du = reinterpret_cast<const float*>(dupd);
+  float y[D], mu = 0.f;
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    y[o] = fmaf(al, u[o], x[o]);
+    dy[o] = dx[o] + dal * u[o] + al * du[o];
+    mu += y[o];
+  }
+  // ---- LayerNorm tangent (eps 1e-5, biased variance)
+  mu *= (1.f / D);
+  float var = 0.f;
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    const float c = y[o] - mu;
+    var = fmaf(c, c, var);
+  }
+  var *= (1.f / D);
+  const float rs = 1.f / sqrtf(var + 1e-5f);
+  float dm = 0.f, yd = 0.f;
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    y[o] = (y[o] - mu) * rs;
+    dm += dy[o];
+    yd = fmaf(y[o], dy[o], yd);
+  }
+  dm *= (1.f / D);
+  yd *= (1.f / D);
+#pragma unroll
+  for (int o = 0; o < D; ++o) dy[o] = W[L::LN_G + o] * rs * (dy[o] - dm - y[o] * yd);
+  store10(out + n * D, dy);
+}
+
+// h, prb, v, out in PLAN order.
+int psignn_f_tile_jvp(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* v,
+                      float* out, hipStream_t st) {
+  ARG_CHECK(p && p->tiled && !p->mixed && nl == 1, "tiled JVP: dirichlet single-layer plans only");
+  using L = WLayout<2>;
+  const int chunk = (int)cdiv(p->n_tiles, 8);
+  const size_t lds = (size_t)p->max_rows * 40 * 4;
+  ARG_CHECK(lds <= 160 * 1024, "tile + halo rows exceed the LDS budget of the tiled JVP");
+  LAUNCH("k_jvp_tile", st, (k_jvp_tile<2><<<(unsigned)(chunk * 8), TILE_THREADS, lds, st>>>(
+      (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
+      p->flags_p, W, L::layer(0), L::tp_layer(nl, false, 0), h, prb, v, out)));
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}

@@ -328,6 +328,19 @@ class FixedPointMap:
                                              nat.stream_ptr(Hc.device)), "psignn_f_jvp")
         return out
 
+    def jvp_p(self, Hp, Vp):
+        """J_f(Hp) Vp with everything in plan order (tiled single-layer dirichlet plans)."""
+        if self._p is None:
+            self.fp(Hp)
+        _, prbp, _ = self._p
+        Hc, Vc = _f32c(Hp), _f32c(Vp)
+        out = torch.empty_like(Hc)
+        with torch.cuda.device(Hc.device):
+            nat.check(nat.lib().psignn_f_jvp_p(self.plan.handle, nat.ptr(self.weights.flat), self.weights.n_layers,
+                                               nat.ptr(Hc), nat.ptr(prbp), nat.ptr(Vc), nat.ptr(out),
+                                               nat.stream_ptr(Hc.device)), "psignn_f_jvp_p")
+        return out
+
     def vjp(self, H, Wv):
         """Wv^T J_f(H): what ``autograd.grad(f(H), H, Wv)`` returns in the reference (model.py:214,432,449)."""
         Hc, Wc = _f32c(H), _f32c(Wv)

@@ -191,8 +191,13 @@ def newton_krylov(f, x0, threshold=30, eps=1e-5, inner_m=30, inner_tol=1e-2, **k
     if not isinstance(f, FixedPointMap):
         raise nat.NativeError("newton_krylov needs the analytic JVP of a FixedPointMap")
     nat.require_cuda(x0, "x0")
-    x = x0.clone()
-    fx = f(x)
+    # tiled single-layer dirichlet plans: the whole iteration in plan order on the tiled f / JVP kernels (norms and
+    # inner products do not depend on the node numbering); results are returned in the caller's numbering
+    plan_mode = f.plan.tiled and not f.weights.mixed and f.weights.n_layers == 1
+    F, J = (f.fp, f.jvp_p) if plan_mode else (f, f.jvp)
+    back = f.from_plan if plan_mode else (lambda t: t)
+    x = f.to_plan(x0) if plan_mode else x0.clone()
+    fx = F(x)
     g = fx - x
     trace = {"abs": [], "rel": []}
     n_feval = 1
@@ -210,7 +215,7 @@ def newton_krylov(f, x0, threshold=30, eps=1e-5, inner_m=30, inner_tol=1e-2, **k
         Hm = torch.zeros(m + 1, m, device=b.device, dtype=b.dtype)
         V[0] = b / beta
         for k in range(m):
-            w = (f.jvp(x, V[k].reshape(x.shape)) - V[k].reshape(x.shape)).reshape(-1)
+            w = (J(x, V[k].reshape(x.shape)) - V[k].reshape(x.shape)).reshape(-1)
             n_feval += 1
             h = V[:k + 1] @ w                      # classical Gram-Schmidt, twice
             w = w - h @ V[:k + 1]
@@ -225,7 +230,7 @@ def newton_krylov(f, x0, threshold=30, eps=1e-5, inner_m=30, inner_tol=1e-2, **k
         y = torch.linalg.lstsq(Hm.double().cpu(), e1.cpu()).solution[:, 0].to(b.device, b.dtype)
         dx = (y @ V[:m]).reshape(x.shape)
         x = x + dx
-        fx = f(x)
+        fx = F(x)
         n_feval += 1
         g = fx - x
         abs_diff = torch.linalg.norm(g).item()
@@ -237,6 +242,6 @@ def newton_krylov(f, x0, threshold=30, eps=1e-5, inner_m=30, inner_tol=1e-2, **k
             lowest, lowest_x, lowest_step = rel_diff, x, nstep
         if rel_diff < eps:
             break
-    return {"result": lowest_x, "lowest": lowest, "nstep": lowest_step, "prot_break": False,
-            "abs_trace": trace["abs"], "rel_trace": trace["rel"], "xest_trace": xest_trace, "eps": eps,
+    return {"result": back(lowest_x), "lowest": lowest, "nstep": lowest_step, "prot_break": False,
+            "abs_trace": trace["abs"], "rel_trace": trace["rel"], "xest_trace": [back(t) for t in xest_trace], "eps": eps,
             "threshold": threshold, "n_feval": n_feval, "n_outer": nstep}

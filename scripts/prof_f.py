@@ -42,7 +42,7 @@ if len(sys.argv) > 5 and sys.argv[5] == "adjoint":
     V = torch.randn_like(H)
     Vp = fm.to_plan(V)
     for name, fn in (("jvp", lambda: fm.jvp(H, V)), ("vjp", lambda: fm.vjp(H, V)), ("f (caller order)", lambda: fm(H)),
-                     ("vjp_p (plan order)", lambda: fm.vjp_p(x, Vp))):
+                     ("vjp_p (plan order)", lambda: fm.vjp_p(x, Vp)), ("jvp_p (plan order)", lambda: fm.jvp_p(x, Vp))):
         fn(); torch.cuda.synchronize()
         t0.record()
         for _ in range(reps):

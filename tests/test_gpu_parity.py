@@ -568,6 +568,27 @@ def test_tiled_vjp_equals_gather_vjp(name, dev):
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
 
 
+@pytest.mark.parametrize("name", ["original_dirichlet_s0", "hex26_dirichlet_s0"])
+def test_tiled_jvp_equals_gather_jvp(name, dev):
+    """Tiled JVP (state and tangent rows staged in LDS) vs the global-gather JVP on an untiled plan and vs fp64 autograd;
+    plan-order entry point; other tile sizes."""
+    g, mesh, md, sd, fmap = bind(name, dev)
+    eng = pkg("engine")
+    flat = eng.FixedPointMap(eng.MeshPlan(md, tile_target=-1), fmap.weights, fmap.h0, md.prb_data, None)
+    x = torch.from_numpy(g["f1"]).to(dev)
+    v = torch.randn(x.shape, generator=torch.Generator().manual_seed(13)).to(dev)
+    a, b = fmap.jvp(x, v), flat.jvp(x, v)
+    want = orc.function_jvp({k: t.double() for k, t in sd.items()}, x.cpu().double(), torch.from_numpy(g["h0"]).double(),
+                            type(mesh)(**{f: (getattr(mesh, f).double() if getattr(mesh, f).is_floating_point() else getattr(mesh, f))
+                                          for f in mesh.keys()}), v.cpu().double())
+    assert rel_l2(a, want) < 1e-5 and rel_l2(b, want) < 1e-5
+    assert rel_l2(a, b) < 2e-6
+    assert torch.equal(fmap.from_plan(fmap.jvp_p(fmap.to_plan(x), fmap.to_plan(v))), a)
+    for tt in (32, 100):
+        fm = eng.FixedPointMap(eng.MeshPlan(md, tile_target=tt), fmap.weights, fmap.h0, md.prb_data, None)
+        assert rel_l2(fm.jvp(x, v), a) < 1e-6, tt
+
+
 def test_implicit_backward_solve(dev):
     """The reference's backward hook solves y = J^T y + grad with the forward solver (model.py:210-223).  Same
     solve on the VJP kernel vs the oracle (autograd VJP + restated broyden): both reach the adjoint fixed point."""
