@@ -222,7 +222,16 @@ class DeepEquilibrium(nn.Module):
         fmap = self.f.bind(H_init, batch)
         g = grad.contiguous()
         if self.config_deq["solver"] is _solver.broyden:  # whole adjoint solve on the device
-            sv = engine.DeviceBroyden(plan=fmap.plan, threshold=self.config_deq["bw_thres"], keep_trace=False)
+            # the solver state (2 * bw_thres * N * d floats) is kept between calls on the same plan: a training loop
+            # would otherwise allocate and free it once per step
+            key = (fmap.plan, self.config_deq["bw_thres"])
+            old = getattr(self, "_bw_key", None)
+            if old is None or old[0] is not key[0] or old[1] != key[1]:
+                if getattr(self, "_bw_solver", None) is not None:
+                    self._bw_solver.close()
+                self._bw_solver = engine.DeviceBroyden(plan=fmap.plan, threshold=self.config_deq["bw_thres"], keep_trace=False)
+                self._bw_key = key
+            sv = self._bw_solver
             out = sv.solve_adjoint(fmap, H_star, g, self.config_deq["bw_tol"])
             out.update(eps=self.config_deq["bw_tol"], threshold=self.config_deq["bw_thres"])
             return out

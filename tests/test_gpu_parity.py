@@ -385,6 +385,56 @@ def test_full_size_properties(dev):
     assert out["rel_trace"][39] < out["rel_trace"][0]
 
 
+def test_full_size_adjoint_and_gradient_properties(dev):
+    """BASELINE configs[4] size (1 000 519 nodes), tiled kernels, size-independent properties of the adjoint side:
+    <w, J v> = <J^T w, v> (JVP vs VJP kernels), linearity, bitwise reproducibility, zero tangent / cotangent flow on
+    Dirichlet rows, and the parameter-VJP: reproducible, linear in the cotangent, consistent with a finite difference of
+    <w, f_theta(h)> along one weight tensor (the fold / transposed sections are rebuilt by pack_weights)."""
+    data, eng = pkg("data"), pkg("engine")
+    sd = load_weights("dirichlet")
+    mesh = data.make_hex_problem(577, seed=0, compute_sol=False)
+    assert mesh.num_nodes == 1000519
+    md = mesh.to(dev)
+    P = "autoencoder.encoder.mlp.mlp."
+    h0 = eng.mlp2(md.x, *[sd[P + k].to(dev) for k in ("0.weight", "0.bias", "2.weight", "2.bias")])
+    fm = eng.FixedPointMap(eng.MeshPlan(md), eng.PackedWeights(sd, dev), h0, md.prb_data)
+    assert fm.plan.tiled
+    gen = torch.Generator(device=dev).manual_seed(3)
+    xp = fm.fp(fm.fp(fm.to_plan(h0)))
+    v = torch.randn(xp.shape, device=dev, generator=gen)
+    w = torch.randn(xp.shape, device=dev, generator=gen)
+    jv, wj = fm.jvp_p(xp, v), fm.vjp_p(xp, w)
+    lhs, rhs = float((w.double() * jv.double()).sum()), float((wj.double() * v.double()).sum())
+    assert abs(lhs - rhs) < 1e-4 * abs(lhs), (lhs, rhs)
+    assert torch.equal(jv, fm.jvp_p(xp, v)) and torch.equal(wj, fm.vjp_p(xp, w))
+    assert rel_l2(fm.vjp_p(xp, 2.5 * w), 2.5 * wj) < 1e-6
+    dmask = fm.to_plan((md.tags == 1).float().expand(-1, 10).contiguous()) > 0
+    assert float(jv[dmask].abs().max()) == 0.0                      # Dirichlet rows of f are constants
+    w0 = torch.where(dmask, w, torch.zeros_like(w))                 # cotangent on Dirichlet rows only -> nothing flows
+    assert float(fm.vjp_p(xp, w0).abs().max()) == 0.0
+    x = fm.from_plan(xp)
+    wc = fm.from_plan(w)
+    g1, _ = fm.param_vjp(x, wc)
+    g2, _ = fm.param_vjp(x, wc)
+    assert all(torch.equal(g1[k], g2[k]) for k in g1)
+    g3, _ = fm.param_vjp(x, -0.5 * wc)
+    for k in g1:
+        assert float((g3[k] + 0.5 * g1[k]).norm()) <= 1e-5 * float(g1[k].norm()) + 1e-12, k
+    # directional finite difference along update_list.0.mlp.2.bias (c2): d<w, f>/dc2 . e = <grad_c2, e>
+    key = "deqdss.f.update_list.0.mlp.2.bias"
+    e = torch.randn(10, generator=torch.Generator().manual_seed(4))
+    eps = 1e-2
+    vals = []
+    for sgn in (+1.0, -1.0):
+        sd2 = dict(sd)
+        sd2[key] = sd[key] + sgn * eps * e
+        f2 = eng.FixedPointMap(fm.plan, eng.PackedWeights(sd2, dev), h0, md.prb_data)
+        vals.append(float((wc.double() * f2(x).double()).sum()))
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    an = float((g1["update_list.0.mlp.2.bias"].cpu().double() * e.double()).sum())
+    assert abs(fd - an) < 2e-2 * abs(an) + 1e-3, (fd, an)
+
+
 # ------------------------------------------------------------------------------------------ tiled plan
 @pytest.mark.parametrize("name,target", [("original_dirichlet_s0", 0), ("hex13_mixed_s1", 64), ("hex26_dirichlet_s0", 0),
                                          ("hex26_dirichlet_s0", 256)])
