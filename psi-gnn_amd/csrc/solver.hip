@@ -50,6 +50,8 @@ struct psignn_broyden {
   float *U = nullptr, *V = nullptr;
   float* xbuf = nullptr;    // (thr+2, M) with trace, else (3, M)
   float *gx = nullptr, *dg = nullptr, *upd = nullptr, *fx = nullptr, *fwork = nullptr;
+  float* nrm_part = nullptr;  // norm partials of the f / residual kernel: 2 * nn floats
+  int nn_cap = 0;
   float *h0p = nullptr, *prbp = nullptr, *nrmp = nullptr;  // plan-order copies of h_initial, prb_data, normals
   float* part = nullptr;    // (3, thr, npart) dot partials; reused for the norm / s,beta partials
   float* coef = nullptr;    // (3, thr)
@@ -241,10 +243,8 @@ __device__ double block_sum_partials(const float* __restrict__ p, int n, double*
 
 // One block: finish the norms, append to the traces, track the lowest iterate, run the stop tests
 // (solver.py:160-183) and rotate the iterate buffers.
-__global__ __launch_bounds__(TB) void k_check(Status* st, const float* __restrict__ part, int npart,
-                                              double* __restrict__ rel_trace, double* __restrict__ abs_trace,
-                                              double eps, int thr, int seq_len, int keep_trace) {
-  __shared__ double sh[TB];
+__device__ void check_block(Status* st, const float* __restrict__ part, int npart, double* __restrict__ rel_trace,
+                            double* __restrict__ abs_trace, double eps, int thr, int seq_len, int keep_trace, double* sh) {
   if (st->done) return;
   double sg = block_sum_partials(part, npart, sh);
   double sf = block_sum_partials(part + npart, npart, sh);
@@ -349,12 +349,23 @@ __global__ __launch_bounds__(TB) void k_dots(int64_t M, int k, const Status* __r
   }
 }
 
-// coef[c][j] = sum of partials; grid = (k, 3)
-__global__ __launch_bounds__(TB) void k_reduce(const Status* __restrict__ st, const float* __restrict__ part, int npart,
-                                               int thr, float* __restrict__ coef) {
+// One launch after the dots pass, grid = (max(k, 1), 4):
+//   blocks (j, c < 3), j < k: coef[c][j] = sum of the dots partials;
+//   block (0, 3): the iteration's bookkeeping (check_block) from the norm partials of the f / residual kernel.
+// The check used to be its own launch before the dots pass; running it here saves a launch per iteration.  The dots
+// pass of the final iteration then runs once more than needed (its results are ignored: every later kernel sees done).
+__global__ __launch_bounds__(TB) void k_reduce_check(Status* st, const float* __restrict__ part, int npart, int thr, int k,
+                                                     float* __restrict__ coef, const float* __restrict__ nrm_part, int nn,
+                                                     double* __restrict__ rel_trace, double* __restrict__ abs_trace,
+                                                     double eps, int seq_len, int keep_trace) {
   __shared__ double sh[TB];
+  if (blockIdx.y == 3) {
+    if (blockIdx.x == 0) check_block(st, nrm_part, nn, rel_trace, abs_trace, eps, thr, seq_len, keep_trace, sh);
+    return;
+  }
   if (st->done) return;
   int j = blockIdx.x, c = blockIdx.y;
+  if (j >= k) return;
   double s = block_sum_partials(part + ((int64_t)c * thr + j) * npart, npart, sh);
   if (threadIdx.x == 0) coef[c * thr + j] = (float)s;
 }
@@ -467,25 +478,23 @@ __global__ __launch_bounds__(TB) void k_axpy_combine(int64_t M, int k, int G, co
   block_pair_store(p1, p2, part, npart);
 }
 
-__global__ __launch_bounds__(TB) void k_reduce2(Status* st, const float* __restrict__ part, int npart) {
-  __shared__ double sh[TB];
-  if (st->done) return;
-  double s = block_sum_partials(part, npart, sh);
-  double b = block_sum_partials(part + npart, npart, sh);
-  if (threadIdx.x == 0) {
-    st->s = (double)(float)s;
-    st->beta = (double)(float)b;
-  }
-}
-
 // u = D1 / s (NaN -> 0) -> U[k] ;  update = D2 - u * beta
 template <int VEC>
-__global__ __launch_bounds__(TB) void k_final(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
-                                              float* __restrict__ upd, int64_t ld) {
+__global__ __launch_bounds__(TB) void k_final(int64_t M, int k, Status* __restrict__ st, float* __restrict__ U,
+                                              float* __restrict__ upd, int64_t ld, const float* __restrict__ part,
+                                              int npart) {
+  // every block first finishes s = vT.dg and beta = vT.g from the axpy pass's per-block partials (fixed order, fp64,
+  // rounded to fp32 like the reference's .item() values) -- formerly a single-block launch of its own
+  __shared__ double sh[TB];
   if (st->done) return;
+  const float s = (float)block_sum_partials(part, npart, sh);
+  const float beta = (float)block_sum_partials(part + npart, npart, sh);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->s = (double)s;
+    st->beta = (double)beta;
+  }
   int64_t e0 = elem0<VEC>();
   if (e0 >= M) return;
-  float s = (float)st->s, beta = (float)st->beta;
   float u[VEC], d2[VEC];
   float* Uk = U + (int64_t)k * ld;
   ldv<VEC>(Uk, e0, M, u);
@@ -537,6 +546,7 @@ static int broyden_alloc(psignn_broyden* s) {
   s->nblk = (int)cdiv(s->M, (int64_t)s->vec * TB);
   s->jgroups = s->nblk >= 768 ? 1 : (int)std::min<int64_t>(8, cdiv(768, s->nblk));
   s->npart = s->nblk * (TB / 64);
+  s->nn_cap = std::max<int>(s->nblk, s->plan ? (int)s->plan->n_tiles : 0);
   size_t nx = s->keep_trace ? thr + 2 : 3;
   s->ld = (s->M + 63) / 64 * 64;  // row pitch of U and V: every stored vector starts on a 256-byte boundary
   size_t ld = (size_t)s->ld;
@@ -545,6 +555,7 @@ static int broyden_alloc(psignn_broyden* s) {
       {(void**)&s->gx, M * 4},        {(void**)&s->dg, M * 4},        {(void**)&s->upd, M * 4},
       {(void**)&s->fx, M * 4},        {(void**)&s->part, 3 * thr * (size_t)s->npart * 4 + 16},
       {(void**)&s->coef, 3 * thr * 4 + 16}, {(void**)&s->st, sizeof(Status)},
+      {(void**)&s->nrm_part, 2 * (size_t)s->nn_cap * 4 + 16},
       {(void**)&s->rel_trace, thr * 8 + 8}, {(void**)&s->abs_trace, thr * 8 + 8}};
   for (auto& a : allocs) {
     if (hipMalloc(a.p, a.n ? a.n : 16) != hipSuccess) {
@@ -585,7 +596,7 @@ static int broyden_alloc(psignn_broyden* s) {
 
 extern "C" void psignn_broyden_destroy(psignn_broyden_t* s) {
   if (!s) return;
-  void* ptrs[] = {s->U, s->V, s->xbuf, s->gx, s->dg, s->upd, s->fx, s->fwork, s->part, s->coef, s->st,
+  void* ptrs[] = {s->U, s->V, s->xbuf, s->gx, s->dg, s->upd, s->fx, s->fwork, s->part, s->coef, s->st, s->nrm_part,
                   s->rel_trace, s->abs_trace, s->h0p, s->prbp, s->nrmp, s->jpart};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -642,22 +653,21 @@ static inline int sel_off_nxt() { return offsetof(Status, nxt) / 4; }
 static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, int fused_npart = 0) {
   unsigned g = (unsigned)s->nblk;
   if (!fused_npart)
-    VLAUNCH("k_resid", st, s->vec, k_resid, (g, TB, 0, st), s->M, s->st, s->xbuf, s->fx, s->gx, s->dg, s->part, s->nblk);
+    VLAUNCH("k_resid", st, s->vec, k_resid, (g, TB, 0, st), s->M, s->st, s->xbuf, s->fx, s->gx, s->dg, s->nrm_part, s->nblk);
   const int np = fused_npart ? fused_npart : s->nblk;  // one partial pair per block / per tile
-  LAUNCH("k_check", st, (k_check<<<1, TB, 0, st>>>(s->st, s->part, np, s->rel_trace, s->abs_trace, eps, s->thr, s->seq_len, s->keep_trace)));
-  if (k >= s->thr) return;  // the threshold stop has fired; no slot left for another pair
   // split of the sweeps over the stored pairs: only when there are enough pairs to share out
   const int G = (s->jgroups > 1 && k >= 4 * s->jgroups) ? s->jgroups : 1;
   const int js = (int)cdiv(std::max(k, 1), G);
-  if (k > 0) {
-    VLAUNCH("k_dots", st, s->vec, k_dots, (dim3(g, G), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->npart, s->thr, js, s->ld);
-    LAUNCH("k_reduce", st, (k_reduce<<<dim3(k, 3), TB, 0, st>>>(s->st, s->part, s->npart, s->thr, s->coef)));
-  }
+  const int kd = k >= s->thr ? 0 : k;  // the threshold stop is about to fire: no slot left for another pair
+  if (kd > 0)
+    VLAUNCH("k_dots", st, s->vec, k_dots, (dim3(g, G), TB, 0, st), s->M, kd, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->npart, s->thr, js, s->ld);
+  LAUNCH("k_reduce_check", st, (k_reduce_check<<<dim3(std::max(kd, 1), 4), TB, 0, st>>>(
+      s->st, s->part, s->npart, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace)));
+  if (k >= s->thr) return;
   VLAUNCH("k_axpy", st, s->vec, k_axpy, (dim3(g, G), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->nblk, js, s->jpart, s->ld);
   if (G > 1)
     VLAUNCH("k_axpy_combine", st, s->vec, k_axpy_combine, (g, TB, 0, st), s->M, k, G, s->st, s->jpart, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->nblk, s->ld);
-  LAUNCH("k_reduce2", st, (k_reduce2<<<1, TB, 0, st>>>(s->st, s->part, s->nblk)));
-  VLAUNCH("k_final", st, s->vec, k_final, (g, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->ld);
+  VLAUNCH("k_final", st, s->vec, k_final, (g, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->ld, s->part, s->nblk);
 }
 
 static int read_status(psignn_broyden* s, hipStream_t st) {
@@ -723,13 +733,13 @@ extern "C" int psignn_broyden_solve(psignn_broyden_t* s, const float* W, int nl,
   // gx0 = f(x0) - x0, update = gx0 (solver.py:131-136)
   if ((rc = psignn_f_eval_p(p, W, nl, s->h0p, nullptr, 0, s->h0p, s->prbp, nrmp, s->fx, s->fwork, st))) return rc;
   VPLAIN(s->vec, k_begin, (g, TB, 0, st), s->M, s->h0p, s->fx, s->xbuf, s->gx, s->upd);
-  const bool fused = p->tiled && (nl == 1 || p->mixed) && (size_t)p->n_tiles * 8 <= 3 * (size_t)s->thr * s->npart;
+  const bool fused = p->tiled && (nl == 1 || p->mixed);
   const int32_t* st_words = reinterpret_cast<const int32_t*>(s->st);
   for (int it = 0; it < s->thr; ++it) {
     if (fused) {
       // one kernel: x_next = x_cur + update, f(x_next), g_new, dg, x_next and the norm partials
       rc = psignn_f_tile_fused(p, W, nl, s->xbuf, s->M, st_words, offsetof(Status, done) / 4, sel_off_cur(),
-                               sel_off_nxt(), s->upd, s->gx, s->dg, s->h0p, s->prbp, nrmp, s->part, st);
+                               sel_off_nxt(), s->upd, s->gx, s->dg, s->h0p, s->prbp, nrmp, s->nrm_part, st);
       if (rc < 0) return rc;
       launch_update(s, it, eps, st, rc);
     } else {
