@@ -695,3 +695,53 @@ def test_eval_harness_reference_protocol(dev):
     assert abs(res[0][0] - float(g["metric_residual"])) < 0.1 * float(g["metric_residual"])
     assert abs(res[3][0] - float(g["metric_rel"])) < 0.1 * float(g["metric_rel"])
     assert secs < 5.0
+
+
+# ------------------------------------------------------------------------------------------ adversarial geometry
+@pytest.mark.parametrize("kind", ["coincident", "line", "random_graph", "graded", "star"])
+def test_tile_builder_survives_adversarial_inputs(kind, dev):
+    """Positions / connectivities a mesh generator would never produce: every node at one point, nodes on a line, a
+    non-planar random graph (halos of hundreds of nodes), a strongly graded point cloud, one hub node of degree N-1.
+    The plan either tiles or falls back to the global-gather kernels (structure limits: tiles.hip header); in both
+    cases f and the VJP must match the oracle -- and nothing may fault."""
+    data, eng = pkg("data"), pkg("engine")
+    sd = load_weights("dirichlet")
+    gen = torch.Generator().manual_seed(17)
+    N = 3000
+    if kind == "star":
+        src = torch.arange(1, N)
+        ei = torch.cat([torch.stack([src, torch.zeros_like(src)]), torch.stack([torch.zeros_like(src), src])], dim=1)
+        pos = torch.randn(N, 2, generator=gen)
+    else:
+        nb = torch.randint(0, N, (N, 6), generator=gen)
+        if kind != "random_graph":   # local connectivity: neighbours by index distance
+            nb = (torch.arange(N)[:, None] + torch.tensor([1, 2, 3, 50, 51, 52])[None, :]) % N
+        src = torch.arange(N)[:, None].expand(-1, 6).reshape(-1)
+        dst = nb.reshape(-1)
+        keep = src != dst
+        ei = torch.stack([torch.cat([src[keep], dst[keep]]), torch.cat([dst[keep], src[keep]])])
+        ei = torch.unique(ei, dim=1)
+        pos = {"coincident": torch.zeros(N, 2),
+               "line": torch.stack([torch.linspace(0, 1, N), torch.zeros(N)], dim=1),
+               "random_graph": torch.rand(N, 2, generator=gen),
+               "graded": torch.rand(N, 2, generator=gen) ** 8}[kind]
+    ei = torch.cat([ei, torch.arange(N)[None, :].expand(2, -1)], dim=1)          # self loops as in the reader
+    E = ei.shape[1]
+    tags = (torch.rand(N, 1, generator=gen) < 0.05).float()
+    m = data.MeshData(x=torch.randn(N, 1, generator=gen), edge_index=ei, edge_attr=torch.randn(E, 3, generator=gen),
+                      a_ij=torch.randn(E, 1, generator=gen), y=torch.zeros(N, 1), sol=torch.zeros(N, 1),
+                      prb_data=torch.randn(N, 2, generator=gen), tags=tags, pos=pos)
+    md = m.to(dev)
+    plan = eng.MeshPlan(md)
+    h0 = 0.1 * torch.randn(N, 10, generator=gen)
+    h = 0.1 * torch.randn(N, 10, generator=gen)
+    w = torch.randn(N, 10, generator=gen)
+    fm = eng.FixedPointMap(plan, eng.PackedWeights(sd, dev), h0.to(dev), md.prb_data)
+    with torch.no_grad():
+        want = orc.function_forward(sd, h.clone(), h0, m)
+    got = fm(h.to(dev))
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) < 5e-6, (kind, plan.tiled, rel_l2(got, want))
+    assert rel_l2(fm.vjp(h.to(dev), w.to(dev)), orc.function_vjp(sd, h, h0, m, w)) < 5e-5
+    out = pkg("utilities.solver").broyden(fm, h0.to(dev), threshold=10, eps=1e-9, keep_trace=False)
+    assert out["n_iter"] == 10 and np.all(np.isfinite(out["rel_trace"][:10]))
