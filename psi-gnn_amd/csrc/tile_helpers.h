@@ -13,6 +13,9 @@
 // Workgroup = 4 waves = TILE_MAX lanes.  (A fifth wave that only helps with the halo rows of stage 1 was tried:
 // 79 us instead of 67 us per 1M-node evaluation -- it costs a wave slot per workgroup for the whole residency.)
 #define TILE_THREADS 256
+#ifndef EDGE_PD
+#define EDGE_PD 2   // prefetch distance of the slot loads in edge_pass
+#endif
 
 // Compiler-level memory barrier between the phases of a kernel.  The tile kernels read > 1 000 wave-uniform weights;
 // fully unrolled, the compiler hoists all their scalar loads to the top and then spills hundreds of SGPRs into VGPR
@@ -86,16 +89,18 @@ __device__ __forceinline__ float edge_pass(const uint4* __restrict__ slots, int 
       for (int p = 0; p < 5; ++p) S[p] += __builtin_elementwise_max(z[p], splat(0.f));
     }
   };
-  // software pipeline, distance 2: the 16-byte slot loads are unconditional (index clamped, never branched
-  // on) so the compiler keeps them whole and places their waits one iteration later
+  // software pipeline, distance EDGE_PD: the 16-byte slot loads are unconditional (index clamped, never branched
+  // on) so the compiler keeps them whole and places their waits EDGE_PD - 1 iterations later
   if (nslots <= 0) return deg;
-  uint4 c0 = slots[0];
-  uint4 c1 = slots[(int64_t)min(1, nslots - 1) * 64];
+  uint4 c[EDGE_PD];
+#pragma unroll
+  for (int i = 0; i < EDGE_PD; ++i) c[i] = slots[(int64_t)min(i, nslots - 1) * 64];
   for (int r = 0; r < nslots; ++r) {
-    const uint4 nx = slots[(int64_t)min(r + 2, nslots - 1) * 64];
-    one(c0);
-    c0 = c1;
-    c1 = nx;
+    const uint4 nx = slots[(int64_t)min(r + EDGE_PD, nslots - 1) * 64];
+    one(c[0]);
+#pragma unroll
+    for (int i = 0; i + 1 < EDGE_PD; ++i) c[i] = c[i + 1];
+    c[EDGE_PD - 1] = nx;
   }
   return deg;
 }
