@@ -64,15 +64,20 @@ class TrainModel:
         self.hist_val = {k: [] for k in _KEYS}
         self.createOptimizerAndScheduler()
 
+    @property
+    def net(self):
+        """The model itself, whether or not it came wrapped in ``loader.DataParallel`` (the reference always wraps)."""
+        return getattr(self.model, "module", self.model)
+
     def createOptimizerAndScheduler(self):
-        self.opt_deq = torch.optim.Adam(self.model.deqdss.parameters(), lr=self.lr_deq)
+        self.opt_deq = torch.optim.Adam(self.net.deqdss.parameters(), lr=self.lr_deq)
         self.sched_deq = torch.optim.lr_scheduler.ReduceLROnPlateau(self.opt_deq, mode="min", factor=self.sched_step_deq)
-        self.opt_ae = torch.optim.Adam(self.model.autoencoder.parameters(), lr=self.lr_ae)
+        self.opt_ae = torch.optim.Adam(self.net.autoencoder.parameters(), lr=self.lr_ae)
         self.sched_ae = torch.optim.lr_scheduler.ReduceLROnPlateau(self.opt_ae, mode="min", factor=self.sched_step_ae)
 
     # ---- checkpoints: same dictionary keys as the reference ------------------------------------------------------
     def checkpoint(self, epoch):
-        return {"epoch": epoch, "hyperparameters": self.config_model, "state_dict": self.model.state_dict(),
+        return {"epoch": epoch, "hyperparameters": self.config_model, "state_dict": self.net.state_dict(),
                 "hist_train": self.hist_train, "hist_val": self.hist_val, "opt_deq": self.opt_deq.state_dict(),
                 "opt_ae": self.opt_ae.state_dict(), "sched_deq": self.sched_deq.state_dict(),
                 "sched_ae": self.sched_ae.state_dict(), "training_time": self.training_time,
@@ -89,7 +94,7 @@ class TrainModel:
         fns = [getattr(solver, n) for n in ("broyden", "anderson", "forward_iteration", "newton")]
         torch.serialization.add_safe_globals(fns + [(f, f"utilities.solver.{f.__name__}") for f in fns])
         ck = torch.load(path, map_location="cpu", weights_only=True)
-        self.model.load_state_dict(ck["state_dict"])
+        self.net.load_state_dict(ck["state_dict"])
         self.opt_deq.load_state_dict(ck["opt_deq"])
         self.opt_ae.load_state_dict(ck["opt_ae"])
         self.sched_deq.load_state_dict(ck["sched_deq"])
@@ -109,8 +114,8 @@ class TrainModel:
         _, loss_dic = self.model(batch)
         loss = self.total_loss(loss_dic)
         loss.backward()
-        allreduce_mean_grads(self.model.parameters())
-        torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.gradient_clip)
+        allreduce_mean_grads(self.net.parameters())
+        torch.nn.utils.clip_grad_norm_(self.net.parameters(), self.gradient_clip)
         self.opt_deq.step()
         self.opt_ae.step()
         return loss, loss_dic

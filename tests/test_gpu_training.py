@@ -9,6 +9,7 @@ is left of either solve by ~1/(1 - rho).  Tensors whose gradient is ~0 (saturate
 the largest gradient."""
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -171,3 +172,19 @@ def test_trainer_steps_and_checkpoint(dev, tmp_path):
     assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(tr2.model.state_dict().values(), net.state_dict().values()))
     with pytest.raises(pkg("_native").NativeError):
         TrainModel(dict(cfg, jac_weight=0.1))
+
+
+def test_trainer_with_reference_style_wrappers(dev):
+    """The reference's main.py shape: DataListLoader (lists of CPU graphs) + DataParallel(model) (main.py:70-78,106)."""
+    loader, TrainModel = pkg("loader"), pkg("training_class").TrainModel
+    sd = load_weights("dirichlet")
+    graphs = [load_case(n)[1] for n in ("hex13_dirichlet_s0", "original_dirichlet_s0", "original_dirichlet_s1")]
+    net = _model(sd, dev, fw_tol=1e-5, fw_thres=300, bw_tol=1e-6, bw_thres=300)
+    wrapped = loader.DataParallel(net).to(dev)
+    tr = TrainModel(dict(loader_train=loader.DataListLoader(graphs, batch_size=2), loader_val=loader.DataListLoader(graphs[:1], batch_size=1),
+                         model=wrapped, config_model=net.config, lr_deq=1e-5, lr_ae=1e-5, sched_step_deq=0.5, sched_step_ae=0.5,
+                         path_ckpt=None, min_loss_save=1e9, max_epochs=1, gradient_clip=1e-2, sup_weight=0.0, jac_weight=0.0))
+    tr.train_model()
+    assert len(tr.hist_train["loss"]) == 1 and np.isfinite(tr.hist_train["loss"][0]) and np.isfinite(tr.hist_val["loss"][0])
+    out = wrapped.eval()([graphs[0]])
+    assert out[0].shape == (graphs[0].num_nodes, 1) and out[0].is_cuda

@@ -171,3 +171,30 @@ def test_dsgps_state_dict_and_packing():
     assert torch.equal(flat[700:1020].reshape(32, 10), Wz.t())
     At = sd["phi_to.mlp.mlp.0.weight"][:, 20:23]
     assert torch.equal(flat[400:430].reshape(3, 10), At.t() * torch.tensor([-1.0, -1.0, 1.0])[:, None])
+
+
+def test_loader_stand_ins():
+    """DataListLoader / DataLoader / DataParallel keep the calling conventions of the PyG pieces the reference's
+    scripts use (main.py:70-78,106; test_func.py:134-140)."""
+    data, loader = pkg("data"), pkg("loader")
+    ds = [data.make_hex_problem(3, seed=s) for s in range(5)]
+    ll = loader.DataListLoader(ds, batch_size=2, shuffle=False)
+    chunks = list(ll)
+    assert len(ll) == 3 and [len(c) for c in chunks] == [2, 2, 1] and chunks[0][1] is ds[1]
+    dl = list(loader.DataLoader(ds, batch_size=2))
+    assert dl[0].num_graphs == 2 and dl[0].num_nodes == 2 * ds[0].num_nodes and dl[2].num_graphs == 1
+    sh = loader.DataListLoader(ds, batch_size=5, shuffle=True, generator=torch.Generator().manual_seed(0))
+    assert sorted(id(g) for g in next(iter(sh))) == sorted(id(g) for g in ds)
+
+    class Probe(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, batch):
+            return batch.num_nodes, getattr(batch, "num_graphs", 1)
+
+    dp = loader.DataParallel(Probe())
+    assert dp.module is not None
+    assert dp([ds[0]]) == (ds[0].num_nodes, 1)
+    assert dp(ds[:3]) == (3 * ds[0].num_nodes, 3)
