@@ -177,17 +177,18 @@ int psignn_mlp2_backward(const float* d_x, const float* d_gy, int64_t n, int din
                          const float* d_b1, const float* d_w2, float* d_gx, float* d_gflat, float* d_work, void* stream);
 int psignn_residual_t(const psignn_plan_t* plan, const float* d_a_ij, const float* d_r, float* d_out, void* stream);
 
-/* DS-GPS, the unrolled recurrent baseline (dirichlet/dsgps/model.py:130-163): k updates
+/* DS-GPS, the unrolled recurrent baseline (dirichlet/dsgps/model.py:130-163, mixed/dsgps/model.py:50-95): k updates
  *   h <- h + sigmoid(Wz c + bz) * tanh(Wc [sigmoid(Wr c + br) * h | mess_to | mess_from | prb] + bc),
- *   c = [h | Phi_to(h) | Phi_from(h) | prb], Dirichlet rows <- d_h0 rows,
- * starting from d_h0 (the encoder state).  Tiled dirichlet plans.  d_weights: psignn_dsgps_weights_size() floats
+ *   c = [h | Phi_to(h) | Phi_from(h) | prb], Dirichlet rows <- d_h0 rows; mixed plans: Neumann rows <-
+ *   update_neumann([h | Phi_neumann(h) | prb | normal]) (d_normals required),
+ * starting from d_h0 (the encoder state).  Tiled plans.  d_weights: psignn_dsgps_weights_size(mixed) floats
  * (layout in csrc/dsgps_tile.hip, built by engine.pack_dsgps); d_work: 4 * N * 10 floats.
  * psignn_dsgps_step_p: a single update with all node tensors in plan order. */
-int64_t psignn_dsgps_weights_size(void);
+int64_t psignn_dsgps_weights_size(int mixed);
 int psignn_dsgps_forward(const psignn_plan_t* plan, const float* d_weights, int k, const float* d_h0, const float* d_prb,
-                         float* d_out, float* d_work, void* stream);
+                         const float* d_normals, float* d_out, float* d_work, void* stream);
 int psignn_dsgps_step_p(const psignn_plan_t* plan, const float* d_weights, const float* d_h, const float* d_h0,
-                        const float* d_prb, float* d_out, void* stream);
+                        const float* d_prb, const float* d_normals, float* d_out, void* stream);
 
 /* DSS, the Deep Statistical Solver baseline (dirichlet/dss/model.py:97-120): k updates with per-step weights
  *   h <- h + alpha * Psi_t([h | Phi_to_t(h) | Phi_from_t(h) | b'_norm]),  H_0 = 0,

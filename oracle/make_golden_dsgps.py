@@ -49,5 +49,27 @@ def main():
                  h_1=orc.dsgps_step(sd, orc.encoder(sd, mesh.x), orc.encoder(sd, mesh.x), mesh).numpy())
 
 
+def main_mixed():
+    """mixed/dsgps/results/50_ite_lamb_0_gamma_0_9/ckpt/best_model.pt on the mixed fixture mesh."""
+    ck = torch.load("/root/reference/mixed/dsgps/results/50_ite_lamb_0_gamma_0_9/ckpt/best_model.pt", map_location="cpu",
+                    weights_only=True)
+    sd = {k: v.float().contiguous() for k, v in ck["state_dict"].items()}
+    k = int(ck["hyperparameters"]["k"])
+    print("mixed DS-GPS config:", ck["hyperparameters"])
+    np.savez(os.path.join(OUT, "weights_dsgps_mixed.npz"), k=np.int64(k), **{n: v.numpy() for n, v in sd.items()})
+    _, mesh = load_case("hex13_mixed_s1")
+    u, h, res, mse = orc.dsgps_inference(sd, mesh, k, trace=True)
+    sd64 = {n: v.double() for n, v in sd.items()}
+    m64 = mesh.clone()
+    for f in ("x", "edge_attr", "a_ij", "y", "sol", "prb_data", "unit_normal_vector"):
+        setattr(m64, f, getattr(m64, f).double())
+    u64, h64 = orc.dsgps_inference(sd64, m64, k)
+    print(f"hex13_mixed_s1: residual {res[-1]:.3e} (first {res[1]:.3e}) mse {mse[-1]:.3e} fp32-vs-fp64 H {float((h - h64).norm() / h64.norm()):.2e}")
+    h0 = orc.encoder(sd, mesh.x)
+    np.savez(os.path.join(OUT, "dsgps_hex13_mixed_s1.npz"), h_k=h.numpy(), u_k=u.numpy(), h_k64=h64.numpy(), u_k64=u64.numpy(),
+             res_trace=np.array(res), mse_trace=np.array(mse), h_1=orc.dsgps_step(sd, h0, h0, mesh).numpy())
+
+
 if __name__ == "__main__":
     main()
+    main_mixed()

@@ -407,7 +407,14 @@ def dsgps_step(sd, h, h0, batch):
     cat2 = torch.cat([reset * h, mess_to, mess_from, batch.prb_data], dim=1)
     corr = torch.tanh(F.linear(cat2, sd["correction.mlp.0.weight"], sd["correction.mlp.0.bias"]))
     h_next = h + alpha * corr
-    idx_d = torch.where(batch.tags == 1)[0]
+    if "phi_neumann.mlp.mlp.0.weight" in sd:   # mixed/dsgps/model.py:79-93: Neumann rows replaced, then Dirichlet rows
+        mp_n = phi(sd, "phi_neumann", h, batch.edge_index, batch.edge_attr, "target_to_source")
+        upd_n = _mlp(sd, "update_neumann", torch.cat([h, mp_n, batch.prb_data, batch.unit_normal_vector], dim=1))
+        idx_n = torch.where(batch.tags[:, 2] == 1)[0]
+        h_next[idx_n, :] = upd_n[idx_n, :]
+        idx_d = torch.where(batch.tags[:, 1] == 1)[0]
+    else:
+        idx_d = torch.where(batch.tags == 1)[0]
     h_next[idx_d, :] = h0[idx_d, :]
     return h_next
 

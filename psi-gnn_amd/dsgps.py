@@ -33,18 +33,25 @@ class MLPActivation(nn.Module):
 
 
 class ModelDSGPS(nn.Module):
-    def __init__(self, config):
+    """``config["bc"] = "mixed"`` (or ``mixed=True``) selects mixed/dsgps/model.py: 3 problem features, Phi_neumann and
+    update_neumann (Neumann rows are replaced by their output), Dirichlet rows in tag column 1."""
+
+    def __init__(self, config, mixed=None):
         super().__init__()
         self.config = dict(config)
-        d = self.config["latent_dim"]
+        self.mixed = (self.config.get("bc") == "mixed") if mixed is None else bool(mixed)
+        d, p = self.config["latent_dim"], 3 if self.mixed else 2
         if d != engine.D:
             raise nat.NativeError(f"HIP kernels are built for latent_dim = {engine.D}")
         self.laynorm = nn.LayerNorm(d)   # declared (and checkpointed) by the reference, unused in its forward
         self.phi_to = Phi_to([2 * d + 3, d, d], nn.ReLU())
         self.phi_from = Phi_from([2 * d + 3, d, d], nn.ReLU())
-        self.z_k = MLPActivation([3 * d + 2, d], nn.Sigmoid())
-        self.r_k = MLPActivation([3 * d + 2, d], nn.Sigmoid())
-        self.correction = MLPActivation([3 * d + 2, d], nn.Tanh())
+        self.z_k = MLPActivation([3 * d + p, d], nn.Sigmoid())
+        self.r_k = MLPActivation([3 * d + p, d], nn.Sigmoid())
+        self.correction = MLPActivation([3 * d + p, d], nn.Tanh())
+        if self.mixed:
+            self.phi_neumann = Phi_from([2 * d + 3, d, d], nn.ReLU())
+            self.update_neumann = MLP([2 * d + 5, d, d], nn.ReLU())
         self.autoencoder = Autoencoder([1, d, d], nn.ReLU())
         self.mse_loss = nn.MSELoss()
         self._packed, self._packed_key = None, None
@@ -64,7 +71,8 @@ class ModelDSGPS(nn.Module):
     def inference(self, batch):
         nat.require_cuda(batch.x, "batch.x")
         h0 = self.autoencoder.encoder(batch.x)
-        hk = engine.dsgps_forward(engine.plan_for(batch), self.packed(h0.device), h0, batch.prb_data, self.config["k"])
+        hk = engine.dsgps_forward(engine.plan_for(batch), self.packed(h0.device), h0, batch.prb_data, self.config["k"],
+                                  batch.unit_normal_vector if self.mixed else None)
         return self.autoencoder.decoder(hk)
 
     @torch.no_grad()
@@ -73,16 +81,17 @@ class ModelDSGPS(nn.Module):
         ae, k, gamma = self.autoencoder, self.config["k"], self.config["gamma"]
         plan = engine.plan_for(batch)
         w = self.packed(batch.x.device)
-        idx = torch.where(batch.tags.reshape(batch.tags.shape[0], -1)[:, 0] == 1)[0]
+        idx = torch.where(batch.tags.reshape(batch.tags.shape[0], -1)[:, 1 if self.mixed else 0] == 1)[0]
         U = {"0": batch.x}
         res, mse = {"0": self.residual_loss(batch.x, batch)}, {"0": self.mse_loss(batch.x, batch.sol)}
         enc, aenc, msd = {}, {}, {}
         h0 = ae.encoder(batch.x)
         h0p, prbp = plan.permute(h0, True), plan.permute(batch.prb_data, True)
+        nrmp = plan.permute(batch.unit_normal_vector, True) if self.mixed else None
         hp = h0p
         total = None
         for t in range(k):
-            hp = engine.dsgps_step_p(plan, w, hp, h0p, prbp)
+            hp = engine.dsgps_step_p(plan, w, hp, h0p, prbp, nrmp)
             h = plan.permute(hp, False)
             u = ae.decoder(h)
             s = str(t + 1)

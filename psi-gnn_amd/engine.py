@@ -413,11 +413,13 @@ class FixedPointMap:
 
 
 def pack_dsgps(sd, device=None) -> torch.Tensor:
-    """Flat weight buffer of the DS-GPS kernels from a ``ModelDSGPS`` state_dict (dirichlet/dsgps/model.py:35-45;
-    layout in csrc/dsgps_tile.hip): every matrix transposed to [in k][out o]."""
+    """Flat weight buffer of the DS-GPS kernels from a ``ModelDSGPS`` state_dict (dirichlet/dsgps/model.py:35-45,
+    mixed/dsgps/model.py:35-48; layout in csrc/dsgps_tile.hip): every matrix transposed to [in k][out o]."""
     m = lambda k: sd[k].detach().to("cpu", torch.float32)
-    if m("phi_to.mlp.mlp.0.weight").shape != (D, 2 * D + 3) or m("z_k.mlp.0.weight").shape != (D, 3 * D + 2):
-        raise nat.NativeError("DS-GPS kernels are built for latent_dim = 10, 3 edge features, 2 problem features")
+    mixed = "phi_neumann.mlp.mlp.0.weight" in sd
+    p = 3 if mixed else 2
+    if m("phi_to.mlp.mlp.0.weight").shape != (D, 2 * D + 3) or m("z_k.mlp.0.weight").shape != (D, 3 * D + p):
+        raise nat.NativeError("DS-GPS kernels are built for latent_dim = 10, 3 edge features, 2 (mixed: 3) problem features")
     t = lambda a: a.t().contiguous().reshape(-1)
     Wt, Wf = m("phi_to.mlp.mlp.0.weight"), m("phi_from.mlp.mlp.0.weight")
     mir = torch.tensor([-1.0, -1.0, 1.0])[:, None]
@@ -428,13 +430,23 @@ def pack_dsgps(sd, device=None) -> torch.Tensor:
              t(m("phi_from.mlp.mlp.2.weight")), m("phi_from.mlp.mlp.2.bias")]
     for g in ("z_k", "r_k", "correction"):
         parts += [t(m(f"{g}.mlp.0.weight")), m(f"{g}.mlp.0.bias")]
-    flat = torch.cat([p.reshape(-1) for p in parts]).contiguous()
-    if flat.numel() != int(nat.lib().psignn_dsgps_weights_size()):
+    if mixed:   # transposed Neumann block, same layout as the mixed PSI-GNN kernels (WLayout<3>::N_*)
+        d64 = lambda k: sd[k].detach().to("cpu", torch.float64)
+        f32 = lambda a: a.to(torch.float32).reshape(-1)
+        Wn, N1, N2 = d64("phi_neumann.mlp.mlp.0.weight"), d64("update_neumann.mlp.0.weight"), d64("update_neumann.mlp.2.weight")
+        Gn = N1[:, D:2 * D] @ d64("phi_neumann.mlp.mlp.2.weight")
+        gn = N1[:, D:2 * D] @ d64("phi_neumann.mlp.mlp.2.bias")
+        n1p = f32(N1[:, 2 * D:].t())
+        parts += [f32(Wn[:, D:2 * D].t()), f32(Wn[:, :D].t()), f32(Wn[:, 2 * D:].t()), f32(d64("phi_neumann.mlp.mlp.0.bias")),
+                  f32(N1[:, :D].t()), f32(Gn.t()), torch.nn.functional.pad(n1p, (0, 50 - n1p.numel())),
+                  f32(d64("update_neumann.mlp.0.bias")), f32(gn), f32(N2.t()), f32(d64("update_neumann.mlp.2.bias"))]
+    flat = torch.cat([q.reshape(-1) for q in parts]).contiguous()
+    if flat.numel() != int(nat.lib().psignn_dsgps_weights_size(int(mixed))):
         raise nat.NativeError(f"packed DS-GPS weight length {flat.numel()} != native layout")
     return flat if device is None else flat.to(device)
 
 
-def dsgps_forward(plan: "MeshPlan", wflat, h0, prb, k: int):
+def dsgps_forward(plan: "MeshPlan", wflat, h0, prb, k: int, nrm=None):
     """H_k of ``ModelDSGPS.inference`` (model.py:141-155): k recurrent updates from the encoder state h0."""
     nat.require_cuda(h0, "h0")
     hc, pc = _f32c(h0), _f32c(prb)
@@ -442,17 +454,17 @@ def dsgps_forward(plan: "MeshPlan", wflat, h0, prb, k: int):
     work = torch.empty(4 * plan.N * D, dtype=torch.float32, device=hc.device)
     with torch.cuda.device(hc.device):
         nat.check(nat.lib().psignn_dsgps_forward(plan.handle, nat.ptr(wflat), int(k), nat.ptr(hc), nat.ptr(pc),
-                                                 nat.ptr(out), nat.ptr(work), nat.stream_ptr(hc.device)),
-                  "psignn_dsgps_forward")
+                                                 nat.ptr(None if nrm is None else _f32c(nrm)), nat.ptr(out),
+                                                 nat.ptr(work), nat.stream_ptr(hc.device)), "psignn_dsgps_forward")
     return out
 
 
-def dsgps_step_p(plan: "MeshPlan", wflat, hp, h0p, prbp):
+def dsgps_step_p(plan: "MeshPlan", wflat, hp, h0p, prbp, nrmp=None):
     """One DS-GPS update, node tensors in plan order."""
     out = torch.empty_like(hp)
     with torch.cuda.device(hp.device):
         nat.check(nat.lib().psignn_dsgps_step_p(plan.handle, nat.ptr(wflat), nat.ptr(_f32c(hp)), nat.ptr(h0p), nat.ptr(prbp),
-                                                nat.ptr(out), nat.stream_ptr(hp.device)), "psignn_dsgps_step_p")
+                                                nat.ptr(nrmp), nat.ptr(out), nat.stream_ptr(hp.device)), "psignn_dsgps_step_p")
     return out
 
 
