@@ -230,6 +230,9 @@ typedef struct {
 /* keep_trace != 0 stores every iterate ((thr+1) * N * d floats) for xest_trace. */
 int psignn_broyden_create(psignn_broyden_t** out, const psignn_plan_t* plan, int threshold, int keep_trace);
 void psignn_broyden_destroy(psignn_broyden_t* s);
+/* stop_mode of the following solves: 0 = "rel" (default; all reference call sites), 1 = "abs" (utilities/solver.py:116,140,174):
+ * objective, lowest-iterate tracking and the protective-break factor (1e6 instead of 1e3) follow it. */
+int psignn_broyden_set_stop_mode(psignn_broyden_t* solver, int abs_mode);
 size_t psignn_broyden_bytes(const psignn_broyden_t* s);
 
 /* Solve; synchronous at the end (the result must be complete when it returns).  The host polls the

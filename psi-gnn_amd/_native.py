@@ -73,6 +73,7 @@ SIGNATURES = {
     "psignn_broyden_create_n": (_INT, [C.POINTER(_P), _I64, _INT, _INT, _INT]),
     "psignn_broyden_destroy": (None, [_P]),
     "psignn_broyden_bytes": (C.c_size_t, [_P]),
+    "psignn_broyden_set_stop_mode": (_INT, [_P, _INT]),
     "psignn_broyden_solve": (_INT, [_P, _P, _INT, _P, _P, _P, C.c_double, _INT, _P, C.POINTER(SolveInfo),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
     "psignn_broyden_solve_adjoint": (_INT, [_P, _P, _INT, _P, _P, _P, _P, C.c_double, _INT, _P, C.POINTER(SolveInfo),

@@ -34,6 +34,9 @@ struct Status {
   int32_t nxt;          // buffer index the next iterate is written to
   double lowest_rel, lowest_abs_at;  // lowest rel, and lowest abs (tracked independently, solver.py:170-175)
   double rel0;
+  double abs0;          // first entry of the abs trace (protective break in stop_mode = "abs")
+  int32_t lowest_step_abs;
+  int32_t stop_abs;     // 0: stop_mode = "rel" (every reference call site), 1: "abs"
   double s, beta;       // vT.dg, vT.g
 };
 
@@ -61,6 +64,7 @@ struct psignn_broyden {
   size_t bytes = 0;
   int ext_iter = 0;
   int64_t ld = 0;           // row pitch (floats) of U and V
+  int stop_abs = 0;         // stop_mode of the next solve
   int plan_order = 1;       // 0 while iterates are kept in the caller's numbering (adjoint solve on the gather kernels)
 };
 
@@ -145,8 +149,9 @@ __device__ __forceinline__ void stv(float* __restrict__ p, int64_t e0, int64_t M
   }
 }
 
-__global__ void k_init_status(Status* st, double* rel_trace, double* abs_trace, int thr) {
+__global__ void k_init_status(Status* st, double* rel_trace, double* abs_trace, int thr, int stop_abs = 0) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    st->abs0 = 0.0; st->lowest_step_abs = 0; st->stop_abs = stop_abs;
     st->n_iter = 0; st->done = 0; st->prot_break = 0; st->stop_reason = 0; st->lowest_step = 0;
     st->cur = 0; st->low = 0; st->nxt = 1;
     st->lowest_rel = 1e8; st->lowest_abs_at = 1e8; st->rel0 = 0.0; st->s = 0.0; st->beta = 0.0;
@@ -256,13 +261,22 @@ __device__ void check_block(Status* st, const float* __restrict__ part, int npar
   st->n_iter = n;
   rel_trace[n - 1] = rel_diff;
   abs_trace[n - 1] = abs_diff;
-  if (n == 1) st->rel0 = rel_diff;
-  bool new_low = rel_diff < st->lowest_rel;
-  if (new_low) {
+  if (n == 1) {
+    st->rel0 = rel_diff;
+    st->abs0 = abs_diff;
+  }
+  // both modes keep their own lowest value / step; the lowest ITERATE follows stop_mode (solver.py:167-172)
+  const bool stop_abs = st->stop_abs != 0;
+  const bool low_rel = rel_diff < st->lowest_rel, low_abs = abs_diff < st->lowest_abs_at;
+  if (low_rel) {
     st->lowest_rel = rel_diff;
     st->lowest_step = n;
   }
-  if (abs_diff < st->lowest_abs_at) st->lowest_abs_at = abs_diff;
+  if (low_abs) {
+    st->lowest_abs_at = abs_diff;
+    st->lowest_step_abs = n;
+  }
+  const bool new_low = stop_abs ? low_abs : low_rel;
   // buffer rotation: the iterate just evaluated lives in nxt
   int cur = st->nxt;
   int low = new_low ? cur : st->low;
@@ -276,20 +290,22 @@ __device__ void check_block(Status* st, const float* __restrict__ part, int npar
   st->cur = cur;
   st->low = low;
   st->nxt = nxt;
-  // stop tests
+  // stop tests on the objective of stop_mode (solver.py:174-181); protect_thres = 1e6 (abs) / 1e3 (rel) * seq_len
+  const double obj = stop_abs ? abs_diff : rel_diff;
+  const double* tr = stop_abs ? abs_trace : rel_trace;
   int reason = -1;
-  if (rel_diff < eps) {
+  if (obj < eps) {
     reason = 1;
-  } else if (rel_diff < 3 * eps && n > 30) {
+  } else if (obj < 3 * eps && n > 30) {
     double mx = -1e300, mn = 1e300;
     for (int i = n - 30; i < n; ++i) {
-      double r = rel_trace[i];
+      double r = tr[i];
       mx = r > mx ? r : mx;
       mn = r < mn ? r : mn;
     }
     if (mx / mn < 1.3) reason = 2;
   }
-  if (reason < 0 && rel_diff > st->rel0 * 1e3 * seq_len) {
+  if (reason < 0 && obj > (stop_abs ? st->abs0 * 1e6 : st->rel0 * 1e3) * seq_len) {
     reason = 3;
     st->prot_break = 1;
   }
@@ -644,6 +660,13 @@ extern "C" int psignn_broyden_create(psignn_broyden_t** out, const psignn_plan_t
 
 extern "C" size_t psignn_broyden_bytes(const psignn_broyden_t* s) { return s ? s->bytes : 0; }
 
+// stop_mode of the following solves: 0 = "rel" (default; every call site of the reference), 1 = "abs" (solver.py:116,140,174)
+extern "C" int psignn_broyden_set_stop_mode(psignn_broyden_t* s, int abs_mode) {
+  ARG_CHECK(s, "NULL solver");
+  s->stop_abs = abs_mode ? 1 : 0;
+  return PSIGNN_OK;
+}
+
 static inline int sel_off_cur() { return offsetof(Status, cur) / 4; }
 static inline int sel_off_low() { return offsetof(Status, low) / 4; }
 static inline int sel_off_nxt() { return offsetof(Status, nxt) / 4; }
@@ -692,11 +715,11 @@ static int finish(psignn_broyden* s, float* d_result, psignn_solve_info_t* info,
   if ((rc = read_status(s, st))) return rc;
   const Status& h = *s->h_st;
   if (info) {
-    info->nstep = h.lowest_step;
+    info->nstep = h.stop_abs ? h.lowest_step_abs : h.lowest_step;
     info->n_iter = h.n_iter;
     info->prot_break = h.prot_break;
     info->stop_reason = h.stop_reason;
-    info->lowest = h.lowest_rel;
+    info->lowest = h.lowest_rel;          // callers pick lowest / lowest_abs by their stop_mode
     info->lowest_abs = h.lowest_abs_at;
   }
   int n = h.n_iter;
@@ -722,7 +745,7 @@ extern "C" int psignn_broyden_solve(psignn_broyden_t* s, const float* W, int nl,
   if (poll_every <= 0) poll_every = 8;
   unsigned g = (unsigned)s->nblk;
   const int32_t* sel_nxt = reinterpret_cast<const int32_t*>(s->st) + sel_off_nxt();
-  k_init_status<<<4, TB, 0, st>>>(s->st, s->rel_trace, s->abs_trace, s->thr);
+  k_init_status<<<4, TB, 0, st>>>(s->st, s->rel_trace, s->abs_trace, s->thr, s->stop_abs);
   // node tensors into plan order once per solve (identity copy on an untiled plan)
   int rc;
   const psignn_plan* p = s->plan;
@@ -802,7 +825,7 @@ extern "C" int psignn_broyden_solve_adjoint(psignn_broyden_t* s, const float* W,
     grad = gr_p;
     prb = s->prbp;
   }
-  k_init_status<<<4, TB, 0, st>>>(s->st, s->rel_trace, s->abs_trace, s->thr);
+  k_init_status<<<4, TB, 0, st>>>(s->st, s->rel_trace, s->abs_trace, s->thr, s->stop_abs);
   // y0 = 0, map(y0) = grad  ->  g0 = grad, update = grad  (solver.py:131-136 with f(0) = grad)
   HIP_TRY(hipMemsetAsync(s->h0p, 0, (size_t)s->M * 4, st));
   VPLAIN(s->vec, k_begin, (g, TB, 0, st), s->M, s->h0p, grad, s->xbuf, s->gx, s->upd);
@@ -840,7 +863,7 @@ extern "C" int psignn_broyden_get_iterate(const psignn_broyden_t* s, int i, floa
 extern "C" int psignn_broyden_ext_begin(psignn_broyden_t* s, const float* d_x0, const float* d_fx0, void* stream) {
   ARG_CHECK(s && d_x0 && d_fx0, "NULL argument");
   hipStream_t st = (hipStream_t)stream;
-  k_init_status<<<4, TB, 0, st>>>(s->st, s->rel_trace, s->abs_trace, s->thr);
+  k_init_status<<<4, TB, 0, st>>>(s->st, s->rel_trace, s->abs_trace, s->thr, s->stop_abs);
   VPLAIN(s->vec, k_begin, ((unsigned)s->nblk, TB, 0, st), s->M, d_x0, d_fx0, s->xbuf, s->gx, s->upd);
   s->ext_iter = 0;
   HIP_TRY(hipGetLastError());

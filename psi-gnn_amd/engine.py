@@ -669,9 +669,17 @@ class DeviceBroyden:
     def nbytes(self):
         return int(nat.lib().psignn_broyden_bytes(self.handle))
 
+    def set_stop_mode(self, stop_mode: str):
+        """"rel" (default, every call site of the reference) or "abs" (solver.py:116,140,174)."""
+        if stop_mode not in ("rel", "abs"):
+            raise nat.NativeError(f"stop_mode {stop_mode!r}: 'rel' or 'abs'")
+        self.stop_mode = stop_mode
+        nat.check(nat.lib().psignn_broyden_set_stop_mode(self.handle, int(stop_mode == "abs")), "psignn_broyden_set_stop_mode")
+
     def _collect(self, info, rel, abs_, shape, dev):
         n_it = info.n_iter
-        out = {"nstep": int(info.nstep), "n_iter": int(n_it), "lowest": float(info.lowest),
+        low = float(info.lowest_abs if getattr(self, "stop_mode", "rel") == "abs" else info.lowest)
+        out = {"nstep": int(info.nstep), "n_iter": int(n_it), "lowest": low,
                "prot_break": bool(info.prot_break), "stop_reason": int(info.stop_reason)}
         # reference pads both traces to threshold+1 entries with the lowest values (solver.py:195-197)
         rel_l = list(rel[:n_it]) + [float(info.lowest)] * (self.threshold + 1 - n_it)

@@ -53,12 +53,16 @@ def broyden(f, x0, threshold, eps=1e-3, stop_mode="rel", ls=False, name="unknown
             poll_every=8):
     """Broyden's method on g(x) = f(x) - x  (reference: utilities/solver.py:116-207).
 
-    Same contract as the reference: ``result`` is the lowest-``rel`` iterate x (not f(x)), ``nstep`` its
-    index, ``rel = |f(x)-x| / (|f(x)| + 1e-9)``, stops on ``rel < eps``, the 30-step plateau rule, the
-    protective break (``rel > rel_0 * 1e3 * d``) or ``threshold`` iterations.
+    Same contract as the reference: ``result`` is the lowest-``stop_mode`` iterate x (not f(x)), ``nstep`` its
+    index, ``rel = |f(x)-x| / (|f(x)| + 1e-9)``, stops on ``objective < eps``, the 30-step plateau rule, the
+    protective break (``rel > rel_0 * 1e3 * d``; ``abs > abs_0 * 1e6 * d`` in stop_mode "abs") or ``threshold``
+    iterations.  ``ls=True`` (Armijo line search, solver.py:61-94) is not implemented: no call site of the reference
+    enables it.
     """
-    if stop_mode != "rel" or ls:
-        raise NotImplementedError("the reference only ever calls broyden with stop_mode='rel', ls=False")
+    if ls:
+        raise NotImplementedError("broyden(ls=True): the line search is not implemented (no reference call site uses it)")
+    if stop_mode not in ("rel", "abs"):
+        raise ValueError(f"stop_mode {stop_mode!r}")
     nat.require_cuda(x0, "x0")
     if x0.dim() != 2:
         raise nat.NativeError(f"x0 must be (N, d), got {tuple(x0.shape)}")
@@ -67,11 +71,13 @@ def broyden(f, x0, threshold, eps=1e-3, stop_mode="rel", ls=False, name="unknown
         keep_trace = (threshold + 2) * M * 4 <= TRACE_BUDGET_BYTES
     if isinstance(f, FixedPointMap):
         solver = DeviceBroyden(plan=f.plan, threshold=threshold, keep_trace=keep_trace)
+        solver.set_stop_mode(stop_mode)
         out = solver.solve(f, eps, poll_every=poll_every)
         x_init = f.h0
     else:
         solver = DeviceBroyden(threshold=threshold, keep_trace=keep_trace, n_elems=M, seq_len=x0.shape[1],
                                device=x0.device)
+        solver.set_stop_mode(stop_mode)
         out = solver.solve_callable(f, x0, eps)
         x_init = x0
     res = out["result"].reshape(x0.shape)

@@ -745,3 +745,23 @@ def test_tile_builder_survives_adversarial_inputs(kind, dev):
     assert rel_l2(fm.vjp(h.to(dev), w.to(dev)), orc.function_vjp(sd, h, h0, m, w)) < 5e-5
     out = pkg("utilities.solver").broyden(fm, h0.to(dev), threshold=10, eps=1e-9, keep_trace=False)
     assert out["n_iter"] == 10 and np.all(np.isfinite(out["rel_trace"][:10]))
+
+
+def test_broyden_stop_mode_abs(dev):
+    """stop_mode = "abs" (utilities/solver.py:116,140,163-181): objective, lowest-iterate tracking and the protective
+    factor follow the absolute residual.  Early iterations are not yet chaotic: same step count and traces as the oracle."""
+    g, mesh, md, sd, fmap = bind("hex13_dirichlet_s0", dev)
+    solver = pkg("utilities.solver")
+    h0 = torch.from_numpy(g["h0"])
+    with torch.no_grad():
+        want = orc.broyden(lambda H: orc.function_forward(sd, H, h0, mesh), h0, threshold=300, eps=3e-2, stop_mode="abs")
+    got = solver.broyden(fmap, fmap.h0, threshold=300, eps=3e-2, stop_mode="abs")
+    assert got["nstep"] == want["nstep"] == 11 and got["n_iter"] == 11
+    assert abs(got["lowest"] - want["lowest"]) < 1e-3 * want["lowest"]
+    assert np.allclose(got["abs_trace"][:11], want["abs_trace"][:11], rtol=2e-3)
+    assert len(got["abs_trace"]) == len(want["abs_trace"]) == 301
+    assert np.allclose(got["abs_trace"][11:], want["lowest"], rtol=1e-3)          # padded with lowest[stop_mode]
+    assert np.allclose(got["rel_trace"][11:], min(want["rel_trace"][:11]), rtol=2e-3)   # ... and lowest[alternative]
+    assert rel_l2(got["result"], want["result"]) < 1e-3   # an unconverged iterate after 11 steps (measured 1.3e-4)
+    with pytest.raises(NotImplementedError):
+        solver.broyden(fmap, fmap.h0, threshold=5, eps=1e-3, ls=True)
