@@ -179,6 +179,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tile
       }
     }
   } else {
+  // mixed family: the Phi_neumann projections are only read by Neumann lanes, i.e. in the few boundary tiles -- every
+  // other tile skips a third of its stage-1 work
+  bool tile_neu = false;
+  if (MIXED) tile_neu = __syncthreads_or(tid < n_t ? (flags[t0 + tid] & FLAG_NEUMANN) : 0) != 0;
   for (int row = tid; row < n_t + n_h; row += TILE_THREADS) {
     const int64_t node = row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t];
     float xr[D];
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tile
     q[2] = make_float4(ta[4].x, ta[4].y, tb[0].x, tb[0].y);
     q[3] = make_float4(tb[1].x, tb[1].y, tb[2].x, tb[2].y);
     q[4] = make_float4(tb[3].x, tb[3].y, tb[4].x, tb[4].y);
-    if (MIXED) {
+    if (MIXED && tile_neu) {
 #pragma unroll
       for (int p = 0; p < 5; ++p) ta[p] = splat(0.f);
       PHASE();
