@@ -105,3 +105,63 @@ __device__ __forceinline__ float edge_pass(const uint4* __restrict__ slots, int 
   return deg;
 }
 
+
+// Both directions of the neighbour sum in ONE walk over the slots: a pair-merged slot is decoded once, its 80-byte LDS row
+// [to | from] is read once, and the IN half (Phi_to, mirrored attr weights) and the OUT half (Phi_from) are evaluated back
+// to back.  Needs both attr blocks (60 wave-uniform floats) in SGPRs for the whole loop -- affordable once the phase
+// barriers keep every other scalar load out of the loop's live range.
+template <int RS>
+__device__ __forceinline__ void edge_pass_both(const uint4* __restrict__ slots, int nslots, const float* __restrict__ lds,
+                                               const float* __restrict__ AT_to, const float* __restrict__ AT_fr,
+                                               const v2f* Pi_to, const v2f* Pi_fr, v2f* S_to, v2f* S_fr, float& deg_in,
+                                               float& deg_out) {
+  v2f wt[15], wf[15];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) {
+    wt[i] = reinterpret_cast<const v2f*>(AT_to)[i];
+    wf[i] = reinterpret_cast<const v2f*>(AT_fr)[i];
+  }
+  deg_in = deg_out = 0.f;
+  if (nslots <= 0) return;
+  uint4 c0 = slots[0];
+  uint4 c1 = slots[(int64_t)min(1, nslots - 1) * 64];
+  for (int r = 0; r < nslots; ++r) {
+    const uint4 nx = slots[(int64_t)min(r + 2, nslots - 1) * 64];
+    const unsigned w = c0.x;
+    if ((w & 0xFFFFu) != ELL_EMPTY) {
+      const v2f a0 = splat(__uint_as_float(c0.y)), a1 = splat(__uint_as_float(c0.z)), a2 = splat(__uint_as_float(c0.w));
+      const float4* row = reinterpret_cast<const float4*>(lds + (int)(w & 0xFFFFu) * RS);
+      const float4 v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3], v4 = row[4];
+      if (w & SLOT_IN) {
+        v2f z[5] = {(v2f){v0.x, v0.y}, (v2f){v0.z, v0.w}, (v2f){v1.x, v1.y}, (v2f){v1.z, v1.w}, (v2f){v2.x, v2.y}};
+        deg_in += 1.f;
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] += Pi_to[p];
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wt[p], a0, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wt[5 + p], a1, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wt[10 + p], a2, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) S_to[p] += __builtin_elementwise_max(z[p], splat(0.f));
+      }
+      if (w & SLOT_OUT) {
+        v2f z[5] = {(v2f){v2.z, v2.w}, (v2f){v3.x, v3.y}, (v2f){v3.z, v3.w}, (v2f){v4.x, v4.y}, (v2f){v4.z, v4.w}};
+        deg_out += 1.f;
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] += Pi_fr[p];
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wf[p], a0, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wf[5 + p], a1, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wf[10 + p], a2, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) S_fr[p] += __builtin_elementwise_max(z[p], splat(0.f));
+      }
+    }
+    c0 = c1;
+    c1 = nx;
+  }
+}
