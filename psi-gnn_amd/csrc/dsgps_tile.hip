@@ -104,17 +104,19 @@ __global__ __launch_bounds__(TILE_THREADS) void k_dsgps_tile(int n_tiles, int ch
   const int slice = tile_slice[tile] + (tid >> 6);
   const uint4* slots = ell + (int64_t)slice_off[slice] * 64 + lane;
   const int nslots = slice_deg[slice];
-  v2f Pi[5], S_to[5], S_fr[5];
+  v2f Pi[5], Pi2[5], S_to[5], S_fr[5];
+  float deg_in, deg_out;
   ld5(W + dsl::B1_TO, Pi);
 #pragma unroll
   for (int p = 0; p < 5; ++p) S_to[p] = S_fr[p] = splat(0.f);
   PHASE();
   mv2<D>(W + dsl::W1I_TO, x, Pi);
-  const float deg_in = edge_pass<RS, 0, SLOT_IN>(slots, nslots, lds, W + dsl::A_TO, Pi, S_to);
-  ld5(W + dsl::B1_FR, Pi);
+  ld5(W + dsl::B1_FR, Pi2);
   PHASE();
-  mv2<D>(W + dsl::W1I_FR, x, Pi);
-  const float deg_out = edge_pass<RS, D, SLOT_OUT>(slots, nslots, lds, W + dsl::A_FR, Pi, S_fr);
+  mv2<D>(W + dsl::W1I_FR, x, Pi2);
+  PHASE();
+  edge_pass_both<RS>(slots, nslots, lds, W + dsl::A_TO, W + dsl::A_FR, Pi, Pi2, S_to, S_fr, deg_in, deg_out);
+  PHASE();
   if (MIXED && (fl & FLAG_NEUMANN)) {
     // H[update+1][index_neumann] = update_neumann([h | Phi_neumann(h) | prb | normal])   (mixed/dsgps/model.py:88-93)
     v2f S_n[5], hid[5], gN[5], y2[5];

@@ -66,17 +66,19 @@ __global__ __launch_bounds__(TILE_THREADS) void k_dss_tile(int n_tiles, int chun
   const int slice = tile_slice[tile] + (tid >> 6);
   const uint4* slots = ell + (int64_t)slice_off[slice] * 64 + lane;
   const int nslots = slice_deg[slice];
-  v2f Pi[5], S_to[5], S_fr[5];
+  v2f Pi[5], Pi2[5], S_to[5], S_fr[5];
+  float deg_in, deg_out;
   ld5(W + dss::B1_TO, Pi);
 #pragma unroll
   for (int p = 0; p < 5; ++p) S_to[p] = S_fr[p] = splat(0.f);
   PHASE();
   mv2<D>(W + dss::W1I_TO, x, Pi);
-  const float deg_in = edge_pass<RS, 0, SLOT_IN>(slots, nslots, lds, W + dss::A_TO, Pi, S_to);
-  ld5(W + dss::B1_FR, Pi);
+  ld5(W + dss::B1_FR, Pi2);
   PHASE();
-  mv2<D>(W + dss::W1I_FR, x, Pi);
-  const float deg_out = edge_pass<RS, D, SLOT_OUT>(slots, nslots, lds, W + dss::A_FR, Pi, S_fr);
+  mv2<D>(W + dss::W1I_FR, x, Pi2);
+  PHASE();
+  edge_pass_both<RS>(slots, nslots, lds, W + dss::A_TO, W + dss::A_FR, Pi, Pi2, S_to, S_fr, deg_in, deg_out);
+  PHASE();
   v2f mt[5], mf[5], b[5];
   ld5(W + dss::B2_TO, b);
 #pragma unroll
