@@ -147,7 +147,17 @@ class _DEQFn(torch.autograd.Function):
         cfg = deq.config_deq
         H0 = H_init.detach()
         fmap = deq.f.bind(H0, batch)
-        out_fw = cfg["solver"](fmap, H0, threshold=cfg["fw_thres"], eps=cfg["fw_tol"])
+        if cfg["solver"] is _solver.broyden:   # forward solver state kept between training steps on the same plan
+            old = getattr(deq, "_fw_key", None)
+            if old is None or old[0] is not fmap.plan or old[1] != cfg["fw_thres"]:
+                if getattr(deq, "_fw_solver", None) is not None:
+                    deq._fw_solver.close()
+                deq._fw_solver = engine.DeviceBroyden(plan=fmap.plan, threshold=cfg["fw_thres"], keep_trace=False)
+                deq._fw_key = (fmap.plan, cfg["fw_thres"])
+            out_fw = _solver.broyden(fmap, H0, threshold=cfg["fw_thres"], eps=cfg["fw_tol"], keep_trace=False,
+                                     solver_obj=deq._fw_solver)
+        else:
+            out_fw = cfg["solver"](fmap, H0, threshold=cfg["fw_thres"], eps=cfg["fw_tol"])
         H_star = out_fw["result"]
         deq.last_forward = out_fw
         _log(deq.path_logs, "forward_iteration.csv", "\n{} \t {}".format(out_fw["lowest"], out_fw["nstep"]))

@@ -50,7 +50,7 @@ class _LazyTrace:
 
 
 def broyden(f, x0, threshold, eps=1e-3, stop_mode="rel", ls=False, name="unknown", keep_trace=None,
-            poll_every=8):
+            poll_every=8, solver_obj=None):
     """Broyden's method on g(x) = f(x) - x  (reference: utilities/solver.py:116-207).
 
     Same contract as the reference: ``result`` is the lowest-``stop_mode`` iterate x (not f(x)), ``nstep`` its
@@ -70,7 +70,10 @@ def broyden(f, x0, threshold, eps=1e-3, stop_mode="rel", ls=False, name="unknown
     if keep_trace is None:
         keep_trace = (threshold + 2) * M * 4 <= TRACE_BUDGET_BYTES
     if isinstance(f, FixedPointMap):
-        solver = DeviceBroyden(plan=f.plan, threshold=threshold, keep_trace=keep_trace)
+        # solver_obj: a DeviceBroyden of the same plan / threshold kept by the caller between solves (a training loop
+        # would otherwise allocate and free 2 * threshold * N * d floats per step); its iterates are overwritten by the
+        # next solve, so it is only meant for callers that do not keep xest_trace
+        solver = solver_obj if solver_obj is not None else DeviceBroyden(plan=f.plan, threshold=threshold, keep_trace=keep_trace)
         solver.set_stop_mode(stop_mode)
         out = solver.solve(f, eps, poll_every=poll_every)
         x_init = f.h0
