@@ -28,23 +28,26 @@ def _dirichlet_mask(batch):
 
 @torch.no_grad()
 def errors_batch(u, batch):
-    """Five lists with one entry per graph of the batch (test_func.py:26-66)."""
+    """Five lists with one entry per graph of the batch (test_func.py:26-66).
+
+    The reference loops over the graphs on the host (five ``.item()`` reads per graph); here the per-graph sums are
+    segment reductions on the device and everything comes back in ONE device-to-host copy -- on the reference's own
+    protocol (50 graphs per batch) the metric loop used to cost three times the solve."""
     residual = engine.residual(engine.plan_for(batch), u, batch.y)
     gid = getattr(batch, "batch", None)
     if gid is None:
         gid = torch.zeros(u.shape[0], dtype=torch.long, device=u.device)
-    bound = _dirichlet_mask(batch)
-    out = [[], [], [], [], []]
-    for i in torch.unique(gid).tolist():
-        idx = gid == i
-        r, y, uu, sol = residual[idx], batch.y[idx], u[idx], batch.sol[idx]
-        b = bound[idx]
-        out[0].append(torch.mean(r ** 2).item())
-        out[1].append((torch.linalg.norm(r) / torch.linalg.norm(y)).item())
-        out[2].append(torch.mean((uu - sol) ** 2).item())
-        out[3].append((torch.linalg.norm(uu - sol) / torch.linalg.norm(sol)).item())
-        out[4].append(torch.mean((uu[b] - sol[b]) ** 2).item())
-    return tuple(out)
+    G = int(getattr(batch, "num_graphs", 0)) or int(gid.max().item()) + 1
+    bound = _dirichlet_mask(batch).reshape(-1).to(u.dtype)
+    err2 = ((u - batch.sol) ** 2).reshape(-1)
+    cols = torch.stack([torch.ones_like(err2), residual.reshape(-1) ** 2, batch.y.reshape(-1) ** 2, err2,
+                        batch.sol.reshape(-1) ** 2, bound, bound * err2], dim=1).double()
+    seg = torch.zeros(G, cols.shape[1], dtype=torch.float64, device=u.device).index_add_(0, gid, cols)
+    n, r2, y2, e2, s2, nb, be2 = seg.unbind(dim=1)
+    out = torch.stack([r2 / n, torch.sqrt(r2) / torch.sqrt(y2), e2 / n, torch.sqrt(e2) / torch.sqrt(s2), be2 / nb], dim=0)
+    present = (n > 0).cpu()
+    out = out.cpu()[:, present]
+    return tuple(row.tolist() for row in out)
 
 
 @torch.no_grad()

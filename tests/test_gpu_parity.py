@@ -689,6 +689,20 @@ def test_eval_harness_reference_protocol(dev):
     ref = {"Residual": 2.694e-3, "ResidualNorm": 1.752e-2, "MSE": 8.498e-3, "Rel": 1.448e-2, "MSEBound": 1.978e-5}
     for k, v in ref.items():  # dirichlet/psignn/test/test.ipynb cell 11
         assert 0.4 * v < rep["mean"][k] < 2.5 * v, (k, rep["mean"][k], v)
+    # the segment-reduced per-graph metrics equal the reference's per-graph loop (test_func.py:38-64) on a union batch
+    batch = data.collate(meshes[:6]).to(dev)
+    u6 = net(batch)[0]
+    got = ev.errors_batch(u6, batch)
+    r = pkg("engine").residual(pkg("engine").plan_for(batch), u6, batch.y).cpu()
+    uc, gid = u6.cpu(), batch.batch.cpu()
+    for i in range(6):
+        idx = gid == i
+        rr, yy, uu, ss = r[idx], batch.y.cpu()[idx], uc[idx], batch.sol.cpu()[idx]
+        bb = (batch.tags.cpu()[idx] == 1).reshape(-1)
+        want = (float(torch.mean(rr ** 2)), float(rr.norm() / yy.norm()), float(torch.mean((uu - ss) ** 2)),
+                float((uu - ss).norm() / ss.norm()), float(torch.mean((uu[bb] - ss[bb]) ** 2)))
+        for c in range(5):
+            assert abs(got[c][i] - want[c]) < 1e-5 * abs(want[c]) + 1e-12, (i, c)
     # single-graph metrics equal the golden ones
     u, loss, secs = ev.test_sample(net, meshes[0], dev)
     res = ev.errors_batch(u, meshes[0].to(dev))
