@@ -15,6 +15,7 @@
 // status block; the host only polls a done flag.  Reductions use fixed-shape partial sums ->
 // bitwise reproducible run to run.
 #include "common.h"
+#include <stdlib.h>
 #include <math.h>
 #include <algorithm>
 #include <vector>
@@ -558,7 +559,14 @@ int psignn_f_tile_fused(const psignn_plan* p, const float* W, int nl, float* xbu
 
 static int broyden_alloc(psignn_broyden* s) {
   size_t M = (size_t)s->M, thr = (size_t)s->thr;
-  s->vec = s->M >= (int64_t)4 << 20 ? 16 : 4;
+  // 16 floats per lane from 768 K elements up, 4 below (PSIGNN_VEC16_MIN overrides).  Re-tuned after the coalesced lane
+  // mapping, Broyden iterations/s with 4 vs 16 (dirichlet meshes, K = 100): 27 k nodes 12 790 / 10 156, 50 k 8 283 /
+  // 7 826, 100 k 4 578 / 4 972, 200 k 2 608 / 2 806, 400 k 1 416 / 1 551 (the old switch point was 4 M elements)
+  static const int64_t vec16_min = [] {
+    const char* e = getenv("PSIGNN_VEC16_MIN");
+    return e ? (int64_t)atoll(e) : (int64_t)3 << 18;
+  }();
+  s->vec = s->M >= vec16_min ? 16 : 4;
   s->nblk = (int)cdiv(s->M, (int64_t)s->vec * TB);
   s->jgroups = s->nblk >= 768 ? 1 : (int)std::min<int64_t>(8, cdiv(768, s->nblk));
   s->npart = s->nblk * (TB / 64);
