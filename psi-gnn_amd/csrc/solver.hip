@@ -49,6 +49,7 @@ struct psignn_broyden {
   int keep_trace = 0;
   int vec = 16;             // elements per thread of the vector kernels
   int nblk = 0, npart = 0;
+  int vec_ax = 0, nblk_ax = 0;  // axpy / final pass: own vector width on mid-size vectors (see broyden_alloc)
   int jgroups = 1;          // block rows of the U/V sweeps (short vectors are also split over the stored pairs)
   float* jpart = nullptr;   // (jgroups, 3, M) partial axpy sums when jgroups > 1
   float *U = nullptr, *V = nullptr;
@@ -570,7 +571,17 @@ static int broyden_alloc(psignn_broyden* s) {
   s->nblk = (int)cdiv(s->M, (int64_t)s->vec * TB);
   s->jgroups = s->nblk >= 768 ? 1 : (int)std::min<int64_t>(8, cdiv(768, s->nblk));
   s->npart = s->nblk * (TB / 64);
-  s->nn_cap = std::max<int>(s->nblk, s->plan ? (int)s->plan->n_tiles : 0);
+  // Mid-size vectors (16 floats per lane, but too few blocks to fill the chip): the dots pass is split over the stored
+  // pairs (free: every pair's partial sums are independent), the axpy pass would need a combine launch after such a split
+  // -- it runs unsplit with 4 floats per lane instead (100 k nodes: 91 us vs 79 + 20 us).  The thread -> element mapping
+  // is per kernel; only the pair partials that k_final reads must follow the axpy pass's block count.
+  s->vec_ax = s->vec;
+  s->nblk_ax = s->nblk;
+  if (s->vec == 16 && s->jgroups > 1 && cdiv(s->M, (int64_t)4 * TB) >= 512) {
+    s->vec_ax = 4;
+    s->nblk_ax = (int)cdiv(s->M, (int64_t)4 * TB);
+  }
+  s->nn_cap = std::max<int>(std::max(s->nblk, s->nblk_ax), s->plan ? (int)s->plan->n_tiles : 0);
   size_t nx = s->keep_trace ? thr + 2 : 3;
   s->ld = (s->M + 63) / 64 * 64;  // row pitch of U and V: every stored vector starts on a 256-byte boundary
   size_t ld = (size_t)s->ld;
@@ -588,7 +599,7 @@ static int broyden_alloc(psignn_broyden* s) {
     }
     s->bytes += a.n;
   }
-  if (s->jgroups > 1) {
+  if (s->jgroups > 1 && s->vec_ax == s->vec) {  // scratch of a split axpy pass
     size_t jb = (size_t)s->jgroups * 3 * M * 4;
     if (hipMalloc((void**)&s->jpart, jb) != hipSuccess) {
       psignn_set_error("broyden: hipMalloc of the split-sweep scratch failed");
@@ -695,6 +706,12 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
   LAUNCH("k_reduce_check", st, (k_reduce_check<<<dim3(std::max(kd, 1), 4), TB, 0, st>>>(
       s->st, s->part, s->npart, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace)));
   if (k >= s->thr) return;
+  if (s->vec_ax != s->vec) {  // unsplit, own width
+    const unsigned ga = (unsigned)s->nblk_ax;
+    VLAUNCH("k_axpy", st, s->vec_ax, k_axpy, (dim3(ga, 1), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->nblk_ax, std::max(k, 1), s->jpart, s->ld);
+    VLAUNCH("k_final", st, s->vec_ax, k_final, (ga, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->ld, s->part, s->nblk_ax);
+    return;
+  }
   VLAUNCH("k_axpy", st, s->vec, k_axpy, (dim3(g, G), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->nblk, js, s->jpart, s->ld);
   if (G > 1)
     VLAUNCH("k_axpy_combine", st, s->vec, k_axpy_combine, (g, TB, 0, st), s->M, k, G, s->st, s->jpart, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->nblk, s->ld);
