@@ -21,7 +21,9 @@
 // fully unrolled, the compiler hoists all their scalar loads to the top and then spills hundreds of SGPRs into VGPR
 // lanes (v_writelane / v_readlane = VALU issue slots in VALU-issue-bound kernels).  The barrier keeps each phase's
 // scalar loads next to their use.
+#ifndef PHASE
 #define PHASE() asm volatile("" ::: "memory")
+#endif
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
