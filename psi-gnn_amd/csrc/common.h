@@ -108,6 +108,10 @@ struct psignn_plan {
   uint8_t* slice_deg = nullptr;                // (n_slices) slot-rows of the slice (max neighbour slots of its nodes)
   uint4* ell = nullptr;                        // (ell_rows, 64) pair-merged slots {row|IN|OUT, a0, a1, a2}, tiles.hip
   uint8_t* flags_p = nullptr;                  // node flags in plan order
+  // mixed plans: tiles without Neumann nodes first, then the (few, boundary) tiles with Neumann nodes -- the f kernel
+  // runs the first group without the Phi_neumann columns in LDS (80-byte rows, one more workgroup per CU)
+  int32_t* tile_order = nullptr;               // (n_tiles) tile ids
+  int64_t n_tiles_plain = 0;                   // tiles in the first group
   float cell_size = 0.f, xmin = 0.f, ymin = 0.f;
   int nx = 0, ny = 0;
 };

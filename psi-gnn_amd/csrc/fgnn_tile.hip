@@ -58,17 +58,21 @@ __device__ __forceinline__ void lds_load10at(const float* __restrict__ p, float*
 // matrix cores (v_mfma_f32_16x16x4_f32) or packed VALU.
 #include <stdlib.h>
 #include <string.h>
-// default form per kernel flavour, from A/Bs on one box (1M-node mesh, after the scalar-load phase barriers removed the SGPR
-// spills of the VALU form): dirichlet plain f 64.6 us (valu) vs 67.7 us (mfma); mixed plain f 102.9 (valu) vs 102.2 (mfma);
-// fused Broyden step 102 us (valu) vs 122-125 us (mfma: it has to re-load x and update for stage 2, which the VALU form
-// gets for free from its stage-1 registers).  Before the barriers the VALU form spilled ~200 SGPRs and lost: 68.2 vs 66.3 us.
+// Default form: packed VALU everywhere.  A/Bs on one box (1M-node mesh) after the scalar-load phase barriers removed the
+// SGPR spills of the VALU form: dirichlet plain f 64.6 us (valu) vs 67.7 us (mfma); fused Broyden step 102 us (valu) vs
+// 122-125 us (mfma: it has to re-load x and update for stage 2, which the VALU form gets for free from its stage-1
+// registers); mixed plain f 102.9 (valu) vs 102.2 (mfma) in one launch, 81.8 us (valu) once the tiles without Neumann
+// nodes run with 80-byte LDS rows (launch_mixed).  Before the barriers the VALU form spilled ~200 SGPRs and lost: 68.2 vs
+// 66.3 us.  The MFMA form stays selectable (PSIGNN_STAGE1=mfma) for A/B runs.
 static int stage1_mfma(bool fused, bool mixed) {
   static int forced = [] {
     const char* e = getenv("PSIGNN_STAGE1");
     return !e ? -1 : (strcmp(e, "mfma") == 0 ? 1 : 0);
   }();
   if (forced >= 0) return forced;
-  return mixed && !fused;
+  (void)fused;
+  (void)mixed;
+  return 0;   // the MFMA form is kept for A/B runs (PSIGNN_STAGE1=mfma); see the comment above
 }
 
 // Broyden fusion (solver.hip): the kernel forms x_next = x_cur + update while loading, and its epilogue
@@ -93,7 +97,8 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 }
 
 template <int P, bool MIXED, bool FUSED, bool MFMA1>
-__global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
+__global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tiles, int chunk, const int32_t* __restrict__ tile_list,
+                                                const int32_t* __restrict__ tile_ptr,
                                                 const int32_t* __restrict__ tile_slice, const int32_t* __restrict__ halo,
                                                 const int32_t* __restrict__ halo_cnt, const int32_t* __restrict__ slice_off,
                                                 const uint8_t* __restrict__ slice_deg, const uint4* __restrict__ ell,
@@ -107,9 +112,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tile
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of tiles so that
   // neighbouring tiles' halo rows hit the same L2.  Speed only; any mapping is correct.
-  const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (tile >= n_tiles) return;
+  const int slot = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (slot >= n_tiles) return;
   if (FUSED && fa.st[fa.off_done]) return;
+  const int tile = tile_list ? tile_list[slot] : slot;   // mixed plans: a sub-list of the tiles (see launch_mixed)
   const int tid = threadIdx.x;
   const int32_t t0 = tile_ptr[tile];
   const int n_t = tile_ptr[tile + 1] - t0;
@@ -415,6 +421,38 @@ __global__ void k_permute_rows(int64_t N, int cols, const int32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------ host
+#define TILE_ARGS p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell, p->flags_p
+
+// Mixed family: two launches over disjoint tile groups.  Tiles without Neumann nodes (all but the boundary tiles) run the
+// kernel WITHOUT the Neumann branch and with 80-byte LDS rows (the Phi_neumann columns are only read by Neumann lanes);
+// the few tiles with Neumann nodes run the full kernel with 128-byte rows.  Same arithmetic per node either way.
+template <bool FUSED>
+static void launch_mixed(const psignn_plan* p, const FuseArgs& fa, const char* name, const float* W, int nl, const float* h,
+                         const int32_t* hsel, int64_t hstride, const float* h0, const float* prb, const float* nrm,
+                         float* out, hipStream_t st) {
+  using L = WLayout<3>;
+  const int lofs = L::layer(nl - 1), tofs = L::tp_layer(nl, true, nl - 1), tnofs = L::tp_neu(nl);
+  int na = (int)p->n_tiles_plain, nb = (int)(p->n_tiles - p->n_tiles_plain);
+  // the second launch costs ~10 us of latency: worth it only when the first group is long (1M nodes: plain f 99 -> 82 us;
+  // 100 k nodes: 3 % slower per Broyden iteration) -- below 2 048 plain tiles everything runs in the full kernel
+  const char* e = getenv("PSIGNN_MIXED_SPLIT_MIN");   // tests force the two-group path on small meshes with 0
+  if (na < (e ? atoi(e) : 2048)) {
+    na = 0;
+    nb = (int)p->n_tiles;
+  }
+  const int32_t* list_b = na > 0 ? p->tile_order + na : nullptr;
+  if (na > 0) {
+    const int chunk = (int)cdiv(na, 8);
+    LAUNCH(name, st, (k_f_tile<3, false, FUSED, false><<<(unsigned)(chunk * 8), TILE_THREADS, (size_t)p->max_rows * TileRow<false>::RS * 4, st>>>(
+        fa, na, chunk, p->tile_order, TILE_ARGS, W, lofs, tofs, tnofs, 1, h, hsel, hstride, h0, prb, nrm, out)));
+  }
+  if (nb > 0) {
+    const int chunk = (int)cdiv(nb, 8);
+    LAUNCH(name, st, (k_f_tile<3, true, FUSED, false><<<(unsigned)(chunk * 8), TILE_THREADS, (size_t)p->max_rows * TileRow<true>::RS * 4, st>>>(
+        fa, nb, chunk, list_b, TILE_ARGS, W, lofs, tofs, tnofs, 1, h, hsel, hstride, h0, prb, nrm, out)));
+  }
+}
+
 // All tensors in plan order.  h = hbase + (*hsel) * hstride when hsel != NULL.
 int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const float* h, const int32_t* hsel,
                           int64_t hstride, const float* h0, const float* prb, const float* nrm, float* out,
@@ -426,15 +464,14 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
   const unsigned grid = (unsigned)(chunk * 8);
   if (p->mixed) {
     using L = WLayout<3>;
-    size_t lds = (size_t)p->max_rows * TileRow<true>::RS * 4;
-    if (stage1_mfma(false, true))
+    if (stage1_mfma(false, true)) {  // single launch, MFMA stage 1 (PSIGNN_STAGE1=mfma)
+      size_t lds = (size_t)p->max_rows * TileRow<true>::RS * 4;
       LAUNCH("k_f_tile", st, (k_f_tile<3, true, false, true><<<grid, TILE_THREADS, lds, st>>>(
-        FuseArgs{}, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
-        p->flags_p, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), L::tp_neu(nl), 1, h, hsel, hstride, h0, prb, nrm, out)));
-    else
-      LAUNCH("k_f_tile", st, (k_f_tile<3, true, false, false><<<grid, TILE_THREADS, lds, st>>>(
-        FuseArgs{}, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
-        p->flags_p, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), L::tp_neu(nl), 1, h, hsel, hstride, h0, prb, nrm, out)));
+        FuseArgs{}, (int)p->n_tiles, chunk, nullptr, TILE_ARGS, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), L::tp_neu(nl), 1,
+        h, hsel, hstride, h0, prb, nrm, out)));
+    } else {
+      launch_mixed<false>(p, FuseArgs{}, "k_f_tile", W, nl, h, hsel, hstride, h0, prb, nrm, out, st);
+    }
   } else {
     using L = WLayout<2>;
     size_t lds = (size_t)p->max_rows * TileRow<false>::RS * 4;
@@ -444,13 +481,13 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
     for (int l = 0; l < nl; ++l) {
       float* dst = (l == nl - 1) ? out : pp[l & 1];
       if (stage1_mfma(false, false))
-      LAUNCH("k_f_tile", st, (k_f_tile<2, false, false, true><<<grid, TILE_THREADS, lds, st>>>(
-          FuseArgs{}, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
-          p->flags_p, W, L::layer(l), L::tp_layer(nl, false, l), 0, l == nl - 1, cur, l == 0 ? hsel : nullptr, hstride, h0, prb, nrm, dst)));
-    else
-      LAUNCH("k_f_tile", st, (k_f_tile<2, false, false, false><<<grid, TILE_THREADS, lds, st>>>(
-          FuseArgs{}, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
-          p->flags_p, W, L::layer(l), L::tp_layer(nl, false, l), 0, l == nl - 1, cur, l == 0 ? hsel : nullptr, hstride, h0, prb, nrm, dst)));
+        LAUNCH("k_f_tile", st, (k_f_tile<2, false, false, true><<<grid, TILE_THREADS, lds, st>>>(
+            FuseArgs{}, (int)p->n_tiles, chunk, nullptr, TILE_ARGS, W, L::layer(l), L::tp_layer(nl, false, l), 0, l == nl - 1, cur,
+            l == 0 ? hsel : nullptr, hstride, h0, prb, nrm, dst)));
+      else
+        LAUNCH("k_f_tile", st, (k_f_tile<2, false, false, false><<<grid, TILE_THREADS, lds, st>>>(
+            FuseArgs{}, (int)p->n_tiles, chunk, nullptr, TILE_ARGS, W, L::layer(l), L::tp_layer(nl, false, l), 0, l == nl - 1, cur,
+            l == 0 ? hsel : nullptr, hstride, h0, prb, nrm, dst)));
       cur = dst;
     }
   }
@@ -471,26 +508,25 @@ int psignn_f_tile_fused(const psignn_plan* p, const float* W, int nl, float* xbu
   FuseArgs fa{upd, gx, dg, xbuf, st_words, off_done, off_cur, off_nxt, M, part, npart};
   if (p->mixed) {
     using L = WLayout<3>;
-    size_t lds = (size_t)p->max_rows * TileRow<true>::RS * 4;
-    if (stage1_mfma(true, true))
+    if (stage1_mfma(true, true)) {
+      size_t lds = (size_t)p->max_rows * TileRow<true>::RS * 4;
       LAUNCH("k_f_tile_fused", st, (k_f_tile<3, true, true, true><<<grid, TILE_THREADS, lds, st>>>(
-        fa, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
-        p->flags_p, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), L::tp_neu(nl), 1, xbuf, nullptr, 0, h0, prb, nrm, nullptr)));
-    else
-      LAUNCH("k_f_tile_fused", st, (k_f_tile<3, true, true, false><<<grid, TILE_THREADS, lds, st>>>(
-        fa, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
-        p->flags_p, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), L::tp_neu(nl), 1, xbuf, nullptr, 0, h0, prb, nrm, nullptr)));
+        fa, (int)p->n_tiles, chunk, nullptr, TILE_ARGS, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), L::tp_neu(nl), 1, xbuf,
+        nullptr, 0, h0, prb, nrm, nullptr)));
+    } else {
+      launch_mixed<true>(p, fa, "k_f_tile_fused", W, nl, xbuf, nullptr, 0, h0, prb, nrm, nullptr, st);
+    }
   } else {
     using L = WLayout<2>;
     size_t lds = (size_t)p->max_rows * TileRow<false>::RS * 4;
     if (stage1_mfma(true, false))
       LAUNCH("k_f_tile_fused", st, (k_f_tile<2, false, true, true><<<grid, TILE_THREADS, lds, st>>>(
-        fa, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
-        p->flags_p, W, L::layer(0), L::tp_layer(nl, false, 0), 0, 1, xbuf, nullptr, 0, h0, prb, nrm, nullptr)));
+        fa, (int)p->n_tiles, chunk, nullptr, TILE_ARGS, W, L::layer(0), L::tp_layer(nl, false, 0), 0, 1, xbuf, nullptr, 0, h0, prb, nrm,
+        nullptr)));
     else
       LAUNCH("k_f_tile_fused", st, (k_f_tile<2, false, true, false><<<grid, TILE_THREADS, lds, st>>>(
-        fa, (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
-        p->flags_p, W, L::layer(0), L::tp_layer(nl, false, 0), 0, 1, xbuf, nullptr, 0, h0, prb, nrm, nullptr)));
+        fa, (int)p->n_tiles, chunk, nullptr, TILE_ARGS, W, L::layer(0), L::tp_layer(nl, false, 0), 0, 1, xbuf, nullptr, 0, h0, prb, nrm,
+        nullptr)));
   }
   HIP_TRY(hipGetLastError());
   return npart;

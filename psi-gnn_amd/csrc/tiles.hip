@@ -302,11 +302,11 @@ int psignn_exclusive_scan(const int32_t* in, int64_t n, int32_t* out, int32_t* b
 
 void psignn_tiles_free(psignn_plan* p) {
   void* ptrs[] = {p->perm, p->inv, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt,
-                  p->slice_off, p->slice_deg, p->ell, p->flags_p};
+                  p->slice_off, p->slice_deg, p->ell, p->flags_p, p->tile_order};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   p->perm = p->inv = p->tile_ptr = p->tile_slice = p->halo = p->halo_cnt = p->slice_off = nullptr;
-  p->slice_deg = nullptr; p->ell = nullptr; p->flags_p = nullptr;
+  p->slice_deg = nullptr; p->ell = nullptr; p->flags_p = nullptr; p->tile_order = nullptr;
   p->tiled = 0;
 }
 
@@ -322,6 +322,16 @@ void psignn_tiles_free(psignn_plan* p) {
 
 // Builds the tile structures.  Returns 0 and sets p->tiled = 1 on success; returns 0 with p->tiled = 0
 // when a structural limit was hit (the caller keeps the untiled plan); negative on HIP errors.
+__global__ void k_tile_has_neumann(int64_t n_tiles, const int32_t* __restrict__ tile_ptr, const uint8_t* __restrict__ flags_p,
+                                   uint8_t* __restrict__ has) {
+  const int64_t t = blockIdx.x;
+  if (t >= n_tiles) return;
+  int any = 0;
+  for (int32_t i = tile_ptr[t] + threadIdx.x; i < tile_ptr[t + 1]; i += blockDim.x) any |= flags_p[i] & FLAG_NEUMANN;
+  any = __syncthreads_or(any);
+  if (threadIdx.x == 0) has[t] = any ? 1 : 0;
+}
+
 int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipStream_t st) {
   const int64_t N = p->N;
   const unsigned TB = 256;
@@ -451,6 +461,26 @@ int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipS
                                                              p->slice_off, p->slice_deg, p->ell);
   HT(hipStreamSynchronize(st));
   HT(hipGetLastError());
+  if (p->mixed) {  // tile order: plain tiles first, tiles with Neumann nodes last
+    uint8_t* d_has = nullptr;
+    HT(hipMalloc((void**)&d_has, p->n_tiles + 1));
+    k_tile_has_neumann<<<(unsigned)p->n_tiles, 64, 0, st>>>(p->n_tiles, p->tile_ptr, p->flags_p, d_has);
+    std::vector<uint8_t> h_has(p->n_tiles);
+    hipError_t e1 = hipMemcpyAsync(h_has.data(), d_has, p->n_tiles, hipMemcpyDeviceToHost, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_has);
+    HT(e1);
+    HT(e2);
+    std::vector<int32_t> order;
+    order.reserve(p->n_tiles);
+    for (int64_t t = 0; t < p->n_tiles; ++t)
+      if (!h_has[t]) order.push_back((int32_t)t);
+    p->n_tiles_plain = (int64_t)order.size();
+    for (int64_t t = 0; t < p->n_tiles; ++t)
+      if (h_has[t]) order.push_back((int32_t)t);
+    HT(hipMalloc((void**)&p->tile_order, p->n_tiles * 4));
+    HT(hipMemcpy(p->tile_order, order.data(), p->n_tiles * 4, hipMemcpyHostToDevice));
+  }
   p->tiled = 1;
 done:
   for (void* q : {(void*)cnt, (void*)cptr, (void*)cur, (void*)bsum, (void*)misc, (void*)slice_tile, (void*)box})

@@ -711,6 +711,28 @@ def test_eval_harness_reference_protocol(dev):
     assert secs < 5.0
 
 
+def test_mixed_two_group_launch(dev, monkeypatch):
+    """Mixed plans run the tiles without Neumann nodes in a launch of their own (80-byte LDS rows, no Neumann branch)
+    when the mesh is large; forced here on small fixtures: bitwise the same f and the same Broyden solve as the
+    single-launch form."""
+    g, mesh, md, sd, fmap = bind("hex13_mixed_s1", dev)
+    data, eng = pkg("data"), pkg("engine")
+    big = data.make_hex_problem(40, seed=3, mixed=True).to(dev)     # 4 921 nodes, ~20 tiles, Neumann sides
+    solver = pkg("utilities.solver")
+    for m, h0 in ((md, fmap.h0), (big, torch.randn(big.num_nodes, 10, generator=torch.Generator().manual_seed(2)).to(dev))):
+        fm = eng.FixedPointMap(eng.MeshPlan(m), fmap.weights, h0, m.prb_data, m.unit_normal_vector)
+        x = 0.5 * h0
+        monkeypatch.setenv("PSIGNN_MIXED_SPLIT_MIN", "1000000")
+        one = fm(x)
+        s1 = solver.broyden(fm, h0, threshold=12, eps=1e-12, keep_trace=False)
+        monkeypatch.setenv("PSIGNN_MIXED_SPLIT_MIN", "0")
+        two = fm(x)
+        s2 = solver.broyden(fm, h0, threshold=12, eps=1e-12, keep_trace=False)
+        assert torch.equal(one, two)
+        assert s1["rel_trace"][:12] == s2["rel_trace"][:12] and torch.equal(s1["result"], s2["result"])
+    monkeypatch.delenv("PSIGNN_MIXED_SPLIT_MIN")
+
+
 # ------------------------------------------------------------------------------------------ adversarial geometry
 @pytest.mark.parametrize("kind", ["coincident", "line", "random_graph", "graded", "star"])
 def test_tile_builder_survives_adversarial_inputs(kind, dev):
