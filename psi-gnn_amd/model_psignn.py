@@ -248,25 +248,37 @@ class DeepEquilibrium(nn.Module):
         return self.config_deq["solver"](lambda y: fmap.vjp(H_star, y) + g, torch.zeros_like(g),
                                          threshold=self.config_deq["bw_thres"], eps=self.config_deq["bw_tol"])
 
+    @staticmethod
+    def _vjp_in_plan_order(fmap, H_star):
+        """(vjp, to_plan, from_plan) working in plan order where the tiled VJP applies (saves the four permutation
+        passes of the caller-order entry point per product; norms and inner products do not depend on the numbering)."""
+        if fmap.plan.tiled and not fmap.weights.mixed and fmap.weights.n_layers == 1:
+            Hp = fmap.to_plan(H_star)
+            return (lambda w: fmap.vjp_p(Hp, w)), fmap.to_plan, fmap.from_plan
+        ident = lambda t: t
+        return (lambda w: fmap.vjp(H_star, w)), ident, ident
+
     def jac_loss_estimate(self, H_star, H_init, batch, vecs=1, generator=None):
         """Hutchinson estimate of tr(J^T J) / (N d) (model.py:416-435) with the VJP kernel."""
         fmap = self.f.bind(H_init, batch)
+        vjp, to_p, _ = self._vjp_in_plan_order(fmap, H_star)
         acc = 0.0
         for _ in range(vecs):
             v = torch.randn(H_star.shape, device=H_star.device, generator=generator)
-            acc = acc + fmap.vjp(H_star, v).norm() ** 2
+            acc = acc + vjp(to_p(v)).norm() ** 2
         return acc / vecs / H_star.numel()
 
     def power_method(self, H_star, H_init, batch, n_iters=150, generator=None):
         """Spectral-radius estimate of J by power iteration on v^T J (model.py:437-452)."""
         fmap = self.f.bind(H_init, batch)
-        ev = torch.randn(H_star.shape, device=H_star.device, generator=generator)
+        vjp, to_p, from_p = self._vjp_in_plan_order(fmap, H_star)
+        ev = to_p(torch.randn(H_star.shape, device=H_star.device, generator=generator))
         val = torch.zeros((), device=H_star.device)
         for _ in range(n_iters):
-            vj = fmap.vjp(H_star, ev)
+            vj = vjp(ev)
             val = (vj * ev).sum() / (ev * ev).sum()
             ev = vj / vj.norm()
-        return ev, val.abs()
+        return from_p(ev), val.abs()
 
 
 # ----------------------------------------------------------------------------------------------
