@@ -197,6 +197,9 @@ int psignn_dsgps_step_p(const psignn_plan_t* plan, const float* d_weights, const
 int64_t psignn_dss_weights_size(int k);
 int psignn_dss_forward(const psignn_plan_t* plan, const float* d_weights, int k, float alpha, const float* d_bprime_norm,
                        float* d_out, float* d_work, void* stream);
+/* update t alone, state and b'_norm in plan order (the per-step loop of DeepStatisticalSolver.forward, model.py:77-93) */
+int psignn_dss_step_p(const psignn_plan_t* plan, const float* d_weights, int t, float alpha, const float* d_h,
+                      const float* d_bprime_norm_p, float* d_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Small dense pieces around the solve.

@@ -9,17 +9,20 @@ from . import data  # noqa: F401
 
 
 def install_reference_aliases():
-    """Register ``utilities`` / ``utilities.solver`` / ``model_psignn`` in ``sys.modules``.
+    """Register ``utilities`` / ``utilities.solver`` / ``model_psignn`` / ``model_dsgps`` / ``model_dss`` in ``sys.modules``
+    (the module names the reference's ``tests/`` scripts import: test_multiple.py:31-33, spec_geo_2.py:32-34).
 
     Reference checkpoints pickle ``config["solver"]`` by its qualified name ``utilities.solver.broyden``
     (training_class.py:60-66) and reference scripts do ``from utilities import solver`` /
     ``import model_psignn``; with the aliases installed both resolve to this package.
     """
-    from . import utilities, model_psignn
+    from . import utilities, model_psignn, dsgps, dss
     from .utilities import solver
     _sys.modules.setdefault("utilities", utilities)
     _sys.modules.setdefault("utilities.solver", solver)
     _sys.modules.setdefault("model_psignn", model_psignn)
+    _sys.modules.setdefault("model_dsgps", dsgps)
+    _sys.modules.setdefault("model_dss", dss)
 
 
 def load_reference_checkpoint(path, map_location="cpu"):

@@ -67,6 +67,7 @@ SIGNATURES = {
     "psignn_dsgps_step_p": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "psignn_dss_weights_size": (_I64, [_INT]),
     "psignn_dss_forward": (_INT, [_P, _P, _INT, C.c_float, _P, _P, _P, _P]),
+    "psignn_dss_step_p": (_INT, [_P, _P, _INT, C.c_float, _P, _P, _P, _P]),
     "psignn_mlp2": (_INT, [_P, _I64, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P]),
     "psignn_residual": (_INT, [_P, _P, _P, _P, _P]),
     "psignn_broyden_create": (_INT, [C.POINTER(_P), _P, _INT, _INT]),

@@ -147,3 +147,20 @@ extern "C" int psignn_dss_forward(const psignn_plan_t* p, const float* W, int k,
   HIP_TRY(hipGetLastError());
   return psignn_plan_permute(p, cur, D, d_out, 0, stream);
 }
+
+// One update (step t's weights) with the state and b'_norm in PLAN order: for callers that keep every iterate
+// (DeepStatisticalSolver.forward decodes and scores each of them, model.py:59-95).
+extern "C" int psignn_dss_step_p(const psignn_plan_t* p, const float* W, int t, float alpha, const float* d_h,
+                                 const float* d_bprime_p, float* d_out, void* stream) {
+  ARG_CHECK(p && W && d_h && d_bprime_p && d_out, "NULL argument");
+  ARG_CHECK(t >= 0, "negative step index");
+  ARG_CHECK(p->tiled, "DSS kernels need a tiled plan (mesh positions)");
+  ARG_CHECK(d_out != d_h, "out must not alias the state");
+  hipStream_t st = (hipStream_t)stream;
+  const int chunk = (int)cdiv(p->n_tiles, 8);
+  LAUNCH("k_dss_tile", st, (k_dss_tile<<<(unsigned)(chunk * 8), TILE_THREADS, (size_t)p->max_rows * 20 * 4, st>>>(
+      (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
+      W + (int64_t)t * dss::STEP, alpha, d_h, d_bprime_p, d_out)));
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}

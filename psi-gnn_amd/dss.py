@@ -5,7 +5,12 @@ reference's module tree (``phi_to_list / phi_from_list / psi_list / decoder_list
 ``load_state_dict(ckpt["state_dict"])`` of ``dirichlet/dss/results/dss_results/ckpt/best_model.pt`` works unchanged.
 
 * ``inference(batch) -> U_k``   (model.py:97-120)
-* ``residual_loss(U, edge_index, a_ij, b_prime)``   (model.py:122-139), diagnostics only.
+* ``forward(batch) -> (U, loss_dic)``: every decoded iterate and the ``residual_loss / mse_loss / mse_dirichlet_loss``
+  traces plus ``train_loss`` (model.py:59-95, tests/model_dss.py:58-104), as diagnostics (no graph)
+* ``residual_loss(U, edge_index, a_ij, b_prime)``   (model.py:122-139).
+
+The copy under the reference's ``tests/`` names the edge fields ``edge_attr / edge_attr_norm`` instead of
+``a_ij / a_ij_norm``; both spellings are accepted.
 
 ``batch`` carries the DSS schema of ``dirichlet/dss/utilities/reader.py:61-92`` (``edge_index`` without self loops,
 ``a_ij``, ``a_ij_norm``, ``b_prime``, ``b_prime_norm``, ``pos``); ``to_dss_batch(mesh)`` derives it from a PSI-GNN
@@ -70,13 +75,23 @@ class DeepStatisticalSolver(nn.Module):
         return self._packed
 
     @staticmethod
+    def _fields(batch):
+        """(a_ij, a_ij_norm) under either spelling (dirichlet/dss/model.py vs tests/model_dss.py)."""
+        a = getattr(batch, "a_ij", None)
+        an = getattr(batch, "a_ij_norm", None)
+        if an is None:
+            a, an = batch.edge_attr, batch.edge_attr_norm
+        return a, an
+
+    @staticmethod
     def _plan(batch):
         """Mesh plan of the DSS graph: the scalar edge feature rides in the third edge_attr column."""
         plan = getattr(batch, "_dss_plan", None)
         if plan is None:
-            z = torch.zeros((batch.a_ij_norm.shape[0], 2), dtype=torch.float32, device=batch.a_ij_norm.device)
-            view = MeshData(x=batch.x, edge_index=batch.edge_index, a_ij=batch.a_ij,
-                            edge_attr=torch.cat([z, batch.a_ij_norm.reshape(-1, 1).float()], dim=1).contiguous(),
+            a_ij, a_norm = DeepStatisticalSolver._fields(batch)
+            z = torch.zeros((a_norm.shape[0], 2), dtype=torch.float32, device=a_norm.device)
+            view = MeshData(x=batch.x, edge_index=batch.edge_index, a_ij=a_ij,
+                            edge_attr=torch.cat([z, a_norm.reshape(-1, 1).float()], dim=1).contiguous(),
                             tags=torch.zeros((batch.x.shape[0], 1), dtype=torch.float32, device=batch.x.device),
                             pos=batch.pos)
             plan = engine.MeshPlan(view)
@@ -95,6 +110,31 @@ class DeepStatisticalSolver(nn.Module):
     def inference(self, batch):
         k = self.config["k"]
         return self.decoder_list[k - 1](self.latent(batch, k))
+
+    @torch.no_grad()
+    def forward(self, batch):
+        nat.require_cuda(batch.x, "batch.x")
+        k, alpha, gamma = self.config["k"], self.config["alpha"], self.config["gamma"]
+        plan, w = self._plan(batch), self.packed(batch.x.device)
+        a_ij, _ = self._fields(batch)
+        idx = torch.where(batch.b_prime[:, 1] == 1)[0]
+        hp = torch.zeros((plan.N, engine.D), dtype=torch.float32, device=batch.x.device)
+        bp = plan.permute(batch.b_prime_norm, True)
+        U = {"0": self.decoder_list[0](hp) + batch.x * 0}     # H_0 = 0 in any numbering
+        res = {"0": self.residual_loss(U["0"], batch.edge_index, a_ij, batch.b_prime)}
+        mse = {"0": self.mse_loss(U["0"], batch.x)}
+        msd = {"0": self.mse_loss(U["0"][idx, :], batch.x[idx, :])}
+        total = None
+        for t in range(k):
+            hp = engine.dss_step_p(plan, w, t, alpha, hp, bp)
+            s = str(t + 1)
+            U[s] = self.decoder_list[t](plan.permute(hp, False))
+            res[s] = self.residual_loss(U[s], batch.edge_index, a_ij, batch.b_prime)
+            mse[s] = self.mse_loss(U[s], batch.x)
+            msd[s] = self.mse_loss(U[s][idx, :], batch.x[idx, :])
+            term = res[s] * gamma ** (k - t - 1)
+            total = term if total is None else total + term
+        return U, {"train_loss": total, "residual_loss": res, "mse_loss": mse, "mse_dirichlet_loss": msd}
 
     @torch.no_grad()
     def residual_loss(self, U, edge_index, a_ij, y):

@@ -504,6 +504,15 @@ def dss_forward(plan: "MeshPlan", wflat, bprime_norm, k: int, alpha: float):
     return out
 
 
+def dss_step_p(plan: "MeshPlan", wflat, t: int, alpha: float, hp, bprime_p):
+    """DSS update t, state and b'_norm in plan order."""
+    out = torch.empty_like(hp)
+    with torch.cuda.device(hp.device):
+        nat.check(nat.lib().psignn_dss_step_p(plan.handle, nat.ptr(wflat), int(t), float(alpha), nat.ptr(_f32c(hp)),
+                                              nat.ptr(bprime_p), nat.ptr(out), nat.stream_ptr(hp.device)), "psignn_dss_step_p")
+    return out
+
+
 def unpack_param_grads(flat, n_layers=1, mixed=False):
     """Name the entries of a flat parameter gradient (layout = leading section of ``pack_weights``)."""
     if n_layers != 1:

@@ -43,3 +43,24 @@ def test_dss_inference_parity(name, dev):
     assert abs(float(orc.dss_residual_loss(u.cpu(), ob.edge_index, ob.a_ij, ob.b_prime)) - res) < 1e-3 * res
     with pytest.raises(pkg("_native").NativeError):
         net.latent(b, 31)    # no weights for a 31st update
+
+
+def test_dss_forward_diagnostics(dev):
+    """DeepStatisticalSolver.forward (model.py:59-95 / tests/model_dss.py:58-104): every decoded iterate and the loss traces;
+    the tests/ spelling of the edge fields (edge_attr / edge_attr_norm) is accepted."""
+    sd, net = _net(dev)
+    _, mesh = load_case("original_dirichlet_s0")
+    g = np.load(os.path.join(GOLDEN, "dss_original_dirichlet_s0.npz"))
+    dss = pkg("dss")
+    b = dss.to_dss_batch(mesh).to(dev)
+    U, ld = net(b)
+    k = net.config["k"]
+    assert list(U) == [str(i) for i in range(k + 1)]
+    assert set(ld) == {"train_loss", "residual_loss", "mse_loss", "mse_dirichlet_loss"}
+    assert rel_l2(U[str(k)], g["u_k64"]) < 1e-4 and torch.equal(U[str(k)], net.inference(b))
+    res = np.array([float(ld["residual_loss"][str(i)]) for i in range(1, k + 1)])
+    assert np.allclose(res, g["res_trace"], rtol=2e-2)
+    assert abs(float(ld["mse_loss"][str(k)]) - float(g["mse"])) < 1e-3 * float(g["mse"])
+    alt = pkg("data").MeshData(x=b.x, sol=b.sol, edge_index=b.edge_index, edge_attr=b.a_ij, edge_attr_norm=b.a_ij_norm,
+                               b_prime=b.b_prime, b_prime_norm=b.b_prime_norm, pos=b.pos, tags=b.tags)
+    assert torch.equal(net.inference(alt), U[str(k)])
