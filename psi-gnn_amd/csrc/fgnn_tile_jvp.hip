@@ -9,6 +9,11 @@
 //            dS += 1[z > 0] (dPi + dPj);  then the tangent of the folded gate / update MLP and of LayerNorm.
 // Dirichlet rows of f are constants: their tangent is 0.
 #include "tile_helpers.h"
+#include <stdlib.h>
+#include <string.h>
+#ifndef JVP_STAGE1_DEFAULT_MFMA
+#define JVP_STAGE1_DEFAULT_MFMA 0   // A/B at 1M nodes: 114 us (mfma) vs 100 us (valu)
+#endif
 
 __device__ __forceinline__ void lds_row10(const float* __restrict__ row, v2f* r) {  // 16-byte aligned
   float4 v0 = reinterpret_cast<const float4*>(row)[0], v1 = reinterpret_cast<const float4*>(row)[1];
@@ -65,7 +70,7 @@ __device__ __forceinline__ float edge_pass_jvp(const uint4* __restrict__ slots, 
   return deg;
 }
 
-template <int P>
+template <int P, bool MFMA1>
 __global__ __launch_bounds__(TILE_THREADS) void k_jvp_tile(int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
                                                            const int32_t* __restrict__ tile_slice,
                                                            const int32_t* __restrict__ halo, const int32_t* __restrict__ halo_cnt,
@@ -87,6 +92,52 @@ __global__ __launch_bounds__(TILE_THREADS) void k_jvp_tile(int n_tiles, int chun
   const float* T = W + tofs;
   // ---- stage 1
   float x[D], dx[D];
+  if constexpr (MFMA1) {
+    // Both dense products of stage 1 -- state rows and tangent rows times the neighbour-side weights -- on the matrix
+    // cores, exactly as in k_f_tile's MFMA stage 1 (weights = A operand, 16 node rows = B, a lane receives four
+    // consecutive outputs of one row = one 16-byte LDS store; the f32 MFMA sums k in order: same bits as the VALU form).
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = tid & 63, g = lane >> 4, c = lane & 15, wave = tid >> 6;
+    float wa[2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int sk = 0; sk < 3; ++sk) {
+        const int o = 16 * mt + c, k = 4 * sk + g;
+        float v = 0.f;
+        if (k < D && o < 2 * D) v = (o < D ? T + L::T_W1J_TO : T + L::T_W1J_FR)[k * D + (o % D)];
+        wa[mt][sk] = v;
+      }
+    const int rows = n_t + n_h;
+    for (int nt = wave; nt * 16 < rows; nt += TILE_THREADS / 64) {
+      const int row = nt * 16 + c;
+      const bool ok = row < rows;
+      const int64_t node = !ok ? (int64_t)t0 : (row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t]);
+#pragma unroll
+      for (int src = 0; src < 2; ++src) {   // 0: state rows -> columns 0..19, 1: tangent rows -> columns 20..39
+        const float* base = src ? tv : h;
+        float xb[3];
+#pragma unroll
+        for (int sk = 0; sk < 3; ++sk) {
+          const int k = 4 * sk + g;
+          xb[sk] = (ok && k < D) ? base[node * D + k] : 0.f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int sk = 0; sk < 3; ++sk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][sk], xb[sk], acc, 0, 0, 0);
+          const int o0 = 16 * mt + 4 * g;
+          if (ok && o0 < 2 * D)
+            *reinterpret_cast<float4*>(lds + row * RS + 2 * D * src + o0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+      }
+    }
+    if (tid < n_t) {
+      load10(h + (int64_t)(t0 + tid) * D, x);
+      load10(tv + (int64_t)(t0 + tid) * D, dx);
+    }
+  } else {
   for (int row = tid; row < n_t + n_h; row += TILE_THREADS) {
     const int64_t node = row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t];
     float xr[D], vr[D];
@@ -119,6 +170,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_jvp_tile(int n_tiles, int chun
     q[7] = make_float4(da[4].x, da[4].y, db[0].x, db[0].y);
     q[8] = make_float4(db[1].x, db[1].y, db[2].x, db[2].y);
     q[9] = make_float4(db[3].x, db[3].y, db[4].x, db[4].y);
+  }
   }
   __syncthreads();
   if (tid >= n_t) return;
@@ -250,9 +302,19 @@ int psignn_f_tile_jvp(const psignn_plan* p, const float* W, int nl, const float*
   const int chunk = (int)cdiv(p->n_tiles, 8);
   const size_t lds = (size_t)p->max_rows * 40 * 4;
   ARG_CHECK(lds <= 160 * 1024, "tile + halo rows exceed the LDS budget of the tiled JVP");
-  LAUNCH("k_jvp_tile", st, (k_jvp_tile<2><<<(unsigned)(chunk * 8), TILE_THREADS, lds, st>>>(
-      (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
-      p->flags_p, W, L::layer(0), L::tp_layer(nl, false, 0), h, prb, v, out)));
+  // stage-1 form: PSIGNN_JVP_STAGE1 = mfma | valu (default: see the A/B in DESIGN.md)
+  static const int use_mfma = [] {
+    const char* e = getenv("PSIGNN_JVP_STAGE1");
+    return e ? (strcmp(e, "mfma") == 0) : JVP_STAGE1_DEFAULT_MFMA;
+  }();
+  if (use_mfma)
+    LAUNCH("k_jvp_tile", st, (k_jvp_tile<2, true><<<(unsigned)(chunk * 8), TILE_THREADS, lds, st>>>(
+        (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
+        p->flags_p, W, L::layer(0), L::tp_layer(nl, false, 0), h, prb, v, out)));
+  else
+    LAUNCH("k_jvp_tile", st, (k_jvp_tile<2, false><<<(unsigned)(chunk * 8), TILE_THREADS, lds, st>>>(
+        (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
+        p->flags_p, W, L::layer(0), L::tp_layer(nl, false, 0), h, prb, v, out)));
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }
