@@ -711,6 +711,23 @@ def test_eval_harness_reference_protocol(dev):
     assert secs < 5.0
 
 
+def test_concurrent_shard_solves(dev):
+    """batch.solve_shard(streams=k): independent meshes solved concurrently on k HIP streams / host threads give
+    bit-identical results to solving them one after the other (BASELINE configs[3] protocol)."""
+    data, batch = pkg("data"), pkg("batch")
+    net = pkg("model_psignn").ModelPSIGNN(dict(latent_dim=10, n_layers=1, fw_tol=1e-5, fw_thres=300))
+    net.load_state_dict(load_weights("dirichlet"))
+    net = net.to(dev).eval()
+    meshes = [data.make_hex_problem(10 + (s % 3), seed=s) for s in range(7)]
+    seq = batch.solve_shard(net, meshes, dev)
+    par = batch.solve_shard(net, meshes, dev, streams=4)
+    assert [r[0] for r in par] == list(range(7))
+    for a, b in zip(seq, par):
+        assert torch.equal(a[1], b[1]) and a[2]["nsteps"] == b[2]["nsteps"]
+    some = batch.solve_shard(net, meshes, dev, indices=[5, 1], streams=2)
+    assert [r[0] for r in some] == [1, 5] and torch.equal(some[0][1], seq[1][1])
+
+
 def test_mixed_two_group_launch(dev, monkeypatch):
     """Mixed plans run the tiles without Neumann nodes in a launch of their own (80-byte LDS rows, no Neumann branch)
     when the mesh is large; forced here on small fixtures: bitwise the same f and the same Broyden solve as the
