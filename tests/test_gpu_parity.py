@@ -821,3 +821,59 @@ def test_broyden_stop_mode_abs(dev):
     assert rel_l2(got["result"], want["result"]) < 1e-3   # an unconverged iterate after 11 steps (measured 1.3e-4)
     with pytest.raises(NotImplementedError):
         solver.broyden(fmap, fmap.h0, threshold=5, eps=1e-3, ls=True)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_graphs_plan_tiles_and_f(seed, dev):
+    """Randomised sweep: graphs with duplicate edges, one-directional edges, self loops, partly mirrored attrs, random
+    tags (both families) and random positions.  Integer structures bit-exact vs the numpy statements (plan_ref.py), tile
+    structures bit-exact when the plan tiles, f vs the oracle."""
+    from plan_ref import tile_reference
+    data, eng = pkg("data"), pkg("engine")
+    rng = np.random.default_rng(100 + seed)
+    N = int(rng.integers(40, 900))
+    deg = int(rng.integers(2, 7))
+    src = np.repeat(np.arange(N), deg)
+    dst = (src + rng.integers(1, 12, size=src.size)) % N            # local neighbours -> small halos, plan tiles
+    keep = rng.random(src.size) < 0.9
+    src, dst = src[keep], dst[keep]
+    attr = rng.standard_normal((src.size, 3)).astype(np.float32)
+    back = rng.random(src.size) < 0.7                                # 70 % of the edges get their mirror edge ...
+    exact = rng.random(src.size) < 0.8                               # ... most of them with the exact mirror attr
+    mattr = attr[back] * np.array([-1, -1, 1], dtype=np.float32)
+    mattr[~exact[back]] += 0.25
+    ei = np.concatenate([np.stack([src, dst]), np.stack([dst[back], src[back]]), np.stack([np.arange(N), np.arange(N)]),
+                         np.stack([src[:5], dst[:5]])], axis=1)      # + self loops + 5 duplicate edges
+    ea = np.concatenate([attr, mattr, np.zeros((N, 3), np.float32), attr[:5]], axis=0)
+    order = rng.permutation(ei.shape[1])
+    ei, ea = ei[:, order], ea[order]
+    mixed = seed % 2 == 1
+    kind = rng.integers(0, 3 if mixed else 2, size=N) if mixed else (rng.random(N) < 0.15).astype(np.int64)
+    tags = np.eye(3, dtype=np.float32)[kind] if mixed else kind.reshape(-1, 1).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    m = data.MeshData(x=t(rng.standard_normal((N, 1)).astype(np.float32)), edge_index=t(ei.astype(np.int64)), edge_attr=t(ea),
+                      a_ij=t(rng.standard_normal((ei.shape[1], 1)).astype(np.float32)), y=torch.zeros(N, 1), sol=torch.zeros(N, 1),
+                      prb_data=t(rng.standard_normal((N, 3 if mixed else 2)).astype(np.float32)), tags=t(tags),
+                      pos=t(np.stack([np.arange(N) % 30, np.arange(N) // 30], axis=1).astype(np.float32) + 0.1 * rng.random((N, 2)).astype(np.float32)))
+    if mixed:
+        m.unit_normal_vector = t(rng.standard_normal((N, 2)).astype(np.float32))
+    md = m.to(dev)
+    plan = eng.MeshPlan(md, tile_target=int(rng.choice([0, 32, 100])))
+    ref = plan_reference(ei, N)
+    for k in ("csr_ptr", "csr_nbr", "csr_eid", "csc_ptr", "csc_nbr", "csc_eid", "a_ptr", "a_col"):
+        assert np.array_equal(plan.export(k), ref[k]), k
+    if plan.tiled:
+        perm, tile_ptr = plan.export("perm"), plan.export("tile_ptr")
+        tr = tile_reference(ei, N, perm, tile_ptr, ea)
+        assert np.array_equal(plan.export("halo_cnt"), tr["halo_cnt"])
+        assert np.array_equal(plan.export("slice_deg"), tr["slice_deg"])
+        assert np.array_equal(plan.export("ell").reshape(-1, 64, 4), tr["ell"])
+    sd = load_weights("mixed" if mixed else "dirichlet")
+    h0 = t(0.3 * rng.standard_normal((N, 10)).astype(np.float32))
+    h = t(0.3 * rng.standard_normal((N, 10)).astype(np.float32))
+    fm = eng.FixedPointMap(plan, eng.PackedWeights(sd, dev), h0.to(dev), md.prb_data, getattr(md, "unit_normal_vector", None))
+    with torch.no_grad():
+        want = orc.function_forward(sd, h.clone(), h0, m)
+    assert rel_l2(fm(h.to(dev)), want) < 5e-6, (seed, plan.tiled)
+    w = t(rng.standard_normal((N, 10)).astype(np.float32))
+    assert rel_l2(fm.vjp(h.to(dev), w.to(dev)), orc.function_vjp(sd, h, h0, m, w)) < 5e-5
