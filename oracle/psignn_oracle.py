@@ -354,10 +354,27 @@ def function_param_vjp(sd, h, h_initial, batch, v):
     return {k[len("deqdss.f."):]: t for k, t in zip(names, g[:-2])}, g[-2], g[-1]
 
 
-def training_step(sd, batch, solver=broyden, fw_tol=1e-5, fw_thres=500, bw_tol=1e-8, bw_thres=500):
+def function_vjp_backward(sd, h, h_initial, batch, v, gbar):
+    """Double backward of the VJP, as ``loss.backward()`` runs it for the Jacobian regulariser (jac_loss_estimate,
+    dirichlet/psignn/model.py:416-435: ``autograd.grad(f0, z0, v, create_graph=True)``): gradient of
+    gbar . (J_f(h)ᵀ v), gbar constant, w.r.t. the ``deqdss.f.*`` parameters and h.  Returns ({name: grad}, d/dh, Jᵀv)."""
+    p = {k: (t.detach().clone().requires_grad_(True) if k.startswith("deqdss.f.") else t) for k, t in sd.items()}
+    hh = h.detach().clone().requires_grad_(True)
+    out = function_forward(p, hh, h_initial.detach(), batch)
+    g = torch.autograd.grad(out, hh, v, create_graph=True)[0]
+    names = [k for k in p if k.startswith("deqdss.f.")]
+    gr = torch.autograd.grad((g * gbar).sum(), [p[k] for k in names] + [hh], allow_unused=True)
+    zero = lambda k, t: torch.zeros_like(p[k]) if t is None else t
+    return {k[len("deqdss.f."):]: zero(k, t) for k, t in zip(names, gr[:-1])}, gr[-1], g.detach()
+
+
+def training_step(sd, batch, solver=broyden, fw_tol=1e-5, fw_thres=500, bw_tol=1e-8, bw_thres=500, jac_weight=0.0,
+                  probe=None):
     """One training forward + ``loss.backward()`` of the dirichlet or mixed model (chosen by the state dict; the two
-    ``ModelDEQDSS.forward`` differ only in the tag column of the Dirichlet rows), jac_weight = 0 (the reference default,
-    utilities/utils.py:58): returns (loss, loss_dic, {state_dict name: grad}, forward dict, backward dict).
+    ``ModelDEQDSS.forward`` differ only in the tag column of the Dirichlet rows): returns (loss, loss_dic,
+    {state_dict name: grad}, forward dict, backward dict).  ``jac_weight`` (utilities/utils.py:58 default 0; the launch
+    scripts use 1.0) weights the Jacobian regulariser ``|probeᵀ J|² / (N d)`` built with ``create_graph=True``
+    (jac_loss_estimate, model.py:416-435; ``probe`` stands for its ``torch.randn``).
 
     Restates ``ModelDEQDSS.forward`` (model.py:58-99), ``DeepEquilibrium.forward`` incl. the backward hook that swaps
     the incoming gradient for the solution of y = Jᵀy + grad (model.py:184-225) and the loss combination of
@@ -370,6 +387,10 @@ def training_step(sd, batch, solver=broyden, fw_tol=1e-5, fw_thres=500, bw_tol=1
     H_star = out_fw["result"].detach().clone().requires_grad_()
     new_H = function_forward(p, H_star, h_init, batch)
     state = {}
+    jac_loss = torch.zeros(())
+    if probe is not None:   # model.py:207, before the hook is registered
+        vJ = torch.autograd.grad(new_H, H_star, probe, retain_graph=True, create_graph=True)[0]
+        jac_loss = vJ.norm() ** 2 / H_star.numel()
 
     def backward_hook(grad):
         state["hook"].remove()   # the reference removes the hook first so that the VJPs below do not re-enter it
@@ -387,7 +408,8 @@ def training_step(sd, batch, solver=broyden, fw_tol=1e-5, fw_thres=500, bw_tol=1
     loss_dic["mse_loss"] = mse(u, batch.sol)
     idx = torch.where(batch.tags == 1)[0]   # model.py:87 (mixed: one-hot tags -> every row)
     loss_dic["mse_dirichlet"] = mse(u[idx, :], batch.x[idx, :])
-    loss = loss_dic["residual_loss"] + loss_dic["encoder_loss"] + loss_dic["autoencoder_loss"]
+    loss_dic["jacobian_loss"] = jac_loss
+    loss = loss_dic["residual_loss"] + jac_weight * jac_loss + loss_dic["encoder_loss"] + loss_dic["autoencoder_loss"]
     loss.backward()
     grads = {k: (t.grad if t.grad is not None else torch.zeros_like(t)) for k, t in p.items()}
     return loss.detach(), {k: v.detach() for k, v in loss_dic.items()}, grads, out_fw, state.get("out_bw")

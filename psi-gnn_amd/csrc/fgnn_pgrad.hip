@@ -254,6 +254,40 @@ extern "C" int psignn_f_param_vjp_p(const psignn_plan_t* p, const float* W, int 
   return PSIGNN_OK;
 }
 
+// ---- backward of the VJP (the Jacobian regulariser's gradient; kernels and derivation in fgnn_jacreg.hip)
+int psignn_jacreg_records(const psignn_plan* p, const float* W, const float* h, const float* prb, const float* v,
+                          const float* gbar, float* out_h, float* work, float* rec, hipStream_t st);
+
+extern "C" int64_t psignn_f_vjp_backward_workspace_floats(const psignn_plan_t* p) {
+  if (!p) return 0;
+  int npw;
+  const int nblk = pgrad_blocks(2 * p->N, &npw);
+  return p->N * (13 * D + 2 * PGREC) + (int64_t)nblk * TabF::NT * 256;
+}
+
+// Gradient of  phi = gbar . (J_f(h)^T v) = v^T J_f(h) gbar  (gbar constant) w.r.t. the parameters (d_grad, layout of
+// psignn_f_param_vjp) and w.r.t. h (d_grad_h): what autograd's double backward leaves after
+// autograd.grad(f(h), h, v, create_graph=True) -- jac_loss_estimate, dirichlet/psignn/model.py:416-435.  Caller's numbering.
+extern "C" int psignn_f_vjp_backward(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* prb,
+                                     const float* v, const float* gbar, float* d_grad, float* d_grad_h, float* work,
+                                     void* stream) {
+  ARG_CHECK(p && W && h && prb && v && gbar && d_grad && d_grad_h && work, "NULL argument");
+  ARG_CHECK(!p->mixed && nl == 1, "the backward of the VJP is implemented for single-layer dirichlet blocks");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t N = p->N;
+  float* rec = work + N * 13 * D;
+  float* part = rec + 2 * N * PGREC;
+  int npw;
+  const int nblk = pgrad_blocks(2 * N, &npw);
+  int rc = psignn_jacreg_records(p, W, h, prb, v, gbar, d_grad_h, work, rec, st);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)WLayout<2>::base_total(nl, false) * 4, st));
+  LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabF><<<nblk, 256, 0, st>>>(2 * N, npw, rec, part)));
+  LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabF::NT, 256, 0, st>>>(nblk, TabF::NT, part, d_grad, MapF())));
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Backward of the two-layer MLP (Encoder / Decoder, model.py:370-392; y = W2 relu(W1 x + b1) + b2) and the
 // transposed residual SpMV -- what autograd runs for the autoencoder / residual terms of the training loss

@@ -187,6 +187,7 @@ class MeshPlan:
         self.max_tile_rows = int(nat.lib().psignn_plan_max_tile_rows(h))
         self._work = None
         self._pwork = None
+        self._jwork = None
 
     def export(self, name):
         which, dt = _EXPORT[name]
@@ -216,6 +217,12 @@ class MeshPlan:
             n = int(nat.lib().psignn_f_param_vjp_workspace_floats(self.handle))
             self._pwork = torch.empty(n, dtype=torch.float32, device=self.device)
         return self._pwork
+
+    def vjp_backward_workspace(self):
+        if self._jwork is None:
+            n = int(nat.lib().psignn_f_vjp_backward_workspace_floats(self.handle))
+            self._jwork = torch.empty(n, dtype=torch.float32, device=self.device)
+        return self._jwork
 
     def permute(self, t, to_plan=True):
         """Rows of an (N, cols) float tensor between the caller's numbering and plan order."""
@@ -399,6 +406,22 @@ class FixedPointMap:
                                            nat.ptr(Hc), nat.ptr(self.prb), nat.ptr(self.nrm), nat.ptr(Wc), nat.ptr(grad),
                                            nat.ptr(out), nat.ptr(self.plan.pgrad_workspace()),
                                            nat.stream_ptr(Hc.device)), "psignn_f_param_vjp")
+        return unpack_param_grads(grad, self.weights.n_layers, self.weights.mixed), out
+
+    def vjp_backward(self, H, V, Gbar):
+        """Gradient of  Gbar . (J_f(H)^T V)  with Gbar held constant: ({name: grad}, d / dH) -- what autograd's double
+        backward computes for ``autograd.grad(f(H), H, V, create_graph=True)`` (jac_loss_estimate,
+        dirichlet/psignn/model.py:416-435).  Single-layer dirichlet blocks, caller's numbering."""
+        Hc, Vc, Gc = _f32c(H), _f32c(V), _f32c(Gbar)
+        l = nat.lib()
+        grad = torch.empty(int(l.psignn_param_grad_size(int(self.weights.mixed), self.weights.n_layers)),
+                           dtype=torch.float32, device=Hc.device)
+        out = torch.empty_like(Hc)
+        with torch.cuda.device(Hc.device):
+            nat.check(l.psignn_f_vjp_backward(self.plan.handle, nat.ptr(self.weights.flat), self.weights.n_layers,
+                                              nat.ptr(Hc), nat.ptr(self.prb), nat.ptr(Vc), nat.ptr(Gc), nat.ptr(grad),
+                                              nat.ptr(out), nat.ptr(self.plan.vjp_backward_workspace()),
+                                              nat.stream_ptr(Hc.device)), "psignn_f_vjp_backward")
         return unpack_param_grads(grad, self.weights.n_layers, self.weights.mixed), out
 
     def phi(self, H, which: int, layer: int = 0):

@@ -180,6 +180,26 @@ class _DEQFn(torch.autograd.Function):
         return (g_init, None, None, None) + tuple(grads[n] for n in ctx.names)
 
 
+class _JacLossFn(torch.autograd.Function):
+    """jac_loss = |v^T J_f(H*)|^2 / (N d) with its gradient w.r.t. the parameters of f: the reference builds the VJP with
+    ``create_graph=True`` (jac_loss_estimate, dirichlet/psignn/model.py:416-435) and lets ``loss.backward()`` run the
+    double backward; here backward is the HIP backward-of-the-VJP (csrc/fgnn_jacreg.hip).  H* is a leaf in the
+    reference (model.py:204), so nothing flows back into the solve."""
+
+    @staticmethod
+    def forward(ctx, fmap, H_star, v, names, *params):
+        g = fmap.vjp(H_star, v)
+        ctx.fmap, ctx.names = fmap, names
+        ctx.save_for_backward(H_star, v, g)
+        return g.norm() ** 2 / H_star.numel()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        H_star, v, g = ctx.saved_tensors
+        grads, _ = ctx.fmap.vjp_backward(H_star, v, g * (2.0 * grad_out / H_star.numel()))
+        return (None, None, None, None) + tuple(grads[n] for n in ctx.names)
+
+
 def _log(path_logs, name, line):
     if path_logs:
         with open(os.path.join(path_logs, name), "a") as f:
@@ -205,8 +225,8 @@ class DeepEquilibrium(nn.Module):
     def train_forward(self, H_init, batch, generator=None):
         """(new_H_star, jacobian_loss) of the training variant.  With gradients enabled new_H_star carries the
         implicit-function backward; without (validation) the spectral radius is logged like the reference does.
-        The Jacobian regulariser is returned as a value only (``jac_weight`` defaults to 0 in the reference,
-        utilities/utils.py:58; its second-order gradient is not implemented)."""
+        The Jacobian regulariser carries its gradient w.r.t. the parameters of f in the dirichlet family
+        (``_JacLossFn``; the reference's launch scripts train with ``jac_weight 1.0``); in the mixed family it is a value only."""
         if torch.is_grad_enabled():
             if self.f.n_layers != 1:
                 raise nat.NativeError("the training path is implemented for single-layer blocks")
@@ -218,6 +238,13 @@ class DeepEquilibrium(nn.Module):
             self.last_forward = out_fw
             H_star = out_fw["result"]
             new_H = self.f.bind(H_init, batch)(H_star)
+        if torch.is_grad_enabled() and not self.f.mixed:
+            # differentiable w.r.t. the parameters of f, as in the reference (vecs = 1, model.py:207)
+            v = torch.randn(H_star.shape, device=H_star.device, generator=generator)
+            self.last_probe = v
+            jac_loss = _JacLossFn.apply(self.f.bind(H_init.detach(), batch), H_star, v, tuple(n for n, _ in named),
+                                        *[p for _, p in named])
+            return new_H, jac_loss
         with torch.no_grad():
             jac_loss = self.jac_loss_estimate(H_star, H_init.detach(), batch, vecs=1, generator=generator)
             if not torch.is_grad_enabled() and self.path_logs:

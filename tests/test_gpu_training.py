@@ -59,6 +59,27 @@ def test_param_vjp_parity(name, dev):
     assert torch.equal(want_h0, torch.where(mask, v, torch.zeros_like(v)))
 
 
+@pytest.mark.parametrize("name", ["original_dirichlet_s0", "hex13_dirichlet_s0", "hex26_dirichlet_s0"])
+def test_vjp_backward_parity(name, dev):
+    """Double backward of the VJP (the Jacobian regulariser's gradient, model.py:416-435) vs autograd on the oracle,
+    per tensor <= 2e-4 of the largest tensor's norm."""
+    g, mesh, md, sd, fmap = _bind(name, dev)
+    h = torch.from_numpy(g["f1"])
+    gen = torch.Generator().manual_seed(31)
+    v = torch.randn(h.shape, generator=gen)
+    gq = fmap.vjp(h.to(dev), v.to(dev)).cpu()
+    gbar = 2.0 * gq / h.numel()            # d jac_loss / d g for jac_loss = |g|^2 / (N d)
+    grads, out_h = fmap.vjp_backward(h.to(dev), v.to(dev), gbar.to(dev))
+    want, want_h, want_g = orc.function_vjp_backward(sd, h, torch.from_numpy(g["h0"]), mesh, v, gbar)
+    assert rel_l2(gq, want_g) < 2e-5
+    assert set(grads) == set(want)
+    scale = max(float(t.norm()) for t in want.values())
+    _cmp(grads, want, 2e-4, scale)
+    assert rel_l2(out_h, want_h) < 2e-4
+    g2, _ = fmap.vjp_backward(h.to(dev), v.to(dev), gbar.to(dev))
+    assert all(torch.equal(grads[k], g2[k]) for k in grads)   # fixed reduction order
+
+
 def test_param_vjp_other_tile_sizes(dev):
     g, mesh, md, sd, fmap = _bind("hex26_dirichlet_s0", dev)
     eng = pkg("engine")
@@ -146,6 +167,33 @@ def test_training_step_gradients(name, dev):
     print("worst gradient error", _cmp(got, wg, 1e-2 if CASES[name] == "mixed" else 5e-3, scale))
 
 
+def test_training_step_with_jacobian_regulariser(dev):
+    """jac_weight = 1 (the reference's launch scripts): loss.backward() also runs the double backward of the VJP.  The
+    regulariser is weighted 50x here so that its gradient is visible next to the residual term's."""
+    name, jw = "hex13_dirichlet_s0", 50.0
+    g, mesh = load_case(name)
+    sd = load_weights(CASES[name])
+    net = _model(sd, dev, fw_tol=1e-7, fw_thres=600).train()
+    u, ld = net(mesh.to(dev))
+    assert ld["jacobian_loss"].requires_grad
+    loss = ld["residual_loss"] + jw * ld["jacobian_loss"] + ld["encoder_loss"] + ld["autoencoder_loss"]
+    loss.backward()
+    probe = net.deqdss.last_probe.cpu()
+    wl, wld, wg, fw, bw = orc.training_step(sd, mesh, fw_tol=1e-7, fw_thres=600, bw_tol=1e-7, bw_thres=400, jac_weight=jw,
+                                            probe=probe)
+    _, _, wg0, _, _ = orc.training_step(sd, mesh, fw_tol=1e-7, fw_thres=600, bw_tol=1e-7, bw_thres=400)
+    print("jac", float(ld["jacobian_loss"]), float(wld["jacobian_loss"]), "loss", float(loss), float(wl))
+    assert abs(float(ld["jacobian_loss"]) - float(wld["jacobian_loss"])) < 2e-3 * float(wld["jacobian_loss"])
+    assert abs(float(loss) - float(wl)) < 5e-3 * float(wl)
+    got = {k: p.grad for k, p in net.named_parameters()}
+    scale = max(float(t.norm()) for t in wg.values())
+    # the regulariser's share of the gradient is not negligible (else this test would not see it)
+    share = max(float((wg[k] - wg0[k]).norm()) for k in wg) / scale
+    print("regulariser share of the gradient", share)
+    assert share > 0.05
+    print("worst gradient error", _cmp(got, wg, 5e-3, scale))
+
+
 def test_trainer_steps_and_checkpoint(dev, tmp_path):
     """TrainModel (training_class.py surface): a few optimisation steps on two meshes lower the training loss;
     checkpoints carry the reference's keys and resume."""
@@ -170,8 +218,13 @@ def test_trainer_steps_and_checkpoint(dev, tmp_path):
     tr2.load_model(str(tmp_path / "running_model.pt"))
     assert tr2.hist_train == tr.hist_train
     assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(tr2.model.state_dict().values(), net.state_dict().values()))
-    with pytest.raises(pkg("_native").NativeError):
-        TrainModel(dict(cfg, jac_weight=0.1))
+    # the reference's launch configuration (jac_weight 1.0, launch_local.sh:24): one more epoch with the regulariser
+    tr3 = TrainModel(dict(cfg, jac_weight=1.0, max_epochs=1, path_ckpt=None))
+    tr3.train_model()
+    assert torch.isfinite(torch.tensor(tr3.hist_train["loss"])).all() and tr3.hist_train["jacobian_loss"][0] > 0
+    with pytest.raises(pkg("_native").NativeError):   # mixed family: the regulariser's gradient is not implemented
+        mixed_net = pkg("model_psignn").ModelDEQDSS(dict(net.config, bc="mixed"))
+        TrainModel(dict(cfg, model=mixed_net, jac_weight=0.1))
 
 
 def test_trainer_with_reference_style_wrappers(dev):
