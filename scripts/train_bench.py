@@ -2,7 +2,10 @@
 hexagon meshes -- forward Broyden solve, on-device adjoint solve, parameter-VJP, optimiser -- on the HIP path, with
 the CPU oracle's restated training step (autograd + restated broyden) timed beside it on the same batch.
 
-    python3 scripts/train_bench.py [graphs_per_batch=50] [hex_n=13] [steps=5] [cpu=1]
+    python3 scripts/train_bench.py [graphs_per_batch=50] [hex_n=13] [steps=5] [cpu=1] [jac_weight=0]
+
+jac_weight = 1 is what the reference's launch scripts use (launch_local.sh:24): the step then also runs the backward of
+the VJP (csrc/fgnn_jacreg.hip).
 
 The reference trains on ~500-node meshes (hsize 0.08) in PyG batches; hex_n = 13 gives 547 nodes per graph.
 Prints one JSON line."""
@@ -24,6 +27,7 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 13
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     cpu = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    jw = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0
     data, nat = pkg("data"), pkg("_native")
     import numpy as np
     w = np.load(os.path.join(ROOT, "tests", "golden", "weights_dirichlet.npz"))
@@ -39,7 +43,7 @@ def main():
     TrainModel = pkg("training_class").TrainModel
     tr = TrainModel(dict(loader_train=[], loader_val=[], model=net, config_model=net.config, lr_deq=1e-6, lr_ae=1e-6,
                          sched_step_deq=0.5, sched_step_ae=0.5, path_ckpt=None, min_loss_save=1e9, max_epochs=0,
-                         gradient_clip=1e-2, sup_weight=0.0, jac_weight=0.0))
+                         gradient_clip=1e-2, sup_weight=0.0, jac_weight=jw))
     bd = batch.to(dev)
     warm, _ = tr.train_step(bd)  # warm-up (plan build, allocations); lr = 1e-6 keeps the weights at the checkpoint
     warm = float(warm.detach())
@@ -57,14 +61,16 @@ def main():
     kern = nat.prof_collect()
     nat.prof_enable(False)
     out = {"workload": f"training step, union batch of {B} hexagon meshes (n={n}): {batch.num_nodes} nodes, "
-                       f"{batch.num_edges} edges; fw_tol 1e-5 / bw_tol 1e-8, thresholds 500 (reference defaults)",
+                       f"{batch.num_edges} edges; fw_tol 1e-5 / bw_tol 1e-8, thresholds 500 (reference defaults), jac_weight {jw}",
            "gpu_s_per_step": dt, "gpu_graphs_per_s": B / dt, "first_step_loss": warm, "fw_nstep": fw, "bw_nstep": bw, "loss": losses,
            "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])[:12]}}
     if cpu:
         from oracle import psignn_oracle as orc
         torch.set_num_threads(min(32, os.cpu_count() or 1))
         t0 = time.perf_counter()
-        wl, _, _, ofw, obw = orc.training_step(sd, batch, fw_tol=1e-5, fw_thres=500, bw_tol=1e-8, bw_thres=500)
+        probe = torch.randn(batch.num_nodes, 10, generator=torch.Generator().manual_seed(0)) if jw else None
+        wl, _, _, ofw, obw = orc.training_step(sd, batch, fw_tol=1e-5, fw_thres=500, bw_tol=1e-8, bw_thres=500,
+                                               jac_weight=jw, probe=probe)
         ct = time.perf_counter() - t0
         out.update(cpu_s_per_step=ct, cpu_threads=torch.get_num_threads(), cpu_fw_nstep=ofw["nstep"],
                    cpu_bw_nstep=obw["nstep"], cpu_loss=float(wl), speedup=ct / dt,
