@@ -174,11 +174,11 @@ int psignn_f_param_vjp_p(const psignn_plan_t* plan, const float* d_weights, int 
  * jac_loss_estimate -- autograd.grad(f0, z0, v, create_graph=True), dirichlet/psignn/model.py:416-435 -- when the
  * Jacobian regulariser is part of the loss (jac_weight, training_class.py:156-159): with g = J^T v and
  * jac_loss = |g|^2 / (N d), pass gbar = (d loss / d jac_loss) * 2 g / (N d).  Caller's numbering; single-layer
- * dirichlet blocks.  d_work: psignn_f_vjp_backward_workspace_floats(plan) floats. */
+ * blocks of both families (mixed: d_normals required, d_grad also covers phi_neumann | update_neumann).  d_work: psignn_f_vjp_backward_workspace_floats(plan) floats. */
 int64_t psignn_f_vjp_backward_workspace_floats(const psignn_plan_t* plan);
 int psignn_f_vjp_backward(const psignn_plan_t* plan, const float* d_weights, int n_layers, const float* d_h,
-                          const float* d_prb, const float* d_v, const float* d_gbar, float* d_grad, float* d_grad_h,
-                          float* d_work, void* stream);
+                          const float* d_prb, const float* d_normals, const float* d_v, const float* d_gbar, float* d_grad,
+                          float* d_grad_h, float* d_work, void* stream);
 
 /* Backward of psignn_mlp2 and of psignn_residual: what autograd runs for the autoencoder and residual terms of
  * the training loss (dirichlet/psignn/model.py:58-99).  d_gflat = gradients of [W1 | b1 | W2 | b2];

@@ -60,7 +60,7 @@ SIGNATURES = {
     "psignn_f_param_vjp": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P, _P]),
     "psignn_f_param_vjp_p": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P]),
     "psignn_f_vjp_backward_workspace_floats": (_I64, [_P]),
-    "psignn_f_vjp_backward": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "psignn_f_vjp_backward": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "psignn_mlp2_backward_workspace_floats": (_I64, [_I64]),
     "psignn_mlp2_backward": (_INT, [_P, _P, _I64, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P]),
     "psignn_residual_t": (_INT, [_P, _P, _P, _P, _P]),

@@ -1,4 +1,4 @@
-// Backward of the vector-Jacobian product of f_theta (gfx950; dirichlet family, single layer, caller's numbering).
+// Backward of the vector-Jacobian product of f_theta (gfx950; both families, single layer, caller's numbering).
 //
 // The reference's Jacobian regulariser  jac_loss = |v^T J_f(H*)|^2 / (N d)  (jac_loss_estimate, dirichlet/psignn/model.py:
 // 416-435, one Gaussian probe v) is built with autograd.grad(..., create_graph=True) and enters the training loss with
@@ -21,11 +21,12 @@
 //        chat^T (dE/d theta_e) gbar, whose right factors are gbar and S' and which has no bias / edge-feature part).
 //   4. the MFMA outer-product reduction of fgnn_pgrad.hip over the 2 N records.
 // Dirichlet rows of f are constants: no node-level terms, they only act as neighbours.
+// Mixed family: a Neumann row is update_neumann([h, Phi_neumann(h), prb, normal]) before LayerNorm (mixed/psignn/model.py:
+// 236,241) -- piecewise linear up to LayerNorm, so its only second-order term is LayerNorm's; its factors go to the
+// record groups 20..29 of the mixed parameter-VJP (fgnn_vjp.hip PgRec).
 #include "fgnn_common.h"
 
 #define PHASE() asm volatile("" ::: "memory")
-#define JR_REC 320
-using L2 = WLayout<2>;
 
 template <int K, bool ACC>
 __device__ __forceinline__ void jr_matvecT(const float* __restrict__ W, int ld, int off, const float* g, float* out) {
@@ -37,23 +38,26 @@ __device__ __forceinline__ void jr_matvecT(const float* __restrict__ W, int ld, 
     out[k] = s;
   }
 }
+// z[o] = Pi[o] + pj[o] + W1[o, 20:23] . a   (W1 = first Phi layer, row length 23)
 __device__ __forceinline__ void jr_edge_z(const float* __restrict__ W1, const float* Pi, const float* pj, float a0, float a1,
                                           float a2, float* z) {
+  constexpr int EIN = 2 * D + 3;
 #pragma unroll
   for (int o = 0; o < D; ++o) {
     float t = Pi[o] + pj[o];
-    t = fmaf(W1[o * L2::EIN + 2 * D], a0, t);
-    t = fmaf(W1[o * L2::EIN + 2 * D + 1], a1, t);
-    t = fmaf(W1[o * L2::EIN + 2 * D + 2], a2, t);
+    t = fmaf(W1[o * EIN + 2 * D], a0, t);
+    t = fmaf(W1[o * EIN + 2 * D + 1], a1, t);
+    t = fmaf(W1[o * EIN + 2 * D + 2], a2, t);
     z[o] = t;
   }
 }
-// one 16-float record group: v[0..n) then up to three trailing values, rest 0
+// one 16-float record group: v[0..n) then up to five trailing values, rest 0
 __device__ __forceinline__ void jr_group(float* __restrict__ g, const float* v, int n, float t0 = 0.f, float t1 = 0.f,
-                                         float t2 = 0.f) {
+                                         float t2 = 0.f, float t3 = 0.f, float t4 = 0.f) {
   float r[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) r[i] = i < n ? v[i] : (i == n ? t0 : (i == n + 1 ? t1 : (i == n + 2 ? t2 : 0.f)));
+  for (int i = 0; i < 16; ++i)
+    r[i] = i < n ? v[i] : (i == n ? t0 : (i == n + 1 ? t1 : (i == n + 2 ? t2 : (i == n + 3 ? t3 : (i == n + 4 ? t4 : 0.f)))));
   float4* q = reinterpret_cast<float4*>(g);
 #pragma unroll
   for (int i = 0; i < 4; ++i) q[i] = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
@@ -62,151 +66,223 @@ __device__ __forceinline__ void jr_zero(float* __restrict__ g, int first, int la
   for (int i = first * 4; i < last * 4; ++i) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// neighbour-side projections of two node fields: P[n] = { W1j_to a_n, W1j_fr a_n, W1j_to b_n, W1j_fr b_n }
-__global__ __launch_bounds__(256) void k_jr_project(int64_t N, const float* __restrict__ W, const float* __restrict__ a,
-                                                    const float* __restrict__ b, float* __restrict__ P) {
-  int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  const float* Wto = W + L2::layer(0) + L2::L_TO + L2::PHI_W1;
-  const float* Wfr = W + L2::layer(0) + L2::L_FROM + L2::PHI_W1;
-  float x[D], t[D];
-  load10(a + n * D, x);
-  matvec10<D, false>(Wto, L2::EIN, D, x, t);
-  store10(P + n * 4 * D, t);
-  PHASE();
-  matvec10<D, false>(Wfr, L2::EIN, D, x, t);
-  store10(P + n * 4 * D + D, t);
-  load10(b + n * D, x);
-  PHASE();
-  matvec10<D, false>(Wto, L2::EIN, D, x, t);
-  store10(P + n * 4 * D + 2 * D, t);
-  PHASE();
-  matvec10<D, false>(Wfr, L2::EIN, D, x, t);
-  store10(P + n * 4 * D + 3 * D, t);
+template <bool MIXED>
+struct JrDims {
+  static constexpr int NP = MIXED ? 3 : 2;      // Phi modules: to, from [, neumann]
+  static constexpr int PJ = 2 * NP * D;         // P row: NP primal projections, then NP tangent ones
+  static constexpr int NB = MIXED ? 6 : 4;      // B row: Pt, Pf, dS_to, dS_fr [, Pn, dS_n]
+  static constexpr int REC = MIXED ? 480 : 320;
+};
+
+// LayerNorm of y with tangent dy and probe w: psi = sum_o w_o gamma_o dyhat_o.  Returns ybar = d psi / d y,
+// dybar = d psi / d dy (the first-order LayerNorm backward of w) and gln = d psi / d gamma.
+__device__ __forceinline__ void jr_layernorm(const float* __restrict__ W, const float* w, float* y, const float* dy, float* ybar,
+                                             float* dybar, float* gln) {
+  float mu = 0.f, var = 0.f;
+#pragma unroll
+  for (int o = 0; o < D; ++o) mu += y[o];
+  mu *= (1.f / D);
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    const float c = y[o] - mu;
+    var = fmaf(c, c, var);
+  }
+  var *= (1.f / D);
+  const float rs = 1.f / sqrtf(var + 1e-5f);
+  float p[D], m1 = 0.f, m2 = 0.f, P1 = 0.f, P2 = 0.f;
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    y[o] = (y[o] - mu) * rs;  // normalised
+    p[o] = w[o] * W[o];       // W = ln_gamma
+    m1 += dy[o];
+    m2 = fmaf(y[o], dy[o], m2);
+    P1 += p[o];
+    P2 = fmaf(p[o], y[o], P2);
+  }
+  m1 *= (1.f / D);
+  m2 *= (1.f / D);
+  P1 *= (1.f / D);
+  P2 *= (1.f / D);
+  // dyhat = rs (dy - m1 - yhat m2)
+  float psi = 0.f, yhb[D], Y1 = 0.f, Y2 = 0.f;
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    const float dyh = rs * (dy[o] - m1 - y[o] * m2);
+    gln[o] = w[o] * dyh;
+    psi = fmaf(p[o], dyh, psi);
+    dybar[o] = rs * (p[o] - P1 - y[o] * P2);
+    yhb[o] = -rs * (dy[o] * P2 + p[o] * m2);   // adjoint of yhat
+    Y1 += yhb[o];
+    Y2 = fmaf(yhb[o], y[o], Y2);
+  }
+  Y1 *= (1.f / D);
+  Y2 *= (1.f / D);
+#pragma unroll
+  for (int o = 0; o < D; ++o) ybar[o] = rs * (yhb[o] - Y1 - y[o] * Y2) - psi * rs * y[o] * (1.f / D);  // last term: rs itself
 }
 
-// step 1: cb[n] = { mp_to, mp_fr, t_to, t_fr };  rec1 groups 3, 4 = (S | deg);  rec2 groups 3, 4 = (S' | 0)
+// neighbour-side projections of h (primal) and gbar (tangent): P[n] = { W1j_m h_n : m } { W1j_m gbar_n : m }
+template <int P, bool MIXED>
+__global__ __launch_bounds__(256) void k_jr_project(int64_t N, const float* __restrict__ W, const float* __restrict__ a,
+                                                    const float* __restrict__ b, float* __restrict__ Pb) {
+  using L = WLayout<P>;
+  using J = JrDims<MIXED>;
+  int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float x[D], t[D];
+#pragma unroll 1
+  for (int f = 0; f < 2; ++f) {
+    load10((f ? b : a) + n * D, x);
+    float* dst = Pb + n * J::PJ + f * J::NP * D;
+    PHASE();
+    matvec10<D, false>(W + L::layer(0) + L::L_TO + L::PHI_W1, L::EIN, D, x, t);
+    store10(dst, t);
+    PHASE();
+    matvec10<D, false>(W + L::layer(0) + L::L_FROM + L::PHI_W1, L::EIN, D, x, t);
+    store10(dst + D, t);
+    if (MIXED) {
+      PHASE();
+      matvec10<D, false>(W + L::phi_neu(1) + L::PHI_W1, L::EIN, D, x, t);
+      store10(dst + 2 * D, t);
+    }
+  }
+}
+
+// one Phi module at node n: S = sum_e relu(z_e), T = sum_e 1[z_e > 0] (dPi + dPj[u]);  mp = W2 S + deg b2, t = W2 T
+template <int PJ>
+__device__ __forceinline__ void jr_phi_tangent(const float* __restrict__ Wm, const float* x, const float* gx,
+                                               const int32_t* __restrict__ nbr, const float* __restrict__ attr, int32_t eb,
+                                               int32_t ee, const float* __restrict__ Pb, int poff, int toff, float* S,
+                                               float* T, float* mp, float* tt) {
+  using L = WLayout<2>;  // Phi blocks have the same layout in both families
+  float Pi[D], dPi[D], z[D], pj[D], dj[D];
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    Pi[o] = Wm[L::PHI_B1 + o];
+    S[o] = T[o] = 0.f;
+  }
+  PHASE();
+  matvec10<D, true>(Wm + L::PHI_W1, L::EIN, 0, x, Pi);
+  PHASE();
+  matvec10<D, false>(Wm + L::PHI_W1, L::EIN, 0, gx, dPi);
+  PHASE();
+  for (int32_t i = eb; i < ee; ++i) {
+    const float* Pu = Pb + (int64_t)nbr[i] * PJ;
+    load10(Pu + poff, pj);
+    load10(Pu + toff, dj);
+    jr_edge_z(Wm + L::PHI_W1, Pi, pj, attr[3 * (int64_t)i], attr[3 * (int64_t)i + 1], attr[3 * (int64_t)i + 2], z);
+#pragma unroll
+    for (int o = 0; o < D; ++o) {
+      S[o] += fmaxf(z[o], 0.f);
+      T[o] += z[o] > 0.f ? dPi[o] + dj[o] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < D; ++o) mp[o] = (float)(ee - eb) * Wm[L::PHI_B2 + o];
+  PHASE();
+  matvec10<D, true>(Wm + L::PHI_W2, D, 0, S, mp);
+  PHASE();
+  matvec10<D, false>(Wm + L::PHI_W2, D, 0, T, tt);
+}
+
+// step 1: cb[n] = { mp_to, mp_fr, t_to, t_fr } (Neumann row: { mp_n, -, t_n, - });  rec1 groups 3, 4 (21) = (S | deg);
+// rec2 groups 3, 4 (21) = (S' | 0)
+template <int P, bool MIXED>
 __global__ __launch_bounds__(256) void k_jr_tangent(int64_t N, const float* __restrict__ W,
                                                     const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_nbr,
                                                     const float* __restrict__ csr_attr, const int32_t* __restrict__ csc_ptr,
                                                     const int32_t* __restrict__ csc_nbr, const float* __restrict__ csc_attr,
                                                     const uint8_t* __restrict__ flags, const float* __restrict__ h,
-                                                    const float* __restrict__ gb, const float* __restrict__ P,
+                                                    const float* __restrict__ gb, const float* __restrict__ Pb,
                                                     float* __restrict__ cb, float* __restrict__ rec1,
                                                     float* __restrict__ rec2) {
+  using L = WLayout<P>;
+  using J = JrDims<MIXED>;
   int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  if (flags[n] & FLAG_DIRICHLET) return;  // k_jr_node clears the row's records
-  const float* Wto = W + L2::layer(0) + L2::L_TO;
-  const float* Wfr = W + L2::layer(0) + L2::L_FROM;
-  float x[D], gx[D], Pt[D], Pf[D], dPt[D], dPf[D];
+  const uint8_t fl = flags[n];
+  if (fl & FLAG_DIRICHLET) return;  // k_jr_node clears the row's records
+  float x[D], gx[D], S[D], T[D], mp[D], tt[D];
   load10(h + n * D, x);
   load10(gb + n * D, gx);
-#pragma unroll
-  for (int o = 0; o < D; ++o) {
-    Pt[o] = Wto[L2::PHI_B1 + o];
-    Pf[o] = Wfr[L2::PHI_B1 + o];
-  }
-  PHASE();
-  matvec10<D, true>(Wto + L2::PHI_W1, L2::EIN, 0, x, Pt);
-  PHASE();
-  matvec10<D, true>(Wfr + L2::PHI_W1, L2::EIN, 0, x, Pf);
-  PHASE();
-  matvec10<D, false>(Wto + L2::PHI_W1, L2::EIN, 0, gx, dPt);
-  PHASE();
-  matvec10<D, false>(Wfr + L2::PHI_W1, L2::EIN, 0, gx, dPf);
   const int32_t ib = csc_ptr[n], ie = csc_ptr[n + 1], ob = csr_ptr[n], oe = csr_ptr[n + 1];
-  float S[D], T[D], z[D], pj[D], dj[D];
-#pragma unroll
-  for (int o = 0; o < D; ++o) S[o] = T[o] = 0.f;
-  PHASE();
-  for (int32_t i = ib; i < ie; ++i) {
-    const float* Pu = P + (int64_t)csc_nbr[i] * 4 * D;
-    load10(Pu, pj);
-    load10(Pu + 2 * D, dj);
-    jr_edge_z(Wto + L2::PHI_W1, Pt, pj, csc_attr[3 * (int64_t)i], csc_attr[3 * (int64_t)i + 1], csc_attr[3 * (int64_t)i + 2], z);
-#pragma unroll
-    for (int o = 0; o < D; ++o) {
-      S[o] += fmaxf(z[o], 0.f);
-      T[o] += z[o] > 0.f ? dPt[o] + dj[o] : 0.f;
-    }
-  }
-  float mp[D], tt[D];
-#pragma unroll
-  for (int o = 0; o < D; ++o) mp[o] = (float)(ie - ib) * Wto[L2::PHI_B2 + o];
-  PHASE();
-  matvec10<D, true>(Wto + L2::PHI_W2, D, 0, S, mp);
-  PHASE();
-  matvec10<D, false>(Wto + L2::PHI_W2, D, 0, T, tt);
   float* c = cb + n * 4 * D;
+  float* r1 = rec1 + n * J::REC;
+  float* r2 = rec2 + n * J::REC;
+  if (MIXED && (fl & FLAG_NEUMANN)) {  // Phi_neumann is of the Phi_from type: out-edges
+    jr_phi_tangent<J::PJ>(W + L::phi_neu(1), x, gx, csr_nbr, csr_attr, ob, oe, Pb, 2 * D, J::NP * D + 2 * D, S, T, mp, tt);
+    store10(c, mp);
+    store10(c + 2 * D, tt);
+    jr_group(r1 + 21 * 16, S, D, (float)(oe - ob));
+    jr_group(r2 + 21 * 16, T, D);
+    return;
+  }
+  jr_phi_tangent<J::PJ>(W + L::layer(0) + L::L_TO, x, gx, csc_nbr, csc_attr, ib, ie, Pb, 0, J::NP * D, S, T, mp, tt);
   store10(c, mp);
   store10(c + 2 * D, tt);
-  jr_group(rec1 + n * JR_REC + 3 * 16, S, D, (float)(ie - ib));
-  jr_group(rec2 + n * JR_REC + 3 * 16, T, D);
-#pragma unroll
-  for (int o = 0; o < D; ++o) S[o] = T[o] = 0.f;
+  jr_group(r1 + 3 * 16, S, D, (float)(ie - ib));
+  jr_group(r2 + 3 * 16, T, D);
   PHASE();
-  for (int32_t i = ob; i < oe; ++i) {
-    const float* Pu = P + (int64_t)csr_nbr[i] * 4 * D;
-    load10(Pu + D, pj);
-    load10(Pu + 3 * D, dj);
-    jr_edge_z(Wfr + L2::PHI_W1, Pf, pj, csr_attr[3 * (int64_t)i], csr_attr[3 * (int64_t)i + 1], csr_attr[3 * (int64_t)i + 2], z);
-#pragma unroll
-    for (int o = 0; o < D; ++o) {
-      S[o] += fmaxf(z[o], 0.f);
-      T[o] += z[o] > 0.f ? dPf[o] + dj[o] : 0.f;
-    }
-  }
-#pragma unroll
-  for (int o = 0; o < D; ++o) mp[o] = (float)(oe - ob) * Wfr[L2::PHI_B2 + o];
-  PHASE();
-  matvec10<D, true>(Wfr + L2::PHI_W2, D, 0, S, mp);
-  PHASE();
-  matvec10<D, false>(Wfr + L2::PHI_W2, D, 0, T, tt);
+  jr_phi_tangent<J::PJ>(W + L::layer(0) + L::L_FROM, x, gx, csr_nbr, csr_attr, ob, oe, Pb, D, J::NP * D + D, S, T, mp, tt);
   store10(c + D, mp);
   store10(c + 3 * D, tt);
-  jr_group(rec1 + n * JR_REC + 4 * 16, S, D, (float)(oe - ob));
-  jr_group(rec2 + n * JR_REC + 4 * 16, T, D);
+  jr_group(r1 + 4 * 16, S, D, (float)(oe - ob));
+  jr_group(r2 + 4 * 16, T, D);
 }
 
 // step 2: node-level second order.  dir1[n] = d psi / d c_h (the direct part of d phi / d h).
+template <int P, bool MIXED>
 __global__ __launch_bounds__(256) void k_jr_node(int64_t N, const float* __restrict__ W, const uint8_t* __restrict__ flags,
                                                  const float* __restrict__ h, const float* __restrict__ prb,
-                                                 const float* __restrict__ v, const float* __restrict__ gb,
-                                                 const float* __restrict__ cb, float* __restrict__ dir1,
-                                                 float* __restrict__ rec1, float* __restrict__ rec2) {
+                                                 const float* __restrict__ nrm, const float* __restrict__ v,
+                                                 const float* __restrict__ gb, const float* __restrict__ cb,
+                                                 float* __restrict__ dir1, float* __restrict__ rec1,
+                                                 float* __restrict__ rec2) {
+  using L = WLayout<P>;
+  using J = JrDims<MIXED>;
+  constexpr int NG = J::REC / 16;
   int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  const float* Wu = W + L2::layer(0) + L2::L_UPD;
-  const float* Wa = W + L2::AL_W;
-  float* r1 = rec1 + n * JR_REC;
-  float* r2 = rec2 + n * JR_REC;
+  const float* Wu = W + L::layer(0) + L::L_UPD;
+  const float* Wa = W + L::AL_W;
+  float* r1 = rec1 + n * J::REC;
+  float* r2 = rec2 + n * J::REC;
+  const uint8_t fl = flags[n];
   float x[D], gx[D];
   load10(h + n * D, x);
   load10(gb + n * D, gx);
   jr_group(r1, x, D, 1.f);   // right factor of the W1 products, also for rows that only act as neighbours
   jr_group(r2, gx, D);
-  if (flags[n] & FLAG_DIRICHLET) {
+  if (fl & FLAG_DIRICHLET) {
     float zero[D];
 #pragma unroll
     for (int o = 0; o < D; ++o) zero[o] = 0.f;
     store10(dir1 + n * D, zero);
     jr_zero(r1, 1, 12);
-    jr_zero(r1, 14, 20);
+    jr_zero(r1, 14, MIXED ? 27 : NG);
     jr_zero(r2, 1, 12);
-    jr_zero(r2, 14, 20);
+    jr_zero(r2, 14, MIXED ? 27 : NG);
+    if (MIXED) {
+      jr_zero(r1, 28, NG);
+      jr_zero(r2, 28, NG);
+    }
     return;
   }
-  float mpt[D], mpf[D], tt[D], tf[D], w[D], pq[2];
+  float w[D], pq[P + 2];
+  load10(v + n * D, w);
+#pragma unroll
+  for (int k = 0; k < P; ++k) pq[k] = prb[n * P + k];
+  pq[P] = pq[P + 1] = 0.f;
+
+  if (MIXED && (fl & FLAG_NEUMANN)) return;  // k_jr_node_neumann
+
+  // ---------------------------------------------------------------------------------------------- interior row
+  float mpt[D], mpf[D], tt[D], tf[D];
   load10(cb + n * 4 * D, mpt);
   load10(cb + n * 4 * D + D, mpf);
   load10(cb + n * 4 * D + 2 * D, tt);
   load10(cb + n * 4 * D + 3 * D, tf);
-  load10(v + n * D, w);
-  pq[0] = prb[n * 2];
-  pq[1] = prb[n * 2 + 1];
-  // ---- primal
-  float a = W[L2::AL_B], da = 0.f;
+  float a = W[L::AL_B], da = 0.f;
   PHASE();
 #pragma unroll
   for (int k = 0; k < D; ++k) {
@@ -217,30 +293,30 @@ __global__ __launch_bounds__(256) void k_jr_node(int64_t N, const float* __restr
     da = fmaf(Wa[D + k], tt[k], da);
     da = fmaf(Wa[2 * D + k], tf[k], da);
   }
-  a = fmaf(Wa[3 * D], pq[0], a);
-  a = fmaf(Wa[3 * D + 1], pq[1], a);
+#pragma unroll
+  for (int k = 0; k < P; ++k) a = fmaf(Wa[3 * D + k], pq[k], a);
   PHASE();
   const float al = 1.f / (1.f + expf(-a));
   const float sp = al * (1.f - al);
   const float dal = sp * da;
   float q[D], dq[D], hid[D], dhid[D], upd[D], dupd[D];
 #pragma unroll
-  for (int o = 0; o < D; ++o) q[o] = Wu[L2::UPD_B1 + o];
+  for (int o = 0; o < D; ++o) q[o] = Wu[L::UPD_B1 + o];
   PHASE();
-  matvec10<D, true>(Wu + L2::UPD_W1, L2::CAT, 0, x, q);
+  matvec10<D, true>(Wu + L::UPD_W1, L::CAT, 0, x, q);
   PHASE();
-  matvec10<D, true>(Wu + L2::UPD_W1, L2::CAT, D, mpt, q);
+  matvec10<D, true>(Wu + L::UPD_W1, L::CAT, D, mpt, q);
   PHASE();
-  matvec10<D, true>(Wu + L2::UPD_W1, L2::CAT, 2 * D, mpf, q);
+  matvec10<D, true>(Wu + L::UPD_W1, L::CAT, 2 * D, mpf, q);
   PHASE();
-  matvec10<2, true>(Wu + L2::UPD_W1, L2::CAT, 3 * D, pq, q);
+  matvec10<P, true>(Wu + L::UPD_W1, L::CAT, 3 * D, pq, q);
   PHASE();
-  matvec10<D, false>(Wu + L2::UPD_W1, L2::CAT, 0, gx, dq);
+  matvec10<D, false>(Wu + L::UPD_W1, L::CAT, 0, gx, dq);
   PHASE();
-  matvec10<D, true>(Wu + L2::UPD_W1, L2::CAT, D, tt, dq);
+  matvec10<D, true>(Wu + L::UPD_W1, L::CAT, D, tt, dq);
   PHASE();
-  matvec10<D, true>(Wu + L2::UPD_W1, L2::CAT, 2 * D, tf, dq);
-  jr_group(r1 + 16, mpt, D, pq[0], pq[1]);
+  matvec10<D, true>(Wu + L::UPD_W1, L::CAT, 2 * D, tf, dq);
+  jr_group(r1 + 16, mpt, D, pq[0], pq[1], P > 2 ? pq[P - 1] : 0.f);
   jr_group(r1 + 2 * 16, mpf, D);
   jr_group(r2 + 16, tt, D);
   jr_group(r2 + 2 * 16, tf, D);
@@ -248,63 +324,26 @@ __global__ __launch_bounds__(256) void k_jr_node(int64_t N, const float* __restr
   for (int o = 0; o < D; ++o) {
     hid[o] = fmaxf(q[o], 0.f);
     dhid[o] = q[o] > 0.f ? dq[o] : 0.f;
-    upd[o] = Wu[L2::UPD_B2 + o];
+    upd[o] = Wu[L::UPD_B2 + o];
   }
   PHASE();
-  matvec10<D, true>(Wu + L2::UPD_W2, D, 0, hid, upd);
+  matvec10<D, true>(Wu + L::UPD_W2, D, 0, hid, upd);
   PHASE();
-  matvec10<D, false>(Wu + L2::UPD_W2, D, 0, dhid, dupd);
+  matvec10<D, false>(Wu + L::UPD_W2, D, 0, dhid, dupd);
   jr_group(r1 + 5 * 16, hid, D, 1.f);
   jr_group(r2 + 5 * 16, dhid, D);
-  float y[D], dy[D], mu = 0.f, var = 0.f;
+  float y[D], dy[D], ybar[D], dybar[D], gln[D];
 #pragma unroll
   for (int o = 0; o < D; ++o) {
     y[o] = fmaf(al, upd[o], x[o]);
     dy[o] = gx[o] + dal * upd[o] + al * dupd[o];
-    mu += y[o];
   }
-  mu *= (1.f / D);
-#pragma unroll
-  for (int o = 0; o < D; ++o) {
-    const float c = y[o] - mu;
-    var = fmaf(c, c, var);
-  }
-  var *= (1.f / D);
-  const float rs = 1.f / sqrtf(var + 1e-5f);
   PHASE();
-  float p[D], m1 = 0.f, m2 = 0.f, P1 = 0.f, P2 = 0.f;
-#pragma unroll
-  for (int o = 0; o < D; ++o) {
-    y[o] = (y[o] - mu) * rs;  // normalised
-    p[o] = w[o] * W[L2::LN_G + o];
-    m1 += dy[o];
-    m2 = fmaf(y[o], dy[o], m2);
-    P1 += p[o];
-    P2 = fmaf(p[o], y[o], P2);
-  }
-  m1 *= (1.f / D);
-  m2 *= (1.f / D);
-  P1 *= (1.f / D);
-  P2 *= (1.f / D);
-  // psi = sum_o p_o dyh_o,  dyh = rs (dy - m1 - yhat m2)
-  float psi = 0.f, gln[D], ybar[D], dybar[D], yhb[D], Y1 = 0.f, Y2 = 0.f;
-#pragma unroll
-  for (int o = 0; o < D; ++o) {
-    const float dyh = rs * (dy[o] - m1 - y[o] * m2);
-    gln[o] = w[o] * dyh;                       // d psi / d gamma_o
-    psi = fmaf(p[o], dyh, psi);
-    dybar[o] = rs * (p[o] - P1 - y[o] * P2);   // adjoint of dy (= the first-order LayerNorm backward of v)
-    yhb[o] = -rs * (dy[o] * P2 + p[o] * m2);   // adjoint of yhat
-    Y1 += yhb[o];
-    Y2 = fmaf(yhb[o], y[o], Y2);
-  }
+  jr_layernorm(W + L::LN_G, w, y, dy, ybar, dybar, gln);
   jr_group(r1 + 14 * 16, gln, D);
-  Y1 *= (1.f / D);
-  Y2 *= (1.f / D);
   float albar = 0.f, dalbar = 0.f, ub[D], dub[D];
 #pragma unroll
   for (int o = 0; o < D; ++o) {
-    ybar[o] = rs * (yhb[o] - Y1 - y[o] * Y2) - psi * rs * y[o] * (1.f / D);
     albar = fmaf(ybar[o], upd[o], albar);
     albar = fmaf(dybar[o], dupd[o], albar);
     dalbar = fmaf(dybar[o], upd[o], dalbar);
@@ -316,9 +355,9 @@ __global__ __launch_bounds__(256) void k_jr_node(int64_t N, const float* __restr
   const float abar = albar * sp;                         // adjoint of a
   float qb[D], dqb[D];
   PHASE();
-  jr_matvecT<D, false>(Wu + L2::UPD_W2, D, 0, ub, qb);
+  jr_matvecT<D, false>(Wu + L::UPD_W2, D, 0, ub, qb);
   PHASE();
-  jr_matvecT<D, false>(Wu + L2::UPD_W2, D, 0, dub, dqb);
+  jr_matvecT<D, false>(Wu + L::UPD_W2, D, 0, dub, dqb);
   jr_group(r1 + 11 * 16, ub, D);
   jr_group(r2 + 11 * 16, dub, D);
 #pragma unroll
@@ -332,11 +371,11 @@ __global__ __launch_bounds__(256) void k_jr_node(int64_t N, const float* __restr
 #pragma unroll
   for (int k = 0; k < D; ++k) ch[k] = fmaf(Wa[k], abar, ybar[k]);
   PHASE();
-  jr_matvecT<D, true>(Wu + L2::UPD_W1, L2::CAT, 0, qb, ch);
+  jr_matvecT<D, true>(Wu + L::UPD_W1, L::CAT, 0, qb, ch);
   PHASE();
-  jr_matvecT<D, false>(Wu + L2::UPD_W1, L2::CAT, D, qb, ct);
+  jr_matvecT<D, false>(Wu + L::UPD_W1, L::CAT, D, qb, ct);
   PHASE();
-  jr_matvecT<D, false>(Wu + L2::UPD_W1, L2::CAT, 2 * D, qb, cf);
+  jr_matvecT<D, false>(Wu + L::UPD_W1, L::CAT, 2 * D, qb, cf);
   PHASE();
 #pragma unroll
   for (int k = 0; k < D; ++k) {
@@ -349,9 +388,9 @@ __global__ __launch_bounds__(256) void k_jr_node(int64_t N, const float* __restr
   jr_group(r1 + 10 * 16, cf, D);
   jr_zero(r1, 15, 16);
   PHASE();
-  jr_matvecT<D, false>(Wu + L2::UPD_W1, L2::CAT, D, dqb, ct);
+  jr_matvecT<D, false>(Wu + L::UPD_W1, L::CAT, D, dqb, ct);
   PHASE();
-  jr_matvecT<D, false>(Wu + L2::UPD_W1, L2::CAT, 2 * D, dqb, cf);
+  jr_matvecT<D, false>(Wu + L::UPD_W1, L::CAT, 2 * D, dqb, cf);
   PHASE();
 #pragma unroll
   for (int k = 0; k < D; ++k) {
@@ -362,187 +401,345 @@ __global__ __launch_bounds__(256) void k_jr_node(int64_t N, const float* __restr
   jr_group(r2 + 9 * 16, ct, D);
   jr_group(r2 + 10 * 16, cf, D);
   jr_zero(r2, 14, 16);
+  if (MIXED) {  // the Neumann branch's factors (27 comes from the remote pass)
+    jr_zero(r1, 20, 27);
+    jr_zero(r1, 28, NG);
+    jr_zero(r2, 20, 27);
+    jr_zero(r2, 28, NG);
+  }
 }
 
-// step 3a: edge-level backward of the cotangent held in groups 9 / 10 of `rec` (masks of h).  TAN: the record's right
+// step 2, Neumann rows of the mixed family (a kernel of its own: together with the interior branch the compiler would keep
+// > 1 000 spilled SGPRs alive)
+template <int P>
+__global__ __launch_bounds__(256) void k_jr_node_neumann(int64_t N, const float* __restrict__ W,
+                                                         const uint8_t* __restrict__ flags, const float* __restrict__ h,
+                                                         const float* __restrict__ prb, const float* __restrict__ nrm,
+                                                         const float* __restrict__ v, const float* __restrict__ gb,
+                                                         const float* __restrict__ cb, float* __restrict__ dir1,
+                                                         float* __restrict__ rec1, float* __restrict__ rec2) {
+  using L = WLayout<P>;
+  using J = JrDims<true>;
+  int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const uint8_t fl = flags[n];
+  if ((fl & FLAG_DIRICHLET) || !(fl & FLAG_NEUMANN)) return;
+  float* r1 = rec1 + n * J::REC;
+  float* r2 = rec2 + n * J::REC;
+  float x[D], gx[D], w[D], pq[P + 2];
+  load10(h + n * D, x);
+  load10(gb + n * D, gx);
+  load10(v + n * D, w);
+  jr_group(r1, x, D, 1.f);
+  jr_group(r2, gx, D);
+#pragma unroll
+  for (int k = 0; k < P; ++k) pq[k] = prb[n * P + k];
+  // ------------------------------------------------ Neumann row: y = N2 relu(N1 [h, mp_n, prb, normal] + nb1) + nb2
+  const float* Un = W + L::upd_neu(1);
+  float mpn[D], tn[D];
+  load10(cb + n * 4 * D, mpn);
+  load10(cb + n * 4 * D + 2 * D, tn);
+  pq[P] = nrm[n * 2];
+  pq[P + 1] = nrm[n * 2 + 1];
+  float q[D], dq[D], hid[D], dhid[D], y[D], dy[D];
+#pragma unroll
+  for (int o = 0; o < D; ++o) q[o] = Un[L::NEU_B1 + o];
+  PHASE();
+  matvec10<D, true>(Un + L::NEU_W1, L::NEU_CAT, 0, x, q);
+  PHASE();
+  matvec10<D, true>(Un + L::NEU_W1, L::NEU_CAT, D, mpn, q);
+  PHASE();
+  matvec10<P + 2, true>(Un + L::NEU_W1, L::NEU_CAT, 2 * D, pq, q);
+  PHASE();
+  matvec10<D, false>(Un + L::NEU_W1, L::NEU_CAT, 0, gx, dq);
+  PHASE();
+  matvec10<D, true>(Un + L::NEU_W1, L::NEU_CAT, D, tn, dq);
+  jr_group(r1 + 20 * 16, mpn, D, pq[0], pq[1], pq[2], pq[3], pq[P + 1]);
+  jr_group(r2 + 20 * 16, tn, D);
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    hid[o] = fmaxf(q[o], 0.f);
+    dhid[o] = q[o] > 0.f ? dq[o] : 0.f;
+    y[o] = Un[L::NEU_B2 + o];
+  }
+  PHASE();
+  matvec10<D, true>(Un + L::NEU_W2, D, 0, hid, y);
+  PHASE();
+  matvec10<D, false>(Un + L::NEU_W2, D, 0, dhid, dy);
+  jr_group(r1 + 22 * 16, hid, D, 1.f);
+  jr_group(r2 + 22 * 16, dhid, D);
+  float ybar[D], dybar[D], gln[D];
+  PHASE();
+  jr_layernorm(W + L::LN_G, w, y, dy, ybar, dybar, gln);
+  jr_group(r1 + 14 * 16, gln, D);
+  jr_group(r1 + 26 * 16, ybar, D);
+  jr_group(r2 + 26 * 16, dybar, D);
+  float qb[D], dqb[D], ch[D], cm[D];
+  PHASE();
+  jr_matvecT<D, false>(Un + L::NEU_W2, D, 0, ybar, qb);
+  PHASE();
+  jr_matvecT<D, false>(Un + L::NEU_W2, D, 0, dybar, dqb);
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    qb[o] = q[o] > 0.f ? qb[o] : 0.f;
+    dqb[o] = q[o] > 0.f ? dqb[o] : 0.f;
+  }
+  jr_group(r1 + 23 * 16, qb, D);
+  jr_group(r2 + 23 * 16, dqb, D);
+  PHASE();
+  jr_matvecT<D, false>(Un + L::NEU_W1, L::NEU_CAT, 0, qb, ch);
+  PHASE();
+  jr_matvecT<D, false>(Un + L::NEU_W1, L::NEU_CAT, D, qb, cm);
+  store10(dir1 + n * D, ch);
+  jr_group(r1 + 25 * 16, cm, D);
+  PHASE();
+  jr_matvecT<D, false>(Un + L::NEU_W1, L::NEU_CAT, D, dqb, cm);
+  jr_group(r2 + 25 * 16, cm, D);
+  // the interior branch's factors; 12 / 13 / 27 come from the remote pass, 21 / 24 / 28.. from the edge passes
+  jr_zero(r1, 1, 12);
+  jr_zero(r1, 15, 20);
+  jr_zero(r2, 1, 12);
+  jr_zero(r2, 14, 20);
+}
+
+// masked cotangent sums of one Phi module over node n's own edges: gs = sum_e 1[z_e > 0] dS, and (ATTR) its
+// edge-feature moments mom[o * 3 + c] = sum_e 1[z_e[o] > 0] dS[o] a_e[c]
+template <int PJ, bool ATTR>
+__device__ __forceinline__ void jr_phi_backward(const float* __restrict__ Wm, const float* Pi, const float* dS,
+                                                const int32_t* __restrict__ nbr, const float* __restrict__ attr, int32_t eb,
+                                                int32_t ee, const float* __restrict__ Pb, int poff, float* gs, float* mom) {
+  using L = WLayout<2>;
+  float z[D], pj[D];
+#pragma unroll
+  for (int o = 0; o < D; ++o) gs[o] = 0.f;
+  PHASE();
+  for (int32_t i = eb; i < ee; ++i) {
+    const float a0 = attr[3 * (int64_t)i], a1 = attr[3 * (int64_t)i + 1], a2 = attr[3 * (int64_t)i + 2];
+    load10(Pb + (int64_t)nbr[i] * PJ + poff, pj);
+    jr_edge_z(Wm + L::PHI_W1, Pi, pj, a0, a1, a2, z);
+#pragma unroll
+    for (int o = 0; o < D; ++o) {
+      const float m = z[o] > 0.f ? dS[o] : 0.f;
+      gs[o] += m;
+      if (ATTR) {
+        mom[o * 3] = fmaf(m, a0, mom[o * 3]);
+        mom[o * 3 + 1] = fmaf(m, a1, mom[o * 3 + 1]);
+        mom[o * 3 + 2] = fmaf(m, a2, mom[o * 3 + 2]);
+      }
+    }
+  }
+}
+
+// step 3a: edge-level backward of the cotangent held in groups 9 / 10 (25) of `rec` (masks of h).  TAN: the record's right
 // factors are tangents (no bias, no edge-feature part) and no d / d h is produced.
-template <bool TAN>
+template <int P, bool MIXED, bool TAN>
 __global__ __launch_bounds__(256) void k_jr_edge_local(int64_t N, const float* __restrict__ W,
                                                        const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_nbr,
                                                        const float* __restrict__ csr_attr, const int32_t* __restrict__ csc_ptr,
                                                        const int32_t* __restrict__ csc_nbr, const float* __restrict__ csc_attr,
                                                        const uint8_t* __restrict__ flags, const float* __restrict__ h,
-                                                       const float* __restrict__ P, const float* __restrict__ dir,
+                                                       const float* __restrict__ Pb, const float* __restrict__ dir,
                                                        float* __restrict__ B, float* __restrict__ out,
                                                        float* __restrict__ rec) {
+  using L = WLayout<P>;
+  using J = JrDims<MIXED>;
   int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  const float* Wto = W + L2::layer(0) + L2::L_TO;
-  const float* Wfr = W + L2::layer(0) + L2::L_FROM;
-  float* Bn = B + n * 4 * D;
+  const float* Wto = W + L::layer(0) + L::L_TO;
+  const float* Wfr = W + L::layer(0) + L::L_FROM;
+  const float* Wn = W + L::phi_neu(1);
+  float* Bn = B + n * J::NB * D;
+  const uint8_t fl = flags[n];
   float zero[D];
 #pragma unroll
   for (int o = 0; o < D; ++o) zero[o] = 0.f;
-  if (flags[n] & FLAG_DIRICHLET) {  // sends nothing
-    store10(Bn, zero);
-    store10(Bn + D, zero);
-    store10(Bn + 2 * D, zero);
-    store10(Bn + 3 * D, zero);
+  if (fl & FLAG_DIRICHLET) {  // sends nothing
+#pragma unroll
+    for (int k = 0; k < J::NB; ++k) store10(Bn + k * D, zero);
     if (!TAN) store10(out + n * D, zero);
     return;
   }
-  float* r = rec + n * JR_REC;
-  float x[D], Pt[D], Pf[D], dmt[D], dmf[D], dSt[D], dSf[D];
+  float* r = rec + n * J::REC;
+  const int32_t ib = csc_ptr[n], ie = csc_ptr[n + 1], ob = csr_ptr[n], oe = csr_ptr[n + 1];
+  float x[D], g[D];
   load10(h + n * D, x);
+  if (!TAN) load10(dir + n * D, g);
+
+  if (MIXED && (fl & FLAG_NEUMANN)) {
+    float Pn[D], dmn[D], dSn[D], gn[D], mom[32];
+#pragma unroll
+    for (int o = 0; o < D; ++o) {
+      Pn[o] = Wn[L::PHI_B1 + o];
+      dmn[o] = r[25 * 16 + o];
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) mom[i] = 0.f;
+    PHASE();
+    matvec10<D, true>(Wn + L::PHI_W1, L::EIN, 0, x, Pn);
+    PHASE();
+    jr_matvecT<D, false>(Wn + L::PHI_W2, D, 0, dmn, dSn);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) store10(Bn + k * D, zero);
+    store10(Bn + 4 * D, Pn);
+    store10(Bn + 5 * D, dSn);
+    jr_phi_backward<J::PJ, !TAN>(Wn, Pn, dSn, csr_nbr, csr_attr, ob, oe, Pb, 2 * D, gn, mom);
+    jr_group(r + 24 * 16, gn, D);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      reinterpret_cast<float4*>(r + 28 * 16)[i] = make_float4(mom[4 * i], mom[4 * i + 1], mom[4 * i + 2], mom[4 * i + 3]);
+    if (!TAN) {
+      PHASE();
+      jr_matvecT<D, true>(Wn + L::PHI_W1, L::EIN, 0, gn, g);
+      store10(out + n * D, g);
+    }
+    return;
+  }
+
+  float Pt[D], Pf[D], dmt[D], dmf[D], dSt[D], dSf[D];
 #pragma unroll
   for (int o = 0; o < D; ++o) {
-    Pt[o] = Wto[L2::PHI_B1 + o];
-    Pf[o] = Wfr[L2::PHI_B1 + o];
+    Pt[o] = Wto[L::PHI_B1 + o];
+    Pf[o] = Wfr[L::PHI_B1 + o];
     dmt[o] = r[9 * 16 + o];
     dmf[o] = r[10 * 16 + o];
   }
   PHASE();
-  matvec10<D, true>(Wto + L2::PHI_W1, L2::EIN, 0, x, Pt);
+  matvec10<D, true>(Wto + L::PHI_W1, L::EIN, 0, x, Pt);
   PHASE();
-  matvec10<D, true>(Wfr + L2::PHI_W1, L2::EIN, 0, x, Pf);
+  matvec10<D, true>(Wfr + L::PHI_W1, L::EIN, 0, x, Pf);
   PHASE();
-  jr_matvecT<D, false>(Wto + L2::PHI_W2, D, 0, dmt, dSt);
+  jr_matvecT<D, false>(Wto + L::PHI_W2, D, 0, dmt, dSt);
   PHASE();
-  jr_matvecT<D, false>(Wfr + L2::PHI_W2, D, 0, dmf, dSf);
+  jr_matvecT<D, false>(Wfr + L::PHI_W2, D, 0, dmf, dSf);
   store10(Bn, Pt);
   store10(Bn + D, Pf);
   store10(Bn + 2 * D, dSt);
   store10(Bn + 3 * D, dSf);
-  const int32_t ib = csc_ptr[n], ie = csc_ptr[n + 1], ob = csr_ptr[n], oe = csr_ptr[n + 1];
-  float gt[D], gf[D], z[D], pj[D], dsa[64];
-#pragma unroll
-  for (int o = 0; o < D; ++o) gt[o] = gf[o] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 64; ++i) dsa[i] = 0.f;
-  PHASE();
-  for (int32_t i = ib; i < ie; ++i) {
-    const float a0 = csc_attr[3 * (int64_t)i], a1 = csc_attr[3 * (int64_t)i + 1], a2 = csc_attr[3 * (int64_t)i + 2];
-    load10(P + (int64_t)csc_nbr[i] * 4 * D, pj);
-    jr_edge_z(Wto + L2::PHI_W1, Pt, pj, a0, a1, a2, z);
-#pragma unroll
-    for (int o = 0; o < D; ++o) {
-      const float m = z[o] > 0.f ? dSt[o] : 0.f;
-      gt[o] += m;
-      if (!TAN) {
-        dsa[o * 3] = fmaf(m, a0, dsa[o * 3]);
-        dsa[o * 3 + 1] = fmaf(m, a1, dsa[o * 3 + 1]);
-        dsa[o * 3 + 2] = fmaf(m, a2, dsa[o * 3 + 2]);
-      }
-    }
+  if (MIXED) {
+    store10(Bn + 4 * D, zero);
+    store10(Bn + 5 * D, zero);
   }
-  PHASE();
-  for (int32_t i = ob; i < oe; ++i) {
-    const float a0 = csr_attr[3 * (int64_t)i], a1 = csr_attr[3 * (int64_t)i + 1], a2 = csr_attr[3 * (int64_t)i + 2];
-    load10(P + (int64_t)csr_nbr[i] * 4 * D + D, pj);
-    jr_edge_z(Wfr + L2::PHI_W1, Pf, pj, a0, a1, a2, z);
+  float gt[D], gf[D], mom[64];
 #pragma unroll
-    for (int o = 0; o < D; ++o) {
-      const float m = z[o] > 0.f ? dSf[o] : 0.f;
-      gf[o] += m;
-      if (!TAN) {
-        dsa[30 + o * 3] = fmaf(m, a0, dsa[30 + o * 3]);
-        dsa[31 + o * 3] = fmaf(m, a1, dsa[31 + o * 3]);
-        dsa[32 + o * 3] = fmaf(m, a2, dsa[32 + o * 3]);
-      }
-    }
-  }
+  for (int i = 0; i < 64; ++i) mom[i] = 0.f;
+  jr_phi_backward<J::PJ, !TAN>(Wto, Pt, dSt, csc_nbr, csc_attr, ib, ie, Pb, 0, gt, mom);
+  jr_phi_backward<J::PJ, !TAN>(Wfr, Pf, dSf, csr_nbr, csr_attr, ob, oe, Pb, D, gf, mom + 30);
   jr_group(r + 7 * 16, gt, D);
   jr_group(r + 8 * 16, gf, D);
+  mom[60] = mom[61] = mom[62] = mom[63] = 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i)
-    reinterpret_cast<float4*>(r + 16 * 16)[i] = make_float4(dsa[4 * i], dsa[4 * i + 1], dsa[4 * i + 2], dsa[4 * i + 3]);
+    reinterpret_cast<float4*>(r + 16 * 16)[i] = make_float4(mom[4 * i], mom[4 * i + 1], mom[4 * i + 2], mom[4 * i + 3]);
   if (!TAN) {
-    float g[D];
-    load10(dir + n * D, g);
     PHASE();
-    jr_matvecT<D, true>(Wto + L2::PHI_W1, L2::EIN, 0, gt, g);
+    jr_matvecT<D, true>(Wto + L::PHI_W1, L::EIN, 0, gt, g);
     PHASE();
-    jr_matvecT<D, true>(Wfr + L2::PHI_W1, L2::EIN, 0, gf, g);
+    jr_matvecT<D, true>(Wfr + L::PHI_W1, L::EIN, 0, gf, g);
     store10(out + n * D, g);
   }
 }
 
-// step 3b: what node u receives as somebody's neighbour (groups 12 / 13, and out += W1j^T acc)
-template <bool TAN>
+// step 3b: what node u receives as somebody's neighbour (groups 12 / 13 (27), and out += W1j^T acc)
+template <int P, bool MIXED, bool TAN>
 __global__ __launch_bounds__(256) void k_jr_edge_remote(int64_t N, const float* __restrict__ W,
                                                         const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_nbr,
                                                         const float* __restrict__ csr_attr, const int32_t* __restrict__ csc_ptr,
                                                         const int32_t* __restrict__ csc_nbr, const float* __restrict__ csc_attr,
-                                                        const float* __restrict__ P, const float* __restrict__ B,
+                                                        const float* __restrict__ Pb, const float* __restrict__ B,
                                                         float* __restrict__ out, float* __restrict__ rec) {
+  using L = WLayout<P>;
+  using J = JrDims<MIXED>;
   int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= N) return;
-  const float* Wto = W + L2::layer(0) + L2::L_TO;
-  const float* Wfr = W + L2::layer(0) + L2::L_FROM;
-  float pjt[D], pjf[D], at[D], af[D], z[D];
-  load10(P + u * 4 * D, pjt);
-  load10(P + u * 4 * D + D, pjf);
+  const float* Wto = W + L::layer(0) + L::L_TO;
+  const float* Wfr = W + L::layer(0) + L::L_FROM;
+  const float* Wn = W + L::phi_neu(1);
+  float pjt[D], pjf[D], pjn[D], at[D], af[D], an[D], z[D];
+  load10(Pb + u * J::PJ, pjt);
+  load10(Pb + u * J::PJ + D, pjf);
+  if (MIXED) load10(Pb + u * J::PJ + 2 * D, pjn);
 #pragma unroll
-  for (int o = 0; o < D; ++o) at[o] = af[o] = 0.f;
+  for (int o = 0; o < D; ++o) at[o] = af[o] = an[o] = 0.f;
   PHASE();
   for (int32_t i = csr_ptr[u]; i < csr_ptr[u + 1]; ++i) {  // u -> n: Phi_to terms of n that read h[u]
-    const float* Bn = B + (int64_t)csr_nbr[i] * 4 * D;
+    const float* Bn = B + (int64_t)csr_nbr[i] * J::NB * D;
     float pt[D], ds[D];
     load10(Bn, pt);
     load10(Bn + 2 * D, ds);
-    jr_edge_z(Wto + L2::PHI_W1, pt, pjt, csr_attr[3 * (int64_t)i], csr_attr[3 * (int64_t)i + 1], csr_attr[3 * (int64_t)i + 2], z);
+    jr_edge_z(Wto + L::PHI_W1, pt, pjt, csr_attr[3 * (int64_t)i], csr_attr[3 * (int64_t)i + 1], csr_attr[3 * (int64_t)i + 2], z);
 #pragma unroll
     for (int o = 0; o < D; ++o) at[o] += z[o] > 0.f ? ds[o] : 0.f;
   }
   PHASE();
-  for (int32_t i = csc_ptr[u]; i < csc_ptr[u + 1]; ++i) {  // n -> u: Phi_from terms of n that read h[u]
-    const float* Bn = B + (int64_t)csc_nbr[i] * 4 * D;
+  for (int32_t i = csc_ptr[u]; i < csc_ptr[u + 1]; ++i) {  // n -> u: Phi_from (Phi_neumann) terms of n that read h[u]
+    const float* Bn = B + (int64_t)csc_nbr[i] * J::NB * D;
+    const float a0 = csc_attr[3 * (int64_t)i], a1 = csc_attr[3 * (int64_t)i + 1], a2 = csc_attr[3 * (int64_t)i + 2];
     float pf[D], ds[D];
     load10(Bn + D, pf);
     load10(Bn + 3 * D, ds);
-    jr_edge_z(Wfr + L2::PHI_W1, pf, pjf, csc_attr[3 * (int64_t)i], csc_attr[3 * (int64_t)i + 1], csc_attr[3 * (int64_t)i + 2], z);
+    jr_edge_z(Wfr + L::PHI_W1, pf, pjf, a0, a1, a2, z);
 #pragma unroll
     for (int o = 0; o < D; ++o) af[o] += z[o] > 0.f ? ds[o] : 0.f;
+    if (MIXED) {
+      load10(Bn + 4 * D, pf);
+      load10(Bn + 5 * D, ds);
+      jr_edge_z(Wn + L::PHI_W1, pf, pjn, a0, a1, a2, z);
+#pragma unroll
+      for (int o = 0; o < D; ++o) an[o] += z[o] > 0.f ? ds[o] : 0.f;
+    }
   }
-  float* r = rec + u * JR_REC;
+  float* r = rec + u * J::REC;
   jr_group(r + 12 * 16, at, D);
   jr_group(r + 13 * 16, af, D);
+  if (MIXED) jr_group(r + 27 * 16, an, D);
   if (!TAN) {
     float g[D];
     load10(out + u * D, g);
     PHASE();
-    jr_matvecT<D, true>(Wto + L2::PHI_W1, L2::EIN, D, at, g);
+    jr_matvecT<D, true>(Wto + L::PHI_W1, L::EIN, D, at, g);
     PHASE();
-    jr_matvecT<D, true>(Wfr + L2::PHI_W1, L2::EIN, D, af, g);
+    jr_matvecT<D, true>(Wfr + L::PHI_W1, L::EIN, D, af, g);
+    if (MIXED) {
+      PHASE();
+      jr_matvecT<D, true>(Wn + L::PHI_W1, L::EIN, D, an, g);
+    }
     store10(out + u * D, g);
   }
 }
 
-// work: P (N, 40) | cb (N, 40) | B (N, 40) | dir (N, 10);  rec: (2 N, 320) = R1 then R2;  out_h: (N, 10) = d phi / d h
-int psignn_jacreg_records(const psignn_plan* p, const float* W, const float* h, const float* prb, const float* v,
-                          const float* gbar, float* out_h, float* work, float* rec, hipStream_t st) {
+template <int P, bool MIXED>
+static void jr_launch(const psignn_plan* p, const float* W, const float* h, const float* prb, const float* nrm, const float* v,
+                      const float* gbar, float* out_h, float* work, float* rec, hipStream_t st) {
+  using J = JrDims<MIXED>;
   const int64_t N = p->N;
   const unsigned grid = (unsigned)cdiv(N, 256);
-  float* P = work;
-  float* cb = P + N * 4 * D;
+  float* Pb = work;
+  float* cb = Pb + N * J::PJ;
   float* B = cb + N * 4 * D;
-  float* dir = B + N * 4 * D;
+  float* dir = B + N * J::NB * D;
   float* rec1 = rec;
-  float* rec2 = rec + N * JR_REC;
-  LAUNCH("k_jr_project", st, (k_jr_project<<<grid, 256, 0, st>>>(N, W, h, gbar, P)));
-  LAUNCH("k_jr_tangent", st, (k_jr_tangent<<<grid, 256, 0, st>>>(N, W, p->csr_ptr, p->csr_nbr, p->csr_attr, p->csc_ptr, p->csc_nbr,
-                                                                p->csc_attr, p->flags, h, gbar, P, cb, rec1, rec2)));
-  LAUNCH("k_jr_node", st, (k_jr_node<<<grid, 256, 0, st>>>(N, W, p->flags, h, prb, v, gbar, cb, dir, rec1, rec2)));
-  LAUNCH("k_jr_edge_local", st, (k_jr_edge_local<false><<<grid, 256, 0, st>>>(N, W, p->csr_ptr, p->csr_nbr, p->csr_attr, p->csc_ptr,
-                                                                            p->csc_nbr, p->csc_attr, p->flags, h, P, dir, B,
-                                                                            out_h, rec1)));
-  LAUNCH("k_jr_edge_remote", st, (k_jr_edge_remote<false><<<grid, 256, 0, st>>>(N, W, p->csr_ptr, p->csr_nbr, p->csr_attr, p->csc_ptr,
-                                                                              p->csc_nbr, p->csc_attr, P, B, out_h, rec1)));
-  LAUNCH("k_jr_edge_local", st, (k_jr_edge_local<true><<<grid, 256, 0, st>>>(N, W, p->csr_ptr, p->csr_nbr, p->csr_attr, p->csc_ptr,
-                                                                           p->csc_nbr, p->csc_attr, p->flags, h, P, dir, B,
-                                                                           nullptr, rec2)));
-  LAUNCH("k_jr_edge_remote", st, (k_jr_edge_remote<true><<<grid, 256, 0, st>>>(N, W, p->csr_ptr, p->csr_nbr, p->csr_attr, p->csc_ptr,
-                                                                             p->csc_nbr, p->csc_attr, P, B, nullptr, rec2)));
+  float* rec2 = rec + N * J::REC;
+#define JR_CSR p->csr_ptr, p->csr_nbr, p->csr_attr, p->csc_ptr, p->csc_nbr, p->csc_attr
+  LAUNCH("k_jr_project", st, (k_jr_project<P, MIXED><<<grid, 256, 0, st>>>(N, W, h, gbar, Pb)));
+  LAUNCH("k_jr_tangent", st, (k_jr_tangent<P, MIXED><<<grid, 256, 0, st>>>(N, W, JR_CSR, p->flags, h, gbar, Pb, cb, rec1, rec2)));
+  LAUNCH("k_jr_node", st, (k_jr_node<P, MIXED><<<grid, 256, 0, st>>>(N, W, p->flags, h, prb, nrm, v, gbar, cb, dir, rec1, rec2)));
+  if constexpr (MIXED)
+    LAUNCH("k_jr_node_neumann", st, (k_jr_node_neumann<P><<<grid, 256, 0, st>>>(N, W, p->flags, h, prb, nrm, v, gbar, cb, dir, rec1, rec2)));
+  LAUNCH("k_jr_edge_local", st, (k_jr_edge_local<P, MIXED, false><<<grid, 256, 0, st>>>(N, W, JR_CSR, p->flags, h, Pb, dir, B, out_h, rec1)));
+  LAUNCH("k_jr_edge_remote", st, (k_jr_edge_remote<P, MIXED, false><<<grid, 256, 0, st>>>(N, W, JR_CSR, Pb, B, out_h, rec1)));
+  LAUNCH("k_jr_edge_local", st, (k_jr_edge_local<P, MIXED, true><<<grid, 256, 0, st>>>(N, W, JR_CSR, p->flags, h, Pb, dir, B, nullptr, rec2)));
+  LAUNCH("k_jr_edge_remote", st, (k_jr_edge_remote<P, MIXED, true><<<grid, 256, 0, st>>>(N, W, JR_CSR, Pb, B, nullptr, rec2)));
+#undef JR_CSR
+}
+
+// work: P (N, 40 | 60) | cb (N, 40) | B (N, 40 | 60) | dir (N, 10)  (<= N * 170 floats);  rec: (2 N, 320 | 480) = R1 then R2;
+// out_h: (N, 10) = d phi / d h
+int psignn_jacreg_records(const psignn_plan* p, const float* W, const float* h, const float* prb, const float* nrm,
+                          const float* v, const float* gbar, float* out_h, float* work, float* rec, hipStream_t st) {
+  if (p->mixed)
+    jr_launch<3, true>(p, W, h, prb, nrm, v, gbar, out_h, work, rec, st);
+  else
+    jr_launch<2, false>(p, W, h, prb, nrm, v, gbar, out_h, work, rec, st);
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }

@@ -255,35 +255,44 @@ extern "C" int psignn_f_param_vjp_p(const psignn_plan_t* p, const float* W, int 
 }
 
 // ---- backward of the VJP (the Jacobian regulariser's gradient; kernels and derivation in fgnn_jacreg.hip)
-int psignn_jacreg_records(const psignn_plan* p, const float* W, const float* h, const float* prb, const float* v,
-                          const float* gbar, float* out_h, float* work, float* rec, hipStream_t st);
+int psignn_jacreg_records(const psignn_plan* p, const float* W, const float* h, const float* prb, const float* nrm,
+                          const float* v, const float* gbar, float* out_h, float* work, float* rec, hipStream_t st);
 
 extern "C" int64_t psignn_f_vjp_backward_workspace_floats(const psignn_plan_t* p) {
   if (!p) return 0;
   int npw;
   const int nblk = pgrad_blocks(2 * p->N, &npw);
-  return p->N * (13 * D + 2 * PGREC) + (int64_t)nblk * TabF::NT * 256;
+  // scratch (<= N * 170) + two records per node + partial tiles (per wave for the mixed family)
+  return p->N * (17 * D + 2 * TabX::NG * 16) + (int64_t)nblk * 4 * TabX::NT * 256;
 }
 
 // Gradient of  phi = gbar . (J_f(h)^T v) = v^T J_f(h) gbar  (gbar constant) w.r.t. the parameters (d_grad, layout of
 // psignn_f_param_vjp) and w.r.t. h (d_grad_h): what autograd's double backward leaves after
 // autograd.grad(f(h), h, v, create_graph=True) -- jac_loss_estimate, dirichlet/psignn/model.py:416-435.  Caller's numbering.
 extern "C" int psignn_f_vjp_backward(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* prb,
-                                     const float* v, const float* gbar, float* d_grad, float* d_grad_h, float* work,
-                                     void* stream) {
+                                     const float* nrm, const float* v, const float* gbar, float* d_grad, float* d_grad_h,
+                                     float* work, void* stream) {
   ARG_CHECK(p && W && h && prb && v && gbar && d_grad && d_grad_h && work, "NULL argument");
-  ARG_CHECK(!p->mixed && nl == 1, "the backward of the VJP is implemented for single-layer dirichlet blocks");
+  ARG_CHECK(nl == 1, "the backward of the VJP is implemented for single-layer blocks");
+  ARG_CHECK(!p->mixed || nrm, "mixed plan needs unit normals");
   hipStream_t st = (hipStream_t)stream;
   const int64_t N = p->N;
-  float* rec = work + N * 13 * D;
-  float* part = rec + 2 * N * PGREC;
+  float* rec = work + N * 17 * D;
   int npw;
   const int nblk = pgrad_blocks(2 * N, &npw);
-  int rc = psignn_jacreg_records(p, W, h, prb, v, gbar, d_grad_h, work, rec, st);
+  int rc = psignn_jacreg_records(p, W, h, prb, nrm, v, gbar, d_grad_h, work, rec, st);
   if (rc) return rc;
-  HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)WLayout<2>::base_total(nl, false) * 4, st));
-  LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabF><<<nblk, 256, 0, st>>>(2 * N, npw, rec, part)));
-  LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabF::NT, 256, 0, st>>>(nblk, TabF::NT, part, d_grad, MapF())));
+  if (p->mixed) {
+    float* part = rec + 2 * N * TabX::NG * 16;
+    HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)WLayout<3>::base_total(nl, true) * 4, st));
+    LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabX><<<nblk, 256, 0, st>>>(2 * N, npw, rec, part)));
+    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabX::NT, 256, 0, st>>>(nblk * 4, TabX::NT, part, d_grad, MapX())));
+  } else {
+    float* part = rec + 2 * N * TabF::NG * 16;
+    HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)WLayout<2>::base_total(nl, false) * 4, st));
+    LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabF><<<nblk, 256, 0, st>>>(2 * N, npw, rec, part)));
+    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabF::NT, 256, 0, st>>>(nblk, TabF::NT, part, d_grad, MapF())));
+  }
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }

@@ -411,7 +411,7 @@ class FixedPointMap:
     def vjp_backward(self, H, V, Gbar):
         """Gradient of  Gbar . (J_f(H)^T V)  with Gbar held constant: ({name: grad}, d / dH) -- what autograd's double
         backward computes for ``autograd.grad(f(H), H, V, create_graph=True)`` (jac_loss_estimate,
-        dirichlet/psignn/model.py:416-435).  Single-layer dirichlet blocks, caller's numbering."""
+        dirichlet/psignn/model.py:416-435).  Single-layer blocks of both families, caller's numbering."""
         Hc, Vc, Gc = _f32c(H), _f32c(V), _f32c(Gbar)
         l = nat.lib()
         grad = torch.empty(int(l.psignn_param_grad_size(int(self.weights.mixed), self.weights.n_layers)),
@@ -419,7 +419,7 @@ class FixedPointMap:
         out = torch.empty_like(Hc)
         with torch.cuda.device(Hc.device):
             nat.check(l.psignn_f_vjp_backward(self.plan.handle, nat.ptr(self.weights.flat), self.weights.n_layers,
-                                              nat.ptr(Hc), nat.ptr(self.prb), nat.ptr(Vc), nat.ptr(Gc), nat.ptr(grad),
+                                              nat.ptr(Hc), nat.ptr(self.prb), nat.ptr(self.nrm), nat.ptr(Vc), nat.ptr(Gc), nat.ptr(grad),
                                               nat.ptr(out), nat.ptr(self.plan.vjp_backward_workspace()),
                                               nat.stream_ptr(Hc.device)), "psignn_f_vjp_backward")
         return unpack_param_grads(grad, self.weights.n_layers, self.weights.mixed), out

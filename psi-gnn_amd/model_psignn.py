@@ -225,8 +225,8 @@ class DeepEquilibrium(nn.Module):
     def train_forward(self, H_init, batch, generator=None):
         """(new_H_star, jacobian_loss) of the training variant.  With gradients enabled new_H_star carries the
         implicit-function backward; without (validation) the spectral radius is logged like the reference does.
-        The Jacobian regulariser carries its gradient w.r.t. the parameters of f in the dirichlet family
-        (``_JacLossFn``; the reference's launch scripts train with ``jac_weight 1.0``); in the mixed family it is a value only."""
+        The Jacobian regulariser carries its gradient w.r.t. the parameters of f (``_JacLossFn``; the reference's launch
+        scripts train with ``jac_weight 1.0``)."""
         if torch.is_grad_enabled():
             if self.f.n_layers != 1:
                 raise nat.NativeError("the training path is implemented for single-layer blocks")
@@ -238,7 +238,7 @@ class DeepEquilibrium(nn.Module):
             self.last_forward = out_fw
             H_star = out_fw["result"]
             new_H = self.f.bind(H_init, batch)(H_star)
-        if torch.is_grad_enabled() and not self.f.mixed:
+        if torch.is_grad_enabled():
             # differentiable w.r.t. the parameters of f, as in the reference (vecs = 1, model.py:207)
             v = torch.randn(H_star.shape, device=H_star.device, generator=generator)
             self.last_probe = v

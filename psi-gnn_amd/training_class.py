@@ -56,9 +56,6 @@ class TrainModel:
         self.gradient_clip = config["gradient_clip"]
         self.sup_weight = config.get("sup_weight", 0.0)
         self.jac_weight = config.get("jac_weight", 0.0)
-        if self.jac_weight != 0.0 and getattr(self.net, "mixed", False):
-            raise nat.NativeError("jac_weight != 0 in the mixed family: the backward of the VJP (the regulariser's "
-                                  "second-order gradient) is implemented for the dirichlet family only")
         self.training_time = 0
         self.hist_train = {k: [] for k in _KEYS}
         self.hist_val = {k: [] for k in _KEYS}
