@@ -274,6 +274,11 @@ int psignn_broyden_get_iterate(const psignn_broyden_t* s, int i, float* d_dst, v
  *   step_end:   given fx = f(x_new): residual norms, stop test, rank-1 update, next update. */
 int psignn_broyden_ext_begin(psignn_broyden_t* s, const float* d_x0, const float* d_fx0, void* stream);
 int psignn_broyden_ext_next_x(psignn_broyden_t* s, float* d_x_new, void* stream);
+/* Line search of `broyden(..., ls=True)` (line_search / scalar_search_armijo, utilities/solver.py:20-94): the host
+ * evaluates phi(s) = |g(x + s * update)|^2 at trial points (ext_trial_x writes x + s * update, no state change) and
+ * commits the accepted step length with ext_scale_step (update <- s * update) before ext_next_x / ext_update. */
+int psignn_broyden_ext_trial_x(psignn_broyden_t* s, double step, float* d_x_trial, void* stream);
+int psignn_broyden_ext_scale_step(psignn_broyden_t* s, double step, void* stream);
 /* returns 1 in *h_done when the stop test fired (synchronous read of the status). */
 int psignn_broyden_ext_update(psignn_broyden_t* s, const float* d_fx_new, double eps, int* h_done, void* stream);
 int psignn_broyden_ext_finish(psignn_broyden_t* s, float* d_result, psignn_solve_info_t* h_info,

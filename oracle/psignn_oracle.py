@@ -153,9 +153,60 @@ def _matvec(Us, VTs, x):  # solver.py:106-114
     return -x + torch.einsum("bijd, bd -> bij", Us, VTx)
 
 
+def _armijo(phi, phi0, slope0, c1=1e-4, s0=1, smin=0):
+    """scalar_search_armijo, solver.py:20-59: first trial s0; then the minimiser of the quadratic through phi(0),
+    phi'(0), phi(s0); then cubic interpolation through the last two trials until phi(s) <= phi0 + c1 s slope0, each new
+    trial pulled back to s1 / 2 when it moved less than 4 % or more than 50 %; None below smin.  As in the reference the
+    quadratic trial itself is never tested.  Returns (s, phi(s), cubic rounds)."""
+    rounds = 0
+    p0 = phi(s0)
+    if p0 <= phi0 + c1 * s0 * slope0:
+        return s0, p0, rounds
+    s1 = -(slope0) * s0 ** 2 / 2.0 / (p0 - phi0 - slope0 * s0)
+    p1 = phi(s1)
+    while s1 > smin:
+        scale = s0 ** 2 * s1 ** 2 * (s1 - s0)
+        ca = s0 ** 2 * (p1 - phi0 - slope0 * s1) - s1 ** 2 * (p0 - phi0 - slope0 * s0)
+        ca = ca / scale
+        cb = -s0 ** 3 * (p1 - phi0 - slope0 * s1) + s1 ** 3 * (p0 - phi0 - slope0 * s0)
+        cb = cb / scale
+        s2 = (-cb + torch.sqrt(torch.abs(cb ** 2 - 3 * ca * slope0))) / (3.0 * ca)
+        p2 = phi(s2)
+        rounds += 1
+        if p2 <= phi0 + c1 * s2 * slope0:
+            return s2, p2, rounds
+        if (s1 - s2) > s1 / 2.0 or (1 - s2 / s1) < 0.96:
+            s2 = s1 / 2.0
+        s0, s1, p0, p1 = s1, s2, p1, p2
+    return None, p1, rounds
+
+
+def _line_search(update, x, gx, g, on):
+    """line_search, solver.py:61-94: step length by ``_armijo`` on phi(s) = |g(x + s update)|^2 with slope -phi(0) and
+    smin = 1e-2 (s = 1 when ``on`` is false or the search fails); the residual at the accepted s is reused when it was the
+    last one evaluated.  Returns (x_new, g_new, x_new - x, g_new - g)."""
+    last = {"s": 0, "g": gx, "phi": torch.norm(gx) ** 2}
+
+    def phi(s):
+        if s == last["s"]:
+            return last["phi"]
+        gn = g((x + s * update)[0, :]).view_as(x)
+        val = torch.norm(gn) ** 2 if torch.isfinite(gn).all() else np.inf
+        last.update(s=s, g=gn, phi=val)
+        return val
+
+    s = None
+    if on:
+        s, _, _ = _armijo(phi, last["phi"], -last["phi"], smin=1e-2)
+    if s is None:
+        s = 1.0
+    x_new = x + s * update
+    g_new = last["g"] if s == last["s"] else g(x_new[0, :]).view_as(x)
+    return x_new, g_new, x_new - x, g_new - gx
+
+
 def broyden(f, x0, threshold, eps=1e-3, stop_mode="rel", ls=False, name="unknown"):
-    """solver.py:116-207 with ls=False (the only mode any caller uses)."""
-    assert not ls, "line search is never enabled by the reference's callers"
+    """solver.py:116-207 (``ls=False`` is the only mode any caller of the reference uses)."""
     x0 = x0[None, :]
     bsz, total_hsize, seq_len = x0.size()
     g = lambda y: f(y) - y
@@ -173,10 +224,7 @@ def broyden(f, x0, threshold, eps=1e-3, stop_mode="rel", ls=False, name="unknown
     nstep, lowest_xest = 0, x_est[0, :]
     xest_trace = [x_est[0, :]]
     while nstep < threshold:
-        x_new = x_est + 1.0 * update  # line_search(on=False): s = 1.0 (solver.py:85-94)
-        gx_new = g(x_new[0, :]).view_as(x_est)
-        delta_x, delta_gx = x_new - x_est, gx_new - gx
-        x_est, gx = x_new, gx_new
+        x_est, gx, delta_x, delta_gx = _line_search(update, x_est, gx, g, ls)  # on=False: s = 1.0 (solver.py:85-94)
         xest_trace.append(x_est[0, :])
         nstep += 1
         abs_diff = torch.norm(gx).item()

@@ -84,6 +84,8 @@ SIGNATURES = {
     "psignn_broyden_get_iterate": (_INT, [_P, _INT, _P, _P]),
     "psignn_broyden_ext_begin": (_INT, [_P, _P, _P, _P]),
     "psignn_broyden_ext_next_x": (_INT, [_P, _P, _P]),
+    "psignn_broyden_ext_trial_x": (_INT, [_P, C.c_double, _P, _P]),
+    "psignn_broyden_ext_scale_step": (_INT, [_P, C.c_double, _P]),
     "psignn_broyden_ext_update": (_INT, [_P, _P, C.c_double, C.POINTER(_INT), _P]),
     "psignn_broyden_ext_finish": (_INT, [_P, _P, C.POINTER(SolveInfo), C.POINTER(C.c_double),
                                          C.POINTER(C.c_double), _P]),

@@ -198,6 +198,26 @@ __global__ __launch_bounds__(TB) void k_xnext(int64_t M, const Status* __restric
   if (copy_out) stv<VEC>(copy_out, e0, M, a);
 }
 
+// line search (solver.py:61-94, ls=True): trial point x_cur + s * upd -> out; commit: the step becomes upd <- s * upd
+template <int VEC>
+__global__ __launch_bounds__(TB) void k_xtrial(int64_t M, const Status* __restrict__ st, const float* __restrict__ xb,
+                                               float* __restrict__ upd, float s, float* __restrict__ out, int commit) {
+  if (st->done) return;
+  int64_t e0 = elem0<VEC>();
+  if (e0 >= M) return;
+  const float* xc = xb + (int64_t)st->cur * M;
+  float a[VEC], b[VEC];
+  ldv<VEC>(xc, e0, M, a);
+  ldv<VEC>(upd, e0, M, b);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    b[i] *= s;
+    a[i] += b[i];
+  }
+  if (out) stv<VEC>(out, e0, M, a);
+  if (commit) stv<VEC>(upd, e0, M, b);
+}
+
 // g_new = fx - x_next ; dg = g_new - g ; g = g_new ; per-wave partials of |g_new|^2 and |fx|^2
 template <int VEC>
 __global__ __launch_bounds__(TB) void k_resid(int64_t M, const Status* __restrict__ st, const float* __restrict__ xb,
@@ -897,6 +917,18 @@ extern "C" int psignn_broyden_ext_begin(psignn_broyden_t* s, const float* d_x0, 
 extern "C" int psignn_broyden_ext_next_x(psignn_broyden_t* s, float* d_x_new, void* stream) {
   ARG_CHECK(s && d_x_new, "NULL argument");
   VPLAIN(s->vec, k_xnext, ((unsigned)s->nblk, TB, 0, (hipStream_t)stream), s->M, s->st, s->xbuf, s->upd, d_x_new);
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+extern "C" int psignn_broyden_ext_trial_x(psignn_broyden_t* s, double step, float* d_x_trial, void* stream) {
+  ARG_CHECK(s && d_x_trial, "NULL argument");
+  VPLAIN(s->vec, k_xtrial, ((unsigned)s->nblk, TB, 0, (hipStream_t)stream), s->M, s->st, s->xbuf, s->upd, (float)step, d_x_trial, 0);
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+extern "C" int psignn_broyden_ext_scale_step(psignn_broyden_t* s, double step, void* stream) {
+  ARG_CHECK(s, "NULL argument");
+  VPLAIN(s->vec, k_xtrial, ((unsigned)s->nblk, TB, 0, (hipStream_t)stream), s->M, s->st, s->xbuf, s->upd, (float)step, nullptr, 1);
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }

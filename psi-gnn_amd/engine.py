@@ -756,8 +756,51 @@ class DeviceBroyden:
                                                            nat.stream_ptr(self.device)), "psignn_broyden_get_iterate")
         return dst
 
-    def solve_callable(self, f, x0, eps):
-        """Generic f (any Python callable on device tensors): one f call per iteration from the host."""
+    def _armijo_step(self, f, phi0, lib, sp, like):
+        """Step length of the reference's line search (line_search / scalar_search_armijo, utilities/solver.py:20-94) for
+        the current update direction: backtracking on phi(s) = |f(x + s u) - (x + s u)|^2 with phi'(0) taken as -phi(0),
+        c1 = 1e-4, first trial s = 1, then the minimiser of the quadratic through (0, 1), then cubic interpolation through
+        the last two trials, safeguarded to shrink by at least 4 % and at most 50 % per round, given up below s = 1e-2
+        (-> s = 1).  Like the reference, the quadratic trial is never tested against the Armijo condition itself.
+        Returns (s, f(x + s u) if it was evaluated at that s else None, phi(s) or None)."""
+        c1, amin, der0 = 1e-4, 1e-2, -phi0
+        cache = {}
+
+        def phi(s):
+            xt = torch.empty_like(like)
+            nat.check(lib.psignn_broyden_ext_trial_x(self.handle, float(s), nat.ptr(xt), sp), "ext_trial_x")
+            fx = _f32c(f(xt.clone()))
+            g = fx - xt
+            val = float(g.norm()) ** 2 if bool(torch.isfinite(g).all()) else float("inf")
+            cache["s"], cache["fx"], cache["phi"] = s, fx, val
+            return val
+
+        def accept(s, val):
+            return val <= phi0 + c1 * s * der0
+
+        s0, p0 = 1.0, phi(1.0)
+        if accept(s0, p0):
+            return s0, cache["fx"], p0
+        s1 = -der0 * s0 ** 2 / 2.0 / (p0 - phi0 - der0 * s0)
+        p1 = phi(s1)
+        while s1 > amin:
+            den = s0 ** 2 * s1 ** 2 * (s1 - s0)
+            r0, r1 = p0 - phi0 - der0 * s0, p1 - phi0 - der0 * s1
+            ca = (s0 ** 2 * r1 - s1 ** 2 * r0) / den
+            cb = (-s0 ** 3 * r1 + s1 ** 3 * r0) / den
+            s2 = (-cb + abs(cb ** 2 - 3.0 * ca * der0) ** 0.5) / (3.0 * ca)
+            p2 = phi(s2)
+            if accept(s2, p2):
+                return s2, cache["fx"], p2
+            if (s1 - s2) > s1 / 2.0 or (1.0 - s2 / s1) < 0.96:
+                s2 = s1 / 2.0
+            s0, s1, p0, p1 = s1, s2, p1, p2
+        # no admissible step: s = 1 (solver.py:85-93; f there is re-evaluated unless the last trial was at s = 1)
+        return 1.0, (cache["fx"] if cache["s"] == 1.0 else None), None
+
+    def solve_callable(self, f, x0, eps, ls=False):
+        """Generic f (any Python callable on device tensors): one f call per iteration from the host (ls=True: plus the
+        trial evaluations of the Armijo line search)."""
         x0c = _f32c(x0)
         lib, sp = nat.lib(), nat.stream_ptr(self.device)
         with torch.cuda.device(self.device):
@@ -765,7 +808,22 @@ class DeviceBroyden:
             nat.check(lib.psignn_broyden_ext_begin(self.handle, nat.ptr(x0c), nat.ptr(fx), sp), "ext_begin")
             done = C.c_int(0)
             xn = torch.empty_like(x0c)
+            phi_cur = float((fx - x0c).norm()) ** 2 if ls else 0.0
+            self.ls_steps = []
             for _ in range(self.threshold):
+                if ls:
+                    s, fx_s, phi_s = self._armijo_step(f, phi_cur, lib, sp, x0c)
+                    self.ls_steps.append(s)
+                    if s != 1.0:
+                        nat.check(lib.psignn_broyden_ext_scale_step(self.handle, float(s), sp), "ext_scale_step")
+                    nat.check(lib.psignn_broyden_ext_next_x(self.handle, nat.ptr(xn), sp), "ext_next_x")
+                    fx = fx_s if fx_s is not None else _f32c(f(xn.clone()))
+                    phi_cur = phi_s if phi_s is not None else float((fx - xn).norm()) ** 2
+                    nat.check(lib.psignn_broyden_ext_update(self.handle, nat.ptr(fx), float(eps), C.byref(done), sp),
+                              "ext_update")
+                    if done.value:
+                        break
+                    continue
                 nat.check(lib.psignn_broyden_ext_next_x(self.handle, nat.ptr(xn), sp), "ext_next_x")
                 fx = _f32c(f(xn.clone()))
                 nat.check(lib.psignn_broyden_ext_update(self.handle, nat.ptr(fx), float(eps), C.byref(done), sp),

@@ -56,11 +56,10 @@ def broyden(f, x0, threshold, eps=1e-3, stop_mode="rel", ls=False, name="unknown
     Same contract as the reference: ``result`` is the lowest-``stop_mode`` iterate x (not f(x)), ``nstep`` its
     index, ``rel = |f(x)-x| / (|f(x)| + 1e-9)``, stops on ``objective < eps``, the 30-step plateau rule, the
     protective break (``rel > rel_0 * 1e3 * d``; ``abs > abs_0 * 1e6 * d`` in stop_mode "abs") or ``threshold``
-    iterations.  ``ls=True`` (Armijo line search, solver.py:61-94) is not implemented: no call site of the reference
-    enables it.
+    iterations.  ``ls=True`` (Armijo line search, solver.py:20-94; no call site of the reference enables it) runs the
+    host-driven loop -- the trial points need extra f evaluations between the device steps -- also for a
+    ``FixedPointMap``.
     """
-    if ls:
-        raise NotImplementedError("broyden(ls=True): the line search is not implemented (no reference call site uses it)")
     if stop_mode not in ("rel", "abs"):
         raise ValueError(f"stop_mode {stop_mode!r}")
     nat.require_cuda(x0, "x0")
@@ -69,7 +68,7 @@ def broyden(f, x0, threshold, eps=1e-3, stop_mode="rel", ls=False, name="unknown
     M = x0.numel()
     if keep_trace is None:
         keep_trace = (threshold + 2) * M * 4 <= TRACE_BUDGET_BYTES
-    if isinstance(f, FixedPointMap):
+    if isinstance(f, FixedPointMap) and not ls:
         # solver_obj: a DeviceBroyden of the same plan / threshold kept by the caller between solves (a training loop
         # would otherwise allocate and free 2 * threshold * N * d floats per step); its iterates are overwritten by the
         # next solve, so it is only meant for callers that do not keep xest_trace
@@ -81,7 +80,7 @@ def broyden(f, x0, threshold, eps=1e-3, stop_mode="rel", ls=False, name="unknown
         solver = DeviceBroyden(threshold=threshold, keep_trace=keep_trace, n_elems=M, seq_len=x0.shape[1],
                                device=x0.device)
         solver.set_stop_mode(stop_mode)
-        out = solver.solve_callable(f, x0, eps)
+        out = solver.solve_callable(f, x0, eps, ls=ls)
         x_init = x0
     res = out["result"].reshape(x0.shape)
     trace = _LazyTrace(solver, out["n_iter"], res, x_init, res, out["nstep"])

@@ -819,8 +819,6 @@ def test_broyden_stop_mode_abs(dev):
     assert np.allclose(got["rel_trace"][11:], min(got["rel_trace"][:11]), rtol=1e-12)   # ... and lowest[alternative]
     assert np.allclose(got["rel_trace"][11:], min(want["rel_trace"][:11]), rtol=2e-2)
     assert rel_l2(got["result"], want["result"]) < 1e-3   # an unconverged iterate after 11 steps (measured 1.3e-4)
-    with pytest.raises(NotImplementedError):
-        solver.broyden(fmap, fmap.h0, threshold=5, eps=1e-3, ls=True)
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -877,3 +875,34 @@ def test_random_graphs_plan_tiles_and_f(seed, dev):
     assert rel_l2(fm(h.to(dev)), want) < 5e-6, (seed, plan.tiled)
     w = t(rng.standard_normal((N, 10)).astype(np.float32))
     assert rel_l2(fm.vjp(h.to(dev), w.to(dev)), orc.function_vjp(sd, h, h0, m, w)) < 5e-5
+
+
+def test_broyden_line_search(dev):
+    """broyden(..., ls=True): Armijo line search (solver.py:20-94) around the device low-rank machinery, vs the reference
+    solver's outputs (tests/golden/broyden_ls.npz, oracle/make_golden_ls.py)."""
+    import os
+    solver = pkg("utilities.solver")
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "broyden_ls.npz"))
+    A, b = torch.from_numpy(G["toy_A"]).to(dev), torch.from_numpy(G["toy_b"]).to(dev)
+    calls = [0]
+
+    def ft(x):
+        calls[0] += 1
+        return torch.tanh(A @ x.reshape(-1) * 1.5 + b).reshape(x.shape)
+    out = solver.broyden(ft, torch.zeros(16, 10, device=dev), threshold=60, eps=1e-6, ls=True)
+    n = int(G["toy_niter"])
+    assert abs(out["nstep"] - int(G["toy_nstep"])) <= 3 and abs(calls[0] - int(G["toy_fcalls"])) <= 6
+    np.testing.assert_allclose(out["rel_trace"][:10], G["toy_rel_trace"][:10], rtol=2e-3)
+    assert out["lowest"] < 1e-6 and rel_l2(out["result"], G["toy_result"]) < 1e-5
+    # the GNN block through the same host-driven loop (a FixedPointMap takes this path when ls=True)
+    g, mesh = load_case("hex13_dirichlet_s0")
+    md = mesh.to(dev)
+    eng = pkg("engine")
+    fmap = eng.FixedPointMap(eng.plan_for(md), eng.PackedWeights(load_weights("dirichlet"), dev),
+                             torch.from_numpy(g["h0"]).to(dev), md.prb_data, None)
+    out = solver.broyden(fmap, fmap.h0, threshold=300, eps=1e-5, ls=True)
+    np.testing.assert_allclose(out["rel_trace"][:5], G["hex13_rel_trace"][:5], rtol=2e-3)
+    assert rel_l2(out["xest_trace"][2], G["hex13_x2"]) < 1e-4
+    assert out["lowest"] < 1e-5 and rel_l2(out["result"], G["hex13_result"]) < 5e-3
+    plain = solver.broyden(fmap, fmap.h0, threshold=300, eps=1e-5)
+    assert rel_l2(out["result"], plain["result"]) < 5e-3
