@@ -1,0 +1,70 @@
+"""Training from random initialisation with the reference's launch configuration (dirichlet/psignn/launch_local.sh:
+batch 50, lr_deq 0.01, lr_ae 0.05, gradient_clip 0.1, solver broyden, jac_weight 1.0, fw 1e-5 / 400, bw 1e-8 / 400,
+seed 1234) through the reference's main.py shape (DataListLoader + DataParallel + TrainModel), on synthetic hexagon
+meshes in the reader's schema (the reference's dataset needs FEniCS + gmsh to generate).
+
+    python3 scripts/train_demo.py [graphs=300] [epochs=15] [out_dir=gpurun_out/train_demo]
+
+Prints one JSON line: per-epoch training / validation losses, seconds per epoch, Broyden step statistics.
+"""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = lambda n="": importlib.import_module("psi-gnn_amd" + ("." + n if n else ""))
+
+
+def main():
+    G = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 15
+    out_dir = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "train_demo")
+    os.makedirs(out_dir, exist_ok=True)
+    torch.manual_seed(1234)
+    np.random.seed(1234)
+    data, loader, solver = pkg("data"), pkg("loader"), pkg("utilities.solver")
+    rng = np.random.default_rng(1234)
+    graphs = [data.make_hex_problem(int(rng.integers(9, 15)), seed=s, phase=0.37 * s) for s in range(G)]
+    n_tr, n_va = int(0.6 * G), int(0.2 * G)            # reader.py split: 60 / 20 / 20
+    train, val = graphs[:n_tr], graphs[n_tr:n_tr + n_va]
+    dev = torch.device("cuda:0")
+    cfg = {"latent_dim": 10, "hidden_dim": 10, "n_layers": 1, "fw_tol": 1e-5, "fw_thres": 400, "bw_tol": 1e-8,
+           "bw_thres": 400, "solver": solver.broyden, "path_logs": out_dir}
+    net = pkg("model_psignn").ModelDEQDSS(cfg)
+    model = loader.DataParallel(net).to(dev)
+    TrainModel = pkg("training_class").TrainModel
+    tr = TrainModel({"model": model, "config_model": cfg,
+                     "loader_train": loader.DataListLoader(train, batch_size=50, shuffle=True),
+                     "loader_val": loader.DataListLoader(val, batch_size=50, shuffle=False),
+                     "sup_weight": 0.0, "jac_weight": 1.0, "gradient_clip": 0.1, "lr_deq": 0.01, "sched_step_deq": 0.5,
+                     "lr_ae": 0.05, "sched_step_ae": 0.5, "max_epochs": epochs, "min_loss_save": 1e5, "path_ckpt": out_dir})
+    t0 = time.perf_counter()
+    tr.train_model()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    def steps(name):
+        path = os.path.join(out_dir, name)
+        if not os.path.exists(path):
+            return None
+        rows = [l.split() for l in open(path).read().splitlines() if l.strip()]
+        n = [int(r[1]) for r in rows if len(r) == 2]
+        return {"solves": len(n), "mean_nstep": float(np.mean(n)), "max_nstep": int(np.max(n))} if n else None
+    nodes = sum(int(g.x.shape[0]) for g in train)
+    print(json.dumps({
+        "workload": f"{n_tr} training / {n_va} validation hexagon meshes (n = 9..14, {nodes} training nodes), batch 50, "
+                    f"{epochs} epochs from xavier initialisation, reference launch_local.sh hyper-parameters (jac_weight 1.0)",
+        "seconds_total": dt, "seconds_per_epoch": dt / epochs,
+        "train": {k: [round(float(x), 6) for x in v] for k, v in tr.hist_train.items()},
+        "val": {k: [round(float(x), 6) for x in v] for k, v in tr.hist_val.items()},
+        "forward_solves": steps("forward_iteration.csv"), "backward_solves": steps("backward_iteration.csv")}))
+
+
+if __name__ == "__main__":
+    main()
