@@ -2,7 +2,7 @@
 hexagon meshes -- forward Broyden solve, on-device adjoint solve, parameter-VJP, optimiser -- on the HIP path, with
 the CPU oracle's restated training step (autograd + restated broyden) timed beside it on the same batch.
 
-    python3 scripts/train_bench.py [graphs_per_batch=50] [hex_n=13] [steps=5] [cpu=1] [jac_weight=0]
+    python3 scripts/train_bench.py [graphs_per_batch=50] [hex_n=13] [steps=5] [cpu=1] [jac_weight=0] [family=dirichlet|mixed]
 
 jac_weight = 1 is what the reference's launch scripts use (launch_local.sh:24): the step then also runs the backward of
 the VJP (csrc/fgnn_jacreg.hip).
@@ -28,16 +28,17 @@ def main():
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     cpu = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     jw = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0
+    mixed = len(sys.argv) > 6 and sys.argv[6] == "mixed"
     data, nat = pkg("data"), pkg("_native")
     import numpy as np
-    w = np.load(os.path.join(ROOT, "tests", "golden", "weights_dirichlet.npz"))
+    w = np.load(os.path.join(ROOT, "tests", "golden", "weights_mixed.npz" if mixed else "weights_dirichlet.npz"))
     sd = {k: torch.from_numpy(w[k]) for k in w.files}
-    meshes = [data.make_hex_problem(n, seed=s, phase=0.37 * s) for s in range(B)]
+    meshes = [data.make_hex_problem(n, seed=s, phase=0.37 * s, mixed=mixed) for s in range(B)]
     batch = data.collate(meshes)
     dev = torch.device("cuda:0")
     solver = pkg("utilities.solver")
     cfg = dict(latent_dim=10, n_layers=1, solver=solver.broyden, fw_tol=1e-5, fw_thres=500, bw_tol=1e-8, bw_thres=500)
-    net = pkg("model_psignn").ModelDEQDSS(cfg)
+    net = (pkg("mixed") if mixed else pkg("model_psignn")).ModelDEQDSS(cfg)
     net.load_state_dict(sd)
     net = net.to(dev).train()
     TrainModel = pkg("training_class").TrainModel
@@ -60,7 +61,7 @@ def main():
     dt = (time.perf_counter() - t0) / steps
     kern = nat.prof_collect()
     nat.prof_enable(False)
-    out = {"workload": f"training step, union batch of {B} hexagon meshes (n={n}): {batch.num_nodes} nodes, "
+    out = {"workload": f"training step ({'mixed' if mixed else 'dirichlet'} family), union batch of {B} hexagon meshes (n={n}): {batch.num_nodes} nodes, "
                        f"{batch.num_edges} edges; fw_tol 1e-5 / bw_tol 1e-8, thresholds 500 (reference defaults), jac_weight {jw}",
            "gpu_s_per_step": dt, "gpu_graphs_per_s": B / dt, "first_step_loss": warm, "fw_nstep": fw, "bw_nstep": bw, "loss": losses,
            "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])[:12]}}
