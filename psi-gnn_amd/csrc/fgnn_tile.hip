@@ -12,6 +12,17 @@
 // The second Phi layer (W2 S + deg b2) is linear and is folded into the consumers' first-layer weights on
 // the host (WLayout fold block).  All node tensors are in PLAN order; the solver keeps its state there.
 #include "tile_helpers.h"
+#ifndef TILE_WPE
+#define TILE_WPE 0    // > 0: __attribute__((amdgpu_waves_per_eu(TILE_WPE))) on k_f_tile (A/B: scripts/ab_edge.sh)
+#endif
+#if TILE_WPE
+#define TILE_WPE_ATTR __attribute__((amdgpu_waves_per_eu(TILE_WPE, TILE_WPE)))
+#else
+#define TILE_WPE_ATTR
+#endif
+#ifndef EDGE_CLAMP
+#define EDGE_CLAMP 1  // relu folded into the clamp bit of the last edge fma (tile_helpers.h: edge_pass_both_clamp)
+#endif
 #ifndef EDGE_BOTH
 #define EDGE_BOTH 1   // both edge directions in one slot walk (edge_pass_both); 0: one walk per direction.  A/B on one
                       // box, 1M nodes: plain f 61.5 vs 62.9 us, fused Broyden step 99.5 vs 104 us
@@ -97,7 +108,7 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 }
 
 template <int P, bool MIXED, bool FUSED, bool MFMA1>
-__global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tiles, int chunk, const int32_t* __restrict__ tile_list,
+__global__ __launch_bounds__(TILE_THREADS) TILE_WPE_ATTR void k_f_tile(FuseArgs fa, int n_tiles, int chunk, const int32_t* __restrict__ tile_list,
                                                 const int32_t* __restrict__ tile_ptr,
                                                 const int32_t* __restrict__ tile_slice, const int32_t* __restrict__ halo,
                                                 const int32_t* __restrict__ halo_cnt, const int32_t* __restrict__ slice_off,
@@ -268,7 +279,11 @@ __global__ __launch_bounds__(TILE_THREADS) void k_f_tile(FuseArgs fa, int n_tile
     PHASE();
     mv2<D>(T + L::T_W1I_FR, x, Pi2);
     PHASE();
+#if EDGE_CLAMP
+    edge_pass_both_clamp<RS>(slots, nslots, lds, T + L::T_A_TO, T + L::T_A_FR, Pi, Pi2, S_to, S_fr, deg_in, deg_out);
+#else
     edge_pass_both<RS>(slots, nslots, lds, T + L::T_A_TO, T + L::T_A_FR, Pi, Pi2, S_to, S_fr, deg_in, deg_out);
+#endif
     PHASE();
   }
 #else

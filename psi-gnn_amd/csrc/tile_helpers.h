@@ -108,6 +108,101 @@ __device__ __forceinline__ float edge_pass(const uint4* __restrict__ slots, int 
 }
 
 
+// ---- relu folded into the last fma of an edge pre-activation -----------------------------------------------------
+// v_max_f32 is not packed on gfx950, so  S += relu(z)  costs two v_max + one v_pk_add per output pair -- 10 of the 35
+// VALU slots of one edge direction.  The VOP3P clamp bit clamps a result to [0, 1] for free; computing the
+// pre-activation SCALED by 2^-40 (every term times a power of two: bit-exact, fp32 rounding commutes with it unless a
+// value underflows below 2^-126, i.e. |z| < 2^-86) turns relu(z) = 2^40 clamp(2^-40 z) for every |z| < 2^40 ~ 1e12.
+// NaN clamps to 0, as v_max(NaN, 0) did.  The attr values a0, a1, a2 are broadcast from the halves of two register
+// pairs with op_sel (the compiler would spend six v_mov per slot on duplicating them).
+#define RELU_SCALE 9.094947017729282e-13f   // 2^-40
+#define RELU_UNSCALE 1099511627776.f        // 2^40
+__device__ __forceinline__ v2f pk_fma_lo(v2f w, v2f a, v2f z) {  // z + w * (a.x, a.x)
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "s"(w), "v"(a), "v"(z));
+  return r;
+}
+__device__ __forceinline__ v2f pk_fma_hi(v2f w, v2f a, v2f z) {  // z + w * (a.y, a.y)
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "s"(w), "v"(a), "v"(z));
+  return r;
+}
+__device__ __forceinline__ v2f pk_fma_lo_clamp(v2f w, v2f a, v2f z) {  // clamp(z + w * (a.x, a.x), 0, 1)
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] clamp" : "=v"(r) : "s"(w), "v"(a), "v"(z));
+  return r;
+}
+
+// edge_pass_both with the clamp form: S_to / S_fr come back UNSCALED (multiplied by 2^40 at the end).
+template <int RS>
+__device__ __forceinline__ void edge_pass_both_clamp(const uint4* __restrict__ slots, int nslots, const float* __restrict__ lds,
+                                                     const float* __restrict__ AT_to, const float* __restrict__ AT_fr,
+                                                     const v2f* Pi_to, const v2f* Pi_fr, v2f* S_to, v2f* S_fr,
+                                                     float& deg_in, float& deg_out) {
+  v2f wt[15], wf[15], pt[5], pf[5];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) {
+    wt[i] = reinterpret_cast<const v2f*>(AT_to)[i];
+    wf[i] = reinterpret_cast<const v2f*>(AT_fr)[i];
+  }
+  const v2f sc = splat(RELU_SCALE);
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    pt[p] = Pi_to[p] * sc;
+    pf[p] = Pi_fr[p] * sc;
+  }
+  deg_in = deg_out = 0.f;
+  if (nslots <= 0) return;
+  uint4 c0 = slots[0];
+  uint4 c1 = slots[(int64_t)min(1, nslots - 1) * 64];
+  for (int r = 0; r < nslots; ++r) {
+    const uint4 nx = slots[(int64_t)min(r + 2, nslots - 1) * 64];
+    const unsigned w = c0.x;
+    if ((w & 0xFFFFu) != ELL_EMPTY) {
+      const v2f a01 = (v2f){__uint_as_float(c0.y), __uint_as_float(c0.z)} * sc;
+      const v2f a2 = (v2f){__uint_as_float(c0.w) * RELU_SCALE, 0.f};
+      const float4* row = reinterpret_cast<const float4*>(lds + (int)(w & 0xFFFFu) * RS);
+      const float4 v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3], v4 = row[4];
+      if (w & SLOT_IN) {
+        v2f z[5] = {(v2f){v0.x, v0.y}, (v2f){v0.z, v0.w}, (v2f){v1.x, v1.y}, (v2f){v1.z, v1.w}, (v2f){v2.x, v2.y}};
+        deg_in += 1.f;
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(z[p], sc, pt[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = pk_fma_lo(wt[p], a01, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = pk_fma_hi(wt[5 + p], a01, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = pk_fma_lo_clamp(wt[10 + p], a2, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) S_to[p] += z[p];
+      }
+      if (w & SLOT_OUT) {
+        v2f z[5] = {(v2f){v2.z, v2.w}, (v2f){v3.x, v3.y}, (v2f){v3.z, v3.w}, (v2f){v4.x, v4.y}, (v2f){v4.z, v4.w}};
+        deg_out += 1.f;
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(z[p], sc, pf[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = pk_fma_lo(wf[p], a01, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = pk_fma_hi(wf[5 + p], a01, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = pk_fma_lo_clamp(wf[10 + p], a2, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) S_fr[p] += z[p];
+      }
+    }
+    c0 = c1;
+    c1 = nx;
+  }
+  const v2f us = splat(RELU_UNSCALE);
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    S_to[p] *= us;
+    S_fr[p] *= us;
+  }
+}
+
 // Both directions of the neighbour sum in ONE walk over the slots: a pair-merged slot is decoded once, its 80-byte LDS row
 // [to | from] is read once, and the IN half (Phi_to, mirrored attr weights) and the OUT half (Phi_from) are evaluated back
 // to back.  Needs both attr blocks (60 wave-uniform floats) in SGPRs for the whole loop -- affordable once the phase
