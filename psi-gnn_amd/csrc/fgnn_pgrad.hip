@@ -297,6 +297,79 @@ extern "C" int psignn_f_vjp_backward(const psignn_plan_t* p, const float* W, int
   return PSIGNN_OK;
 }
 
+// ---- DS-GPS: backward of one recurrent update (kernels in fgnn_jacreg.hip)
+struct TabG {  // groups: see fgnn_jacreg.hip
+  static constexpr int NG = 20, NT = 19;
+  __host__ __device__ static constexpr int a(int t) {
+    constexpr int tab[NT] = {6, 6, 6, 7, 8, 9, 10, 11, 12, 13, 11, 11, -1, -1, -1, -1, 14, 14, 14};
+    return tab[t];
+  }
+  __host__ __device__ static constexpr int b(int t) {
+    constexpr int tab[NT] = {0, 1, 2, 0, 0, 3, 4, 0, 0, 0, 1, 2, 16, 17, 18, 19, 5, 1, 2};
+    return tab[t];
+  }
+};
+// gradient layout: the f_theta base layout (phi_to / phi_from slots of layer 0) followed by the gates
+// [Wz (10x32) | bz | Wr | br | Wc | bc]
+struct MapG {
+  __device__ int operator()(int t, int i, int j) const {
+    constexpr int CAT = 3 * D + 2, GSZ = D * CAT + D;
+    constexpr int G0 = WLayout<2>::base_total(1, false);
+    int gate = -1, blk = 0;
+    switch (t) {
+      case 0: gate = 0; blk = 0; break;
+      case 1: gate = 0; blk = 1; break;
+      case 2: gate = 0; blk = 2; break;
+      case 7: gate = 1; blk = 0; break;
+      case 10: gate = 1; blk = 1; break;
+      case 11: gate = 1; blk = 2; break;
+      case 16: gate = 2; blk = 0; break;
+      case 17: gate = 2; blk = 1; break;
+      case 18: gate = 2; blk = 2; break;
+      default: return pg_offset<2>(t, i, j);   // tiles 3..6, 8, 9, 12..15 coincide with TabF's Phi tiles
+    }
+    if (i >= D) return -1;
+    const int base = G0 + gate * GSZ;
+    if (blk == 0) return j < D ? base + i * CAT + j : (j == D ? base + D * CAT + i : -1);
+    if (blk == 1) return j < D ? base + i * CAT + D + j : (j < D + 2 ? base + i * CAT + 3 * D + (j - D) : -1);
+    return j < D ? base + i * CAT + 2 * D + j : -1;
+  }
+};
+
+int psignn_dsgps_step_records(const psignn_plan* p, const float* Wf, const float* Wg, const float* h, const float* prb,
+                              const float* w, float* out_h, float* work, float* rec, hipStream_t st);
+
+extern "C" int64_t psignn_dsgps_grad_size() { return WLayout<2>::base_total(1, false) + 3 * (D * (3 * D + 2) + D); }
+extern "C" int64_t psignn_dsgps_step_backward_workspace_floats(const psignn_plan_t* p) {
+  if (!p) return 0;
+  int npw;
+  const int nblk = pgrad_blocks(p->N, &npw);
+  return p->N * (13 * D + PGREC) + (int64_t)nblk * 4 * TabG::NT * 256;
+}
+
+// w^T (d h' / d theta) -> d_grad (psignn_dsgps_grad_size floats) and w^T (d h' / d h) -> d_out_h for one DS-GPS update
+// h' = step(h) of the dirichlet family (caller's numbering).  d_phi_weights: the Phi modules in the f_theta weight layout
+// (psignn_weights_size(0, 1) floats, only the phi_to / phi_from blocks are read); d_gate_weights: [Wz|bz|Wr|br|Wc|bc].
+extern "C" int psignn_dsgps_step_backward(const psignn_plan_t* p, const float* d_phi_weights, const float* d_gate_weights,
+                                          const float* h, const float* prb, const float* w, float* d_grad, float* d_out_h,
+                                          float* work, void* stream) {
+  ARG_CHECK(p && d_phi_weights && d_gate_weights && h && prb && w && d_grad && d_out_h && work, "NULL argument");
+  ARG_CHECK(!p->mixed, "the DS-GPS backward is implemented for the dirichlet family");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t N = p->N;
+  float* rec = work + N * 13 * D;
+  float* part = rec + N * PGREC;
+  int npw;
+  const int nblk = pgrad_blocks(N, &npw);
+  int rc = psignn_dsgps_step_records(p, d_phi_weights, d_gate_weights, h, prb, w, d_out_h, work, rec, st);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)psignn_dsgps_grad_size() * 4, st));
+  LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabG><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
+  LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabG::NT, 256, 0, st>>>(nblk * 4, TabG::NT, part, d_grad, MapG())));
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Backward of the two-layer MLP (Encoder / Decoder, model.py:370-392; y = W2 relu(W1 x + b1) + b2) and the
 // transposed residual SpMV -- what autograd runs for the autoencoder / residual terms of the training loss

@@ -6,9 +6,10 @@ unchanged -- and the reference's two entry points:
 
 * ``inference(batch) -> U_k``                                   (model.py:130-163)
 * ``forward(batch) -> (U, loss_dic)``: every decoded iterate ``U['0'..'k']`` and the per-step loss dictionaries
-  (``residual_loss, encoder_loss, autoencoder_loss, mse_dirichlet, mse_loss`` keyed '0'..'k', ``train_loss``) as
-  diagnostics (model.py:48-128).  Back-propagation through the k unrolled steps (training DS-GPS) is not implemented:
-  ``forward`` runs without a graph.
+  (``residual_loss, encoder_loss, autoencoder_loss, mse_dirichlet, mse_loss`` keyed '0'..'k', ``train_loss``)
+  (model.py:48-128).  In train mode (dirichlet family) ``train_loss`` carries its gradients: back-propagation through
+  the k unrolled updates runs on ``psignn_dsgps_step_backward`` (``training_class.TrainModelDSGPS`` is the trainer of
+  dirichlet/dsgps/training_class.py); in eval mode / under ``no_grad`` the same dictionaries come as diagnostics.
 
 Same gather -> edge MLP -> segment-sum kernels as PSI-GNN's f; k launches back to back, no solver.
 """
@@ -20,6 +21,43 @@ import torch.nn as nn
 from . import _native as nat
 from . import engine
 from .model_psignn import MLP, Autoencoder, Phi_from, Phi_to, initialize_weights_xavier
+
+
+class _StepCtx:
+    """Per-forward constants of the unrolled training pass: plan, packed weights, plan-order inputs."""
+
+    def __init__(self, net, batch, H0):
+        dev = H0.device
+        self.plan = engine.plan_for(batch)
+        self.w = net.packed(dev)
+        self.wf, self.wg = engine.pack_dsgps_train(net.state_dict(), dev)
+        self.prb = batch.prb_data
+        self.prbp = self.plan.permute(batch.prb_data, True)
+        self.h0p = self.plan.permute(H0.detach(), True)
+        self.dirichlet = batch.tags.reshape(batch.tags.shape[0], -1)[:, :1] == 1
+
+
+class _DsgpsStepFn(torch.autograd.Function):
+    """One recurrent update H_t -> H_{t+1} (dirichlet/dsgps/model.py:72-89) as an autograd node: forward on the tile kernel,
+    backward on ``psignn_dsgps_step_backward`` (VJP w.r.t. H_t, parameter gradients of phi_to / phi_from and the three
+    gates; the Dirichlet rows' cotangent goes to H_0).  Autograd chains the k nodes: back-propagation through time."""
+
+    @staticmethod
+    def forward(ctx, h, h0, sc, names, *params):
+        hp = sc.plan.permute(h.detach(), True)
+        out = sc.plan.permute(engine.dsgps_step_p(sc.plan, sc.w, hp, sc.h0p, sc.prbp, None), False)
+        ctx.sc, ctx.names = sc, names
+        ctx.save_for_backward(h.detach())
+        return out
+
+    @staticmethod
+    def backward(ctx, w):
+        (h,) = ctx.saved_tensors
+        sc = ctx.sc
+        w = w.contiguous()
+        grads, dh = engine.dsgps_step_backward(sc.plan, sc.wf, sc.wg, h, sc.prb, w)
+        g0 = torch.where(sc.dirichlet, w, torch.zeros_like(w))
+        return (dh, g0, None, None) + tuple(grads[n] for n in ctx.names)
 
 
 class MLPActivation(nn.Module):
@@ -75,8 +113,57 @@ class ModelDSGPS(nn.Module):
                                   batch.unit_normal_vector if self.mixed else None)
         return self.autoencoder.decoder(hk)
 
-    @torch.no_grad()
     def forward(self, batch):
+        if self.training and torch.is_grad_enabled():
+            return self._train_forward(batch)
+        with torch.no_grad():
+            return self._eval_forward(batch)
+
+    def _train_forward(self, batch):
+        """dirichlet/dsgps/model.py:48-128 with gradients: every term of ``train_loss`` carries the gradient it has in the
+        reference -- the residual of each decoded iterate through the decoder and the unrolled updates (BPTT), the
+        encoder term with the decoder's parameters frozen, the autoencoder term with the encoder's frozen (:100-112)."""
+        nat.require_cuda(batch.x, "batch.x")
+        if self.mixed:
+            raise nat.NativeError("training DS-GPS is implemented for the dirichlet family")
+        ae, k, gamma = self.autoencoder, self.config["k"], self.config["gamma"]
+        plan = engine.plan_for(batch)
+        residual = lambda u: torch.mean(engine.residual_autograd(plan, u, batch.y, batch.a_ij) ** 2)
+        idx = torch.where(batch.tags.reshape(batch.tags.shape[0], -1)[:, 0] == 1)[0]
+        U = {"0": batch.x}
+        res, mse = {"0": residual(batch.x)}, {"0": self.mse_loss(batch.x, batch.sol)}
+        enc, aenc, msd = {}, {}, {}
+        H0 = ae.encoder(batch.x)
+        sc = _StepCtx(self, batch, H0)
+        named = [(n, p) for n, p in self.named_parameters()
+                 if n.startswith(("phi_to.", "phi_from.", "z_k.", "r_k.", "correction."))]
+        names, params = tuple(n for n, _ in named), [p for _, p in named]
+
+        def frozen(module, fn):
+            ps = list(module.parameters())
+            for p in ps:
+                p.requires_grad = False
+            try:
+                return fn()
+            finally:
+                for p in ps:
+                    p.requires_grad = True
+        h, total = H0, None
+        for t in range(k):
+            h = _DsgpsStepFn.apply(h, H0, sc, names, *params)
+            u = ae.decoder(h)
+            s = str(t + 1)
+            U[s] = u
+            res[s], mse[s] = residual(u), self.mse_loss(u, batch.sol)
+            enc[s] = frozen(ae.decoder, lambda: self.mse_loss(ae(h, sens="latent"), h))
+            aenc[s] = frozen(ae.encoder, lambda: self.mse_loss(ae(u, sens="physics"), u))
+            msd[s] = self.mse_loss(u[idx, :], batch.sol[idx, :])
+            term = res[s] * gamma ** (k - t - 1) + enc[s] + aenc[s]
+            total = term if total is None else total + term
+        return U, {"train_loss": total, "residual_loss": res, "encoder_loss": enc, "autoencoder_loss": aenc,
+                   "mse_dirichlet": msd, "mse_loss": mse}
+
+    def _eval_forward(self, batch):
         nat.require_cuda(batch.x, "batch.x")
         ae, k, gamma = self.autoencoder, self.config["k"], self.config["gamma"]
         plan = engine.plan_for(batch)

@@ -491,6 +491,56 @@ def dsgps_step_p(plan: "MeshPlan", wflat, hp, h0p, prbp, nrmp=None):
     return out
 
 
+_DSGPS_GRAD_NAMES = ("phi_to", "phi_from")
+
+
+def pack_dsgps_train(sd, device):
+    """(phi weights in the f_theta layout, gate weights [Wz|bz|Wr|br|Wc|bc]) for ``psignn_dsgps_step_backward``."""
+    g = lambda k: sd[k].detach().to(device, torch.float32).reshape(-1)
+    wf = torch.zeros(int(nat.lib().psignn_weights_size(0, 1)), dtype=torch.float32, device=device)
+    o = 64   # WLayout<2>: shared block, then phi_to{W1,b1,W2,b2} phi_from{...} of layer 0
+    for m in _DSGPS_GRAD_NAMES:
+        blk = torch.cat([g(f"{m}.mlp.mlp.0.weight"), g(f"{m}.mlp.mlp.0.bias"), g(f"{m}.mlp.mlp.2.weight"), g(f"{m}.mlp.mlp.2.bias")])
+        wf[o:o + blk.numel()] = blk
+        o += blk.numel()
+    wg = torch.cat([g(f"{m}.mlp.0.{p}") for m in ("z_k", "r_k", "correction") for p in ("weight", "bias")])
+    return wf, wg
+
+
+def unpack_dsgps_grads(flat):
+    """{state_dict name: gradient} from the flat buffer of ``psignn_dsgps_step_backward``."""
+    out, o = {}, 64
+    for m in _DSGPS_GRAD_NAMES:
+        for name, shape in ((f"{m}.mlp.mlp.0.weight", (D, 2 * D + 3)), (f"{m}.mlp.mlp.0.bias", (D,)),
+                            (f"{m}.mlp.mlp.2.weight", (D, D)), (f"{m}.mlp.mlp.2.bias", (D,))):
+            n = int(np.prod(shape))
+            out[name] = flat[o:o + n].reshape(shape)
+            o += n
+    o = int(nat.lib().psignn_param_grad_size(0, 1))
+    for m in ("z_k", "r_k", "correction"):
+        out[f"{m}.mlp.0.weight"] = flat[o:o + D * (3 * D + 2)].reshape(D, 3 * D + 2)
+        o += D * (3 * D + 2)
+        out[f"{m}.mlp.0.bias"] = flat[o:o + D]
+        o += D
+    return out
+
+
+def dsgps_step_backward(plan: "MeshPlan", wf, wg, h, prb, w):
+    """({name: grad}, w^T dh'/dh) of one DS-GPS update (dirichlet family, caller's numbering)."""
+    hc, wc = _f32c(h), _f32c(w)
+    l = nat.lib()
+    grad = torch.empty(int(l.psignn_dsgps_grad_size()), dtype=torch.float32, device=hc.device)
+    out = torch.empty_like(hc)
+    if getattr(plan, "_dswork", None) is None:
+        plan._dswork = torch.empty(int(l.psignn_dsgps_step_backward_workspace_floats(plan.handle)), dtype=torch.float32,
+                                   device=hc.device)
+    with torch.cuda.device(hc.device):
+        nat.check(l.psignn_dsgps_step_backward(plan.handle, nat.ptr(wf), nat.ptr(wg), nat.ptr(hc), nat.ptr(_f32c(prb)),
+                                               nat.ptr(wc), nat.ptr(grad), nat.ptr(out), nat.ptr(plan._dswork),
+                                               nat.stream_ptr(hc.device)), "psignn_dsgps_step_backward")
+    return unpack_dsgps_grads(grad), out
+
+
 def pack_dss(sd, k, device=None) -> torch.Tensor:
     """Flat per-step weight buffer of the DSS kernels from a ``DeepStatisticalSolver`` state_dict
     (dirichlet/dss/model.py:33-55; layout in csrc/dss_tile.hip)."""

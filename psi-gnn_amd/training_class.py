@@ -42,6 +42,14 @@ def allreduce_mean_grads(params, group=None):
 
 
 class TrainModel:
+    KEYS = _KEYS
+    _LINE = "\t Res : {:.4e} \t Jac : {:.4e} \t Enc : {:.4e} \t AEnc : {:.4e} \t MSE : {:.4e}"
+    _EPOCH = "\t Res : {:.5e} \t Jac : {:.5e} \t Enc : {:.5e} \t AE : {:.5e} \t MSE : {:.5e}"
+
+    @staticmethod
+    def _value(loss_dic, key):
+        return loss_dic[key].mean().item()
+
     def __init__(self, config):
         self.loader_train = config["loader_train"]
         self.loader_val = config["loader_val"]
@@ -57,8 +65,8 @@ class TrainModel:
         self.sup_weight = config.get("sup_weight", 0.0)
         self.jac_weight = config.get("jac_weight", 0.0)
         self.training_time = 0
-        self.hist_train = {k: [] for k in _KEYS}
-        self.hist_val = {k: [] for k in _KEYS}
+        self.hist_train = {k: [] for k in self.KEYS}
+        self.hist_val = {k: [] for k in self.KEYS}
         self.createOptimizerAndScheduler()
 
     @property
@@ -140,43 +148,43 @@ class TrainModel:
     def train_loop(self, current_epoch):
         self.model.train()
         n = len(self.loader_train)
-        cumul = dict.fromkeys(_KEYS, 0.0)
-        run = dict.fromkeys(_KEYS, 0.0)
+        KEYS = self.KEYS
+        cumul = dict.fromkeys(KEYS, 0.0)
+        run = dict.fromkeys(KEYS, 0.0)
         cnt = 0
         marks = {ceil(0.25 * n), ceil(0.5 * n), ceil(0.75 * n)}
         for i, batch in enumerate(self.loader_train):
             loss, loss_dic = self.train_step(batch)
-            vals = {"loss": loss.item(), **{k: loss_dic[k].mean().item() for k in _KEYS[1:]}}
-            for k in _KEYS:
+            vals = {"loss": loss.item(), **{k: self._value(loss_dic, k) for k in KEYS[1:]}}
+            for k in KEYS:
                 cumul[k] += vals[k]
                 run[k] += vals[k]
             cnt += 1
             if i in marks:
-                self._write("\nEpoch {}, {:d}% \t Loss : {:.4e} \t Res : {:.4e} \t Jac : {:.4e} \t Enc : {:.4e} \t AEnc : {:.4e} "
-                            "\t MSE : {:.4e}".format(current_epoch, int(i * 100 / n), *[run[k] / cnt for k in _KEYS]))
-                run = dict.fromkeys(_KEYS, 0.0)
+                self._write(("\nEpoch {}, {:d}% \t Loss : {:.4e} " + self._LINE).format(
+                    current_epoch, int(i * 100 / n), *[run[k] / cnt for k in KEYS]))
+                run = dict.fromkeys(KEYS, 0.0)
                 cnt = 0
-        means = self._mean_over_ranks([cumul[k] / max(n, 1) for k in _KEYS])
-        for k, v in zip(_KEYS, means):
+        means = self._mean_over_ranks([cumul[k] / max(n, 1) for k in KEYS])
+        for k, v in zip(KEYS, means):
             self.hist_train[k].append(v)
-        self._write("\nTraining Epoch {} : \t Train : {:.5e} \t Res : {:.5e} \t Jac : {:.5e} \t Enc : {:.5e} \t AE : {:.5e} "
-                    "\t MSE : {:.5e}".format(current_epoch, *means))
+        self._write(("\nTraining Epoch {} : \t Train : {:.5e} " + self._EPOCH).format(current_epoch, *means))
 
     def validation_loop(self, current_epoch):
         self.model.eval()
         n = len(self.loader_val)
-        cumul = dict.fromkeys(_KEYS, 0.0)
+        KEYS = self.KEYS
+        cumul = dict.fromkeys(KEYS, 0.0)
         with torch.no_grad():
             for batch in self.loader_val:
                 _, loss_dic = self.model(batch)
                 cumul["loss"] += self.total_loss(loss_dic).item()
-                for k in _KEYS[1:]:
-                    cumul[k] += loss_dic[k].mean().item()
-        means = self._mean_over_ranks([cumul[k] / max(n, 1) for k in _KEYS])
-        for k, v in zip(_KEYS, means):
+                for k in KEYS[1:]:
+                    cumul[k] += self._value(loss_dic, k)
+        means = self._mean_over_ranks([cumul[k] / max(n, 1) for k in KEYS])
+        for k, v in zip(KEYS, means):
             self.hist_val[k].append(v)
-        self._write("\nValidation Epoch {} : \t Train : {:.5e} \t Res : {:.5e} \t Jac : {:.5e} \t Enc : {:.5e} \t AE : {:.5e} "
-                    "\t MSE : {:.5e}".format(current_epoch, *means))
+        self._write(("\nValidation Epoch {} : \t Train : {:.5e} " + self._EPOCH).format(current_epoch, *means))
 
     def train_model(self):
         for epoch in range(self.max_epochs):
@@ -202,5 +210,73 @@ class TrainModel:
                 epoch, time.time() - t0, self.training_time))
             self._write("\nCurrent Learning rate DEQ : {}".format(self.opt_deq.param_groups[0]["lr"]))
             self._write("\nCurrent Learning rate AUTOENC : {}".format(self.opt_ae.param_groups[0]["lr"]))
+            if saved:
+                self._write("\nMODEL SAVED")
+
+
+class TrainModelDSGPS(TrainModel):
+    """``dirichlet/dsgps/training_class.py``: one Adam over all parameters (``config["lr"]``), the loss is the model's
+    ``train_loss`` (residual of every unrolled update weighted by gamma^(k-t-1), plus encoder / autoencoder terms,
+    dsgps/model.py:116-121), statistics are those of the last update ``str(k)``; no schedulers; the optimiser state is
+    checkpointed under ``opt_deq`` like the reference does."""
+    KEYS = ("loss", "residual_loss", "encoder_loss", "autoencoder_loss", "mse_loss")
+    _LINE = "\t Res : {:.4e} \t Enc : {:.4e} \t AEnc : {:.4e} \t MSE : {:.4e}"
+    _EPOCH = "\t Res : {:.5e} \t Enc : {:.5e} \t AE : {:.5e} \t MSE : {:.5e}"
+
+    def __init__(self, config):
+        cfg = dict(config)
+        self.lr = cfg["lr"]
+        for k, v in (("lr_deq", cfg["lr"]), ("lr_ae", cfg["lr"]), ("sched_step_deq", 1.0), ("sched_step_ae", 1.0)):
+            cfg.setdefault(k, v)
+        super().__init__(cfg)
+
+    def _value(self, loss_dic, key):
+        return loss_dic[key][str(self.config_model["k"])].mean().item()
+
+    def createOptimizerAndScheduler(self):
+        self.opt = torch.optim.Adam(self.net.parameters(), lr=self.lr)
+
+    def total_loss(self, loss_dic):
+        return loss_dic["train_loss"].mean()
+
+    def train_step(self, batch):
+        self.opt.zero_grad()
+        _, loss_dic = self.model(batch)
+        loss = self.total_loss(loss_dic)
+        loss.backward()
+        allreduce_mean_grads(self.net.parameters())
+        torch.nn.utils.clip_grad_norm_(self.net.parameters(), self.gradient_clip)
+        self.opt.step()
+        return loss, loss_dic
+
+    def checkpoint(self, epoch):
+        return {"epoch": epoch, "hyperparameters": self.config_model, "state_dict": self.net.state_dict(),
+                "hist_train": self.hist_train, "hist_val": self.hist_val, "opt_deq": self.opt.state_dict(),
+                "training_time": self.training_time}
+
+    def load_model(self, path):
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        self.net.load_state_dict(ck["state_dict"])
+        self.opt.load_state_dict(ck["opt_deq"])
+        self.hist_train, self.hist_val = ck["hist_train"], ck["hist_val"]
+        self.training_time = ck["training_time"]
+
+    def train_model(self):
+        for epoch in range(self.max_epochs):
+            t0 = time.time()
+            self.train_loop(epoch)
+            self.validation_loop(epoch)
+            self.training_time += time.time() - t0
+            saved = False
+            if self._rank() == 0 and self.path_ckpt:
+                ck = self.checkpoint(epoch)
+                self.save_model(ck, dirName=self.path_ckpt, model_name="running_model")
+                if self.hist_val["residual_loss"][-1] <= self.min_loss_save:
+                    self.save_model(ck, dirName=self.path_ckpt, model_name="best_model")
+                    self.min_loss_save = self.hist_val["residual_loss"][-1]
+                    saved = True
+            self._write("\nTraining Epoch {} finished, took current epoch {:.2f}s, cumulative time {:.2f}s".format(
+                epoch, time.time() - t0, self.training_time))
+            self._write("\nCurrent Learning rate : {}".format(self.opt.param_groups[0]["lr"]))
             if saved:
                 self._write("\nMODEL SAVED")
