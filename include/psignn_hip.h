@@ -200,18 +200,19 @@ int psignn_dsgps_forward(const psignn_plan_t* plan, const float* d_weights, int 
                          const float* d_normals, float* d_out, float* d_work, void* stream);
 int psignn_dsgps_step_p(const psignn_plan_t* plan, const float* d_weights, const float* d_h, const float* d_h0,
                         const float* d_prb, const float* d_normals, float* d_out, void* stream);
-/* Backward of one DS-GPS update h' = step(h) (dirichlet family, caller's numbering): what loss.backward() runs per unrolled
- * update of ModelDSGPS.forward (dirichlet/dsgps/model.py:72-89, training_class.py of that directory).  d_w: cotangent on h'.
- * d_out_h = w^T dh'/dh (the Dirichlet rows' share goes to H_0: it is d_w on those rows); d_grad:
- * psignn_dsgps_grad_size() floats = the f_theta gradient layout (phi_to / phi_from slots, psignn_param_grad_size(0, 1))
- * followed by [Wz (10x32) | bz | Wr | br | Wc | bc].  d_phi_weights: the two Phi modules in the f_theta weight layout
- * (psignn_weights_size(0, 1) floats; only the phi_to / phi_from blocks of layer 0 are read); d_gate_weights:
- * [Wz | bz | Wr | br | Wc | bc] as nn.Linear stores them.  d_work: psignn_dsgps_step_backward_workspace_floats(plan). */
-int64_t psignn_dsgps_grad_size(void);
+/* Backward of one DS-GPS update h' = step(h) (both families, caller's numbering): what loss.backward() runs per unrolled
+ * update of ModelDSGPS.forward (dirichlet/dsgps/model.py:72-89, mixed/dsgps/model.py:72-93; training_class.py of those
+ * directories).  d_w: cotangent on h'.  d_out_h = w^T dh'/dh (the Dirichlet rows' share goes to H_0: it is d_w on those
+ * rows); d_grad: psignn_dsgps_grad_size(mixed) floats = the f_theta gradient layout (phi_to / phi_from slots, mixed: also
+ * phi_neumann | update_neumann; psignn_param_grad_size(mixed, 1)) followed by [Wz (10 x (30+P)) | bz | Wr | br | Wc | bc].
+ * d_phi_weights: those modules in the f_theta weight layout (psignn_weights_size(mixed, 1) floats; only their blocks are
+ * read); d_gate_weights: [Wz | bz | Wr | br | Wc | bc] as nn.Linear stores them.  d_normals: mixed plans.
+ * d_work: psignn_dsgps_step_backward_workspace_floats(plan). */
+int64_t psignn_dsgps_grad_size(int mixed);
 int64_t psignn_dsgps_step_backward_workspace_floats(const psignn_plan_t* plan);
 int psignn_dsgps_step_backward(const psignn_plan_t* plan, const float* d_phi_weights, const float* d_gate_weights,
-                               const float* d_h, const float* d_prb, const float* d_w, float* d_grad, float* d_out_h,
-                               float* d_work, void* stream);
+                               const float* d_h, const float* d_prb, const float* d_normals, const float* d_w, float* d_grad,
+                               float* d_out_h, float* d_work, void* stream);
 
 /* DSS, the Deep Statistical Solver baseline (dirichlet/dss/model.py:97-120): k updates with per-step weights
  *   h <- h + alpha * Psi_t([h | Phi_to_t(h) | Phi_from_t(h) | b'_norm]),  H_0 = 0,

@@ -510,20 +510,27 @@ def dsgps_inference(sd, batch, k, trace=False):
 def dsgps_training_step(sd, batch, k, gamma):
     """``ModelDSGPS.forward`` in train mode + ``loss.backward()`` on ``train_loss`` (dirichlet/dsgps/model.py:48-128,
     training_class.py:141-146): residual of every decoded iterate weighted gamma^(k-t-1), the encoder term with the
-    decoder's parameters frozen (:100-105), the autoencoder term with the encoder's frozen (:107-112).  Plain autograd
+    decoder's parameters frozen (:100-105), the autoencoder term with the encoder's frozen (:107-112); the mixed family
+    (mixed/dsgps/model.py:100-107) uses detached iterates for those two terms instead.  Plain autograd
     through the k restated updates.  Returns (train_loss, {name: grad}, last residual / mse)."""
     p = {n: (t.detach().clone().requires_grad_(True) if torch.is_tensor(t) and t.is_floating_point() and t.dim() > 0 else t)
          for n, t in sd.items()}
     froz = lambda prefix: {n: (t.detach() if n.startswith(prefix) else t) for n, t in p.items()}
     p_dec_frozen, p_enc_frozen = froz("autoencoder.decoder."), froz("autoencoder.encoder.")
+    mixed = "phi_neumann.mlp.mlp.0.weight" in sd
     H0 = encoder(p, batch.x)
     h, total = H0, None
     for t in range(k):
         h = dsgps_step(p, h, H0, batch)
         u = decoder(p, h)
         res = residual_loss(u, batch)
-        enc = F.mse_loss(encoder(p, decoder(p_dec_frozen, h)), h)
-        aenc = F.mse_loss(decoder(p, encoder(p_enc_frozen, u)), u)
+        if mixed:   # mixed/dsgps/model.py:100-107
+            u_d, h_d = u.detach(), h.detach()
+            enc = F.mse_loss(encoder(p, u_d), h_d)
+            aenc = F.mse_loss(decoder(p, encoder(p, u_d).detach()), u_d)
+        else:
+            enc = F.mse_loss(encoder(p, decoder(p_dec_frozen, h)), h)
+            aenc = F.mse_loss(decoder(p, encoder(p_enc_frozen, u)), u)
         term = res * gamma ** (k - t - 1) + enc + aenc
         total = term if total is None else total + term
     total.backward()

@@ -67,9 +67,9 @@ SIGNATURES = {
     "psignn_dsgps_weights_size": (_I64, [_INT]),
     "psignn_dsgps_forward": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P]),
     "psignn_dsgps_step_p": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P]),
-    "psignn_dsgps_grad_size": (_I64, []),
+    "psignn_dsgps_grad_size": (_I64, [_INT]),
     "psignn_dsgps_step_backward_workspace_floats": (_I64, [_P]),
-    "psignn_dsgps_step_backward": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "psignn_dsgps_step_backward": (_INT, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "psignn_dss_weights_size": (_I64, [_INT]),
     "psignn_dss_forward": (_INT, [_P, _P, _INT, C.c_float, _P, _P, _P, _P]),
     "psignn_dss_step_p": (_INT, [_P, _P, _INT, C.c_float, _P, _P, _P, _P]),

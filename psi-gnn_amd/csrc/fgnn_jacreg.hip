@@ -750,26 +750,35 @@ int psignn_jacreg_records(const psignn_plan* p, const float* W, const float* h, 
 // f_theta, then  z = sigma(Wz c + bz), r = sigma(Wr c + br), corr = tanh(Wc [r h, mp_to, mp_fr, prb] + bc),
 // h' = h + z corr, Dirichlet rows <- H_0.  The node kernel turns the cotangent w on h' into the cotangent on
 // c = [h, mp_to, mp_fr] and the gate factors; the edge-level backward is the injected-cotangent pair above.  The Phi
-// weights come in the f_theta layout (WLayout<2>: phi_to / phi_from blocks of layer 0), the gates as
-// Wg = [Wz (10x32) | bz | Wr | br | Wc | bc] (nn.Linear layout).  Record groups (320 floats, reduced with TabG in
+// weights come in the f_theta layout (WLayout<P>: phi_to / phi_from blocks of layer 0; mixed family: also phi_neumann and
+// update_neumann -- a Neumann row is replaced by update_neumann([h, Phi_neumann(h), prb, normal]), mixed/dsgps/model.py:79-93),
+// the gates as Wg = [Wz (10 x (30+P)) | bz | Wr | br | Wc | bc] (nn.Linear layout).  Record groups (320 floats, reduced with TabG in
 // fgnn_pgrad.hip): 0 x|1, 1 mp_to|prb, 2 mp_fr, 3 S_to|deg, 4 S_fr|deg, 5 r h|1, 6 d pre_z, 7 gt, 8 gf, 9 d mp_to,
 // 10 d mp_fr, 11 d pre_r, 12 acc_t, 13 acc_f, 14 d pre_c, 16..19 dS (.) attr.
 // ---------------------------------------------------------------------------------------------------------------------
+template <int P, bool MIXED>
 __global__ __launch_bounds__(256) void k_ds_phi(int64_t N, const float* __restrict__ W, const int32_t* __restrict__ csr_ptr,
                                                 const int32_t* __restrict__ csr_nbr, const float* __restrict__ csr_attr,
                                                 const int32_t* __restrict__ csc_ptr, const int32_t* __restrict__ csc_nbr,
                                                 const float* __restrict__ csc_attr, const uint8_t* __restrict__ flags,
                                                 const float* __restrict__ h, const float* __restrict__ Pb,
                                                 float* __restrict__ cb, float* __restrict__ rec) {
-  using L = WLayout<2>;
-  using J = JrDims<false>;
+  using L = WLayout<P>;
+  using J = JrDims<MIXED>;
   int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  if (flags[n] & FLAG_DIRICHLET) return;
+  const uint8_t fl = flags[n];
+  if (fl & FLAG_DIRICHLET) return;
   float x[D], S[D], T[D], mp[D], tt[D];
   load10(h + n * D, x);
   float* c = cb + n * 4 * D;
   float* r = rec + n * J::REC;
+  if (MIXED && (fl & FLAG_NEUMANN)) {
+    jr_phi_tangent<J::PJ>(W + L::phi_neu(1), x, x, csr_nbr, csr_attr, csr_ptr[n], csr_ptr[n + 1], Pb, 2 * D, J::NP * D + 2 * D, S, T, mp, tt);
+    store10(c, mp);
+    jr_group(r + 21 * 16, S, D, (float)(csr_ptr[n + 1] - csr_ptr[n]));
+    return;
+  }
   jr_phi_tangent<J::PJ>(W + L::layer(0) + L::L_TO, x, x, csc_nbr, csc_attr, csc_ptr[n], csc_ptr[n + 1], Pb, 0, J::NP * D, S, T, mp, tt);
   store10(c, mp);
   jr_group(r + 3 * 16, S, D, (float)(csc_ptr[n + 1] - csc_ptr[n]));
@@ -779,10 +788,11 @@ __global__ __launch_bounds__(256) void k_ds_phi(int64_t N, const float* __restri
   jr_group(r + 4 * 16, S, D, (float)(csr_ptr[n + 1] - csr_ptr[n]));
 }
 
-// gate pre-activation  out[o] = b[o] + W[o, 0:10] . a + W[o, 10:20] . mt + W[o, 20:30] . mf + W[o, 30:32] . pq
+// gate pre-activation  out[o] = b[o] + W[o, 0:10] . a + W[o, 10:20] . mt + W[o, 20:30] . mf + W[o, 30:30+P] . pq
+template <int P>
 __device__ __forceinline__ void ds_gate(const float* __restrict__ Wm, const float* a, const float* mt, const float* mf,
                                         const float* pq, float* out) {
-  constexpr int CAT = 3 * D + 2;
+  constexpr int CAT = 3 * D + P;
 #pragma unroll
   for (int o = 0; o < D; ++o) out[o] = Wm[D * CAT + o];
   PHASE();
@@ -792,45 +802,88 @@ __device__ __forceinline__ void ds_gate(const float* __restrict__ Wm, const floa
   PHASE();
   matvec10<D, true>(Wm, CAT, 2 * D, mf, out);
   PHASE();
-  matvec10<2, true>(Wm, CAT, 3 * D, pq, out);
+  matvec10<P, true>(Wm, CAT, 3 * D, pq, out);
 }
 
-__global__ __launch_bounds__(256) void k_ds_node_bwd(int64_t N, const float* __restrict__ Wg, const uint8_t* __restrict__ flags,
-                                                     const float* __restrict__ h, const float* __restrict__ prb,
+// Wf: the Phi modules (and, mixed, update_neumann) in the f_theta layout; Wg: the gates
+template <int P, bool MIXED>
+__global__ __launch_bounds__(256) void k_ds_node_bwd(int64_t N, const float* __restrict__ Wf, const float* __restrict__ Wg,
+                                                     const uint8_t* __restrict__ flags, const float* __restrict__ h,
+                                                     const float* __restrict__ prb, const float* __restrict__ nrm,
                                                      const float* __restrict__ wv, const float* __restrict__ cb,
                                                      float* __restrict__ dir, float* __restrict__ rec) {
-  using J = JrDims<false>;
-  constexpr int CAT = 3 * D + 2, GSZ = D * CAT + D;
+  using L = WLayout<P>;
+  using J = JrDims<MIXED>;
+  constexpr int NG = J::REC / 16;
+  constexpr int CAT = 3 * D + P, GSZ = D * CAT + D;
   int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float* r = rec + n * J::REC;
+  const uint8_t fl = flags[n];
   float x[D];
   load10(h + n * D, x);
   jr_group(r, x, D, 1.f);
-  if (flags[n] & FLAG_DIRICHLET) {  // the row is a copy of H_0: its cotangent goes there (host side), nothing flows through
+  if (fl & FLAG_DIRICHLET) {  // the row is a copy of H_0: its cotangent goes there (host side), nothing flows through
     float zero[D];
 #pragma unroll
     for (int o = 0; o < D; ++o) zero[o] = 0.f;
     store10(dir + n * D, zero);
     jr_zero(r, 1, 12);
+    jr_zero(r, 14, MIXED ? 27 : NG);
+    if (MIXED) jr_zero(r, 28, NG);
+    return;
+  }
+  float w[D], pq[P + 2];
+  load10(wv + n * D, w);
+#pragma unroll
+  for (int k = 0; k < P; ++k) pq[k] = prb[n * P + k];
+  pq[P] = pq[P + 1] = 0.f;
+  if (MIXED && (fl & FLAG_NEUMANN)) {  // h' = N2 relu(N1 [h, mp_n, prb, normal] + nb1) + nb2 (the row is replaced)
+    const float* Un = Wf + L::upd_neu(1);
+    float mpn[D], q[D], hid[D], dq[D], g[D], dm[D];
+    load10(cb + n * 4 * D, mpn);
+    pq[P] = nrm[n * 2];
+    pq[P + 1] = nrm[n * 2 + 1];
+#pragma unroll
+    for (int o = 0; o < D; ++o) q[o] = Un[L::NEU_B1 + o];
+    PHASE();
+    matvec10<D, true>(Un + L::NEU_W1, L::NEU_CAT, 0, x, q);
+    PHASE();
+    matvec10<D, true>(Un + L::NEU_W1, L::NEU_CAT, D, mpn, q);
+    PHASE();
+    matvec10<P + 2, true>(Un + L::NEU_W1, L::NEU_CAT, 2 * D, pq, q);
+#pragma unroll
+    for (int o = 0; o < D; ++o) hid[o] = fmaxf(q[o], 0.f);
+    PHASE();
+    jr_matvecT<D, false>(Un + L::NEU_W2, D, 0, w, dq);
+#pragma unroll
+    for (int o = 0; o < D; ++o) dq[o] = q[o] > 0.f ? dq[o] : 0.f;
+    PHASE();
+    jr_matvecT<D, false>(Un + L::NEU_W1, L::NEU_CAT, 0, dq, g);
+    PHASE();
+    jr_matvecT<D, false>(Un + L::NEU_W1, L::NEU_CAT, D, dq, dm);
+    store10(dir + n * D, g);
+    jr_zero(r, 1, 12);
     jr_zero(r, 14, 20);
+    jr_group(r + 20 * 16, mpn, D, pq[0], pq[1], pq[2], pq[3], pq[P + 1]);
+    jr_group(r + 22 * 16, hid, D, 1.f);
+    jr_group(r + 23 * 16, dq, D);
+    jr_group(r + 25 * 16, dm, D);
+    jr_group(r + 26 * 16, w, D);
     return;
   }
   const float* Wz = Wg;
   const float* Wr = Wg + GSZ;
   const float* Wc = Wg + 2 * GSZ;
-  float mt[D], mf[D], w[D], pq[2];
+  float mt[D], mf[D];
   load10(cb + n * 4 * D, mt);
   load10(cb + n * 4 * D + D, mf);
-  load10(wv + n * D, w);
-  pq[0] = prb[n * 2];
-  pq[1] = prb[n * 2 + 1];
-  jr_group(r + 16, mt, D, pq[0], pq[1]);
+  jr_group(r + 16, mt, D, pq[0], pq[1], P > 2 ? pq[P - 1] : 0.f);
   jr_group(r + 2 * 16, mf, D);
   float z[D], rr[D], rx[D], co[D];
-  ds_gate(Wz, x, mt, mf, pq, z);
+  ds_gate<P>(Wz, x, mt, mf, pq, z);
   PHASE();
-  ds_gate(Wr, x, mt, mf, pq, rr);
+  ds_gate<P>(Wr, x, mt, mf, pq, rr);
 #pragma unroll
   for (int o = 0; o < D; ++o) {
     z[o] = 1.f / (1.f + expf(-z[o]));
@@ -838,7 +891,7 @@ __global__ __launch_bounds__(256) void k_ds_node_bwd(int64_t N, const float* __r
     rx[o] = rr[o] * x[o];
   }
   PHASE();
-  ds_gate(Wc, rx, mt, mf, pq, co);
+  ds_gate<P>(Wc, rx, mt, mf, pq, co);
   jr_group(r + 5 * 16, rx, D, 1.f);
   float dpc[D], dpz[D], dpr[D], dx[D], dmt[D], dmf[D], t[D];
 #pragma unroll
@@ -877,12 +930,16 @@ __global__ __launch_bounds__(256) void k_ds_node_bwd(int64_t N, const float* __r
   jr_group(r + 10 * 16, dmf, D);
   jr_group(r + 11 * 16, dpr, D);
   jr_zero(r, 15, 16);
+  if (MIXED) {
+    jr_zero(r, 20, 27);
+    jr_zero(r, 28, NG);
+  }
 }
 
-// work: P (N, 40) | cb (N, 40) | B (N, 40) | dir (N, 10);  rec: (N, 320);  out_h: (N, 10) = w^T d step / d h
-int psignn_dsgps_step_records(const psignn_plan* p, const float* Wf, const float* Wg, const float* h, const float* prb,
-                              const float* w, float* out_h, float* work, float* rec, hipStream_t st) {
-  using J = JrDims<false>;
+template <int P, bool MIXED>
+static void ds_launch(const psignn_plan* p, const float* Wf, const float* Wg, const float* h, const float* prb, const float* nrm,
+                      const float* w, float* out_h, float* work, float* rec, hipStream_t st) {
+  using J = JrDims<MIXED>;
   const int64_t N = p->N;
   const unsigned grid = (unsigned)cdiv(N, 256);
   float* Pb = work;
@@ -890,12 +947,21 @@ int psignn_dsgps_step_records(const psignn_plan* p, const float* Wf, const float
   float* B = cb + N * 4 * D;
   float* dir = B + N * J::NB * D;
 #define JR_CSR p->csr_ptr, p->csr_nbr, p->csr_attr, p->csc_ptr, p->csc_nbr, p->csc_attr
-  LAUNCH("k_jr_project", st, (k_jr_project<2, false><<<grid, 256, 0, st>>>(N, Wf, h, h, Pb)));
-  LAUNCH("k_ds_phi", st, (k_ds_phi<<<grid, 256, 0, st>>>(N, Wf, JR_CSR, p->flags, h, Pb, cb, rec)));
-  LAUNCH("k_ds_node_bwd", st, (k_ds_node_bwd<<<grid, 256, 0, st>>>(N, Wg, p->flags, h, prb, w, cb, dir, rec)));
-  LAUNCH("k_jr_edge_local", st, (k_jr_edge_local<2, false, false><<<grid, 256, 0, st>>>(N, Wf, JR_CSR, p->flags, h, Pb, dir, B, out_h, rec)));
-  LAUNCH("k_jr_edge_remote", st, (k_jr_edge_remote<2, false, false><<<grid, 256, 0, st>>>(N, Wf, JR_CSR, Pb, B, out_h, rec)));
+  LAUNCH("k_jr_project", st, (k_jr_project<P, MIXED><<<grid, 256, 0, st>>>(N, Wf, h, h, Pb)));
+  LAUNCH("k_ds_phi", st, (k_ds_phi<P, MIXED><<<grid, 256, 0, st>>>(N, Wf, JR_CSR, p->flags, h, Pb, cb, rec)));
+  LAUNCH("k_ds_node_bwd", st, (k_ds_node_bwd<P, MIXED><<<grid, 256, 0, st>>>(N, Wf, Wg, p->flags, h, prb, nrm, w, cb, dir, rec)));
+  LAUNCH("k_jr_edge_local", st, (k_jr_edge_local<P, MIXED, false><<<grid, 256, 0, st>>>(N, Wf, JR_CSR, p->flags, h, Pb, dir, B, out_h, rec)));
+  LAUNCH("k_jr_edge_remote", st, (k_jr_edge_remote<P, MIXED, false><<<grid, 256, 0, st>>>(N, Wf, JR_CSR, Pb, B, out_h, rec)));
 #undef JR_CSR
+}
+
+// work: P (N, 40 | 60) | cb (N, 40) | B (N, 40 | 60) | dir (N, 10);  rec: (N, 320 | 480);  out_h: (N, 10) = w^T d step / d h
+int psignn_dsgps_step_records(const psignn_plan* p, const float* Wf, const float* Wg, const float* h, const float* prb,
+                              const float* nrm, const float* w, float* out_h, float* work, float* rec, hipStream_t st) {
+  if (p->mixed)
+    ds_launch<3, true>(p, Wf, Wg, h, prb, nrm, w, out_h, work, rec, st);
+  else
+    ds_launch<2, false>(p, Wf, Wg, h, prb, nrm, w, out_h, work, rec, st);
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }

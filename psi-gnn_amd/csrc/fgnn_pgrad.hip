@@ -309,12 +309,24 @@ struct TabG {  // groups: see fgnn_jacreg.hip
     return tab[t];
   }
 };
-// gradient layout: the f_theta base layout (phi_to / phi_from slots of layer 0) followed by the gates
-// [Wz (10x32) | bz | Wr | br | Wc | bc]
+struct TabGX {  // mixed family: TabG + the Neumann tiles of TabX (groups 20..29)
+  static constexpr int NG = 30, NT = 27;
+  __host__ __device__ static constexpr int a(int t) {
+    constexpr int tab[NT] = {6, 6, 6, 7, 8, 9, 10, 11, 12, 13, 11, 11, -1, -1, -1, -1, 14, 14, 14, 23, 23, 24, 25, 26, 27, -1, -1};
+    return tab[t];
+  }
+  __host__ __device__ static constexpr int b(int t) {
+    constexpr int tab[NT] = {0, 1, 2, 0, 0, 3, 4, 0, 0, 0, 1, 2, 16, 17, 18, 19, 5, 1, 2, 0, 20, 0, 21, 22, 0, 28, 29};
+    return tab[t];
+  }
+};
+// gradient layout: the f_theta base layout (Phi slots of layer 0; mixed: phi_neumann | update_neumann too) followed by the
+// gates [Wz (10 x (30+P)) | bz | Wr | br | Wc | bc]
+template <int P>
 struct MapG {
   __device__ int operator()(int t, int i, int j) const {
-    constexpr int CAT = 3 * D + 2, GSZ = D * CAT + D;
-    constexpr int G0 = WLayout<2>::base_total(1, false);
+    constexpr int CAT = 3 * D + P, GSZ = D * CAT + D;
+    constexpr int G0 = WLayout<P>::base_total(1, P == 3);
     int gate = -1, blk = 0;
     switch (t) {
       case 0: gate = 0; blk = 0; break;
@@ -326,46 +338,54 @@ struct MapG {
       case 16: gate = 2; blk = 0; break;
       case 17: gate = 2; blk = 1; break;
       case 18: gate = 2; blk = 2; break;
-      default: return pg_offset<2>(t, i, j);   // tiles 3..6, 8, 9, 12..15 coincide with TabF's Phi tiles
+      default: return pg_offset<P>(t < 19 ? t : t - 3, i, j);   // Phi tiles as in TabF; 19..26 = TabX's Neumann tiles 16..23
     }
     if (i >= D) return -1;
     const int base = G0 + gate * GSZ;
     if (blk == 0) return j < D ? base + i * CAT + j : (j == D ? base + D * CAT + i : -1);
-    if (blk == 1) return j < D ? base + i * CAT + D + j : (j < D + 2 ? base + i * CAT + 3 * D + (j - D) : -1);
+    if (blk == 1) return j < D ? base + i * CAT + D + j : (j < D + P ? base + i * CAT + 3 * D + (j - D) : -1);
     return j < D ? base + i * CAT + 2 * D + j : -1;
   }
 };
 
 int psignn_dsgps_step_records(const psignn_plan* p, const float* Wf, const float* Wg, const float* h, const float* prb,
-                              const float* w, float* out_h, float* work, float* rec, hipStream_t st);
+                              const float* nrm, const float* w, float* out_h, float* work, float* rec, hipStream_t st);
 
-extern "C" int64_t psignn_dsgps_grad_size() { return WLayout<2>::base_total(1, false) + 3 * (D * (3 * D + 2) + D); }
+extern "C" int64_t psignn_dsgps_grad_size(int mixed) {
+  return mixed ? WLayout<3>::base_total(1, true) + 3 * (D * (3 * D + 3) + D) : WLayout<2>::base_total(1, false) + 3 * (D * (3 * D + 2) + D);
+}
 extern "C" int64_t psignn_dsgps_step_backward_workspace_floats(const psignn_plan_t* p) {
   if (!p) return 0;
   int npw;
   const int nblk = pgrad_blocks(p->N, &npw);
-  return p->N * (13 * D + PGREC) + (int64_t)nblk * 4 * TabG::NT * 256;
+  return p->N * (17 * D + TabGX::NG * 16) + (int64_t)nblk * 4 * TabGX::NT * 256;
 }
 
 // w^T (d h' / d theta) -> d_grad (psignn_dsgps_grad_size floats) and w^T (d h' / d h) -> d_out_h for one DS-GPS update
-// h' = step(h) of the dirichlet family (caller's numbering).  d_phi_weights: the Phi modules in the f_theta weight layout
-// (psignn_weights_size(0, 1) floats, only the phi_to / phi_from blocks are read); d_gate_weights: [Wz|bz|Wr|br|Wc|bc].
+// h' = step(h) (caller's numbering).  d_phi_weights: the Phi modules (mixed: and update_neumann) in the f_theta weight
+// layout (psignn_weights_size(mixed, 1) floats); d_gate_weights: [Wz|bz|Wr|br|Wc|bc].
 extern "C" int psignn_dsgps_step_backward(const psignn_plan_t* p, const float* d_phi_weights, const float* d_gate_weights,
-                                          const float* h, const float* prb, const float* w, float* d_grad, float* d_out_h,
-                                          float* work, void* stream) {
+                                          const float* h, const float* prb, const float* nrm, const float* w, float* d_grad,
+                                          float* d_out_h, float* work, void* stream) {
   ARG_CHECK(p && d_phi_weights && d_gate_weights && h && prb && w && d_grad && d_out_h && work, "NULL argument");
-  ARG_CHECK(!p->mixed, "the DS-GPS backward is implemented for the dirichlet family");
+  ARG_CHECK(!p->mixed || nrm, "mixed plan needs unit normals");
   hipStream_t st = (hipStream_t)stream;
   const int64_t N = p->N;
-  float* rec = work + N * 13 * D;
-  float* part = rec + N * PGREC;
+  float* rec = work + N * 17 * D;
   int npw;
   const int nblk = pgrad_blocks(N, &npw);
-  int rc = psignn_dsgps_step_records(p, d_phi_weights, d_gate_weights, h, prb, w, d_out_h, work, rec, st);
+  int rc = psignn_dsgps_step_records(p, d_phi_weights, d_gate_weights, h, prb, nrm, w, d_out_h, work, rec, st);
   if (rc) return rc;
-  HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)psignn_dsgps_grad_size() * 4, st));
-  LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabG><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
-  LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabG::NT, 256, 0, st>>>(nblk * 4, TabG::NT, part, d_grad, MapG())));
+  HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)psignn_dsgps_grad_size(p->mixed) * 4, st));
+  if (p->mixed) {
+    float* part = rec + N * TabGX::NG * 16;
+    LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabGX><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
+    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabGX::NT, 256, 0, st>>>(nblk * 4, TabGX::NT, part, d_grad, MapG<3>())));
+  } else {
+    float* part = rec + N * TabG::NG * 16;
+    LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabG><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
+    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabG::NT, 256, 0, st>>>(nblk * 4, TabG::NT, part, d_grad, MapG<2>())));
+  }
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }

@@ -7,7 +7,7 @@ unchanged -- and the reference's two entry points:
 * ``inference(batch) -> U_k``                                   (model.py:130-163)
 * ``forward(batch) -> (U, loss_dic)``: every decoded iterate ``U['0'..'k']`` and the per-step loss dictionaries
   (``residual_loss, encoder_loss, autoencoder_loss, mse_dirichlet, mse_loss`` keyed '0'..'k', ``train_loss``)
-  (model.py:48-128).  In train mode (dirichlet family) ``train_loss`` carries its gradients: back-propagation through
+  (model.py:48-128).  In train mode ``train_loss`` carries its gradients (both families): back-propagation through
   the k unrolled updates runs on ``psignn_dsgps_step_backward`` (``training_class.TrainModelDSGPS`` is the trainer of
   dirichlet/dsgps/training_class.py); in eval mode / under ``no_grad`` the same dictionaries come as diagnostics.
 
@@ -34,7 +34,10 @@ class _StepCtx:
         self.prb = batch.prb_data
         self.prbp = self.plan.permute(batch.prb_data, True)
         self.h0p = self.plan.permute(H0.detach(), True)
-        self.dirichlet = batch.tags.reshape(batch.tags.shape[0], -1)[:, :1] == 1
+        self.nrm = batch.unit_normal_vector if net.mixed else None
+        self.nrmp = self.plan.permute(self.nrm, True) if net.mixed else None
+        col = 1 if net.mixed else 0   # mixed: one-hot [interior, dirichlet, neumann]
+        self.dirichlet = batch.tags.reshape(batch.tags.shape[0], -1)[:, col:col + 1] == 1
 
 
 class _DsgpsStepFn(torch.autograd.Function):
@@ -45,7 +48,7 @@ class _DsgpsStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, h0, sc, names, *params):
         hp = sc.plan.permute(h.detach(), True)
-        out = sc.plan.permute(engine.dsgps_step_p(sc.plan, sc.w, hp, sc.h0p, sc.prbp, None), False)
+        out = sc.plan.permute(engine.dsgps_step_p(sc.plan, sc.w, hp, sc.h0p, sc.prbp, sc.nrmp), False)
         ctx.sc, ctx.names = sc, names
         ctx.save_for_backward(h.detach())
         return out
@@ -55,7 +58,7 @@ class _DsgpsStepFn(torch.autograd.Function):
         (h,) = ctx.saved_tensors
         sc = ctx.sc
         w = w.contiguous()
-        grads, dh = engine.dsgps_step_backward(sc.plan, sc.wf, sc.wg, h, sc.prb, w)
+        grads, dh = engine.dsgps_step_backward(sc.plan, sc.wf, sc.wg, h, sc.prb, w, sc.nrm)
         g0 = torch.where(sc.dirichlet, w, torch.zeros_like(w))
         return (dh, g0, None, None) + tuple(grads[n] for n in ctx.names)
 
@@ -124,19 +127,17 @@ class ModelDSGPS(nn.Module):
         reference -- the residual of each decoded iterate through the decoder and the unrolled updates (BPTT), the
         encoder term with the decoder's parameters frozen, the autoencoder term with the encoder's frozen (:100-112)."""
         nat.require_cuda(batch.x, "batch.x")
-        if self.mixed:
-            raise nat.NativeError("training DS-GPS is implemented for the dirichlet family")
         ae, k, gamma = self.autoencoder, self.config["k"], self.config["gamma"]
         plan = engine.plan_for(batch)
         residual = lambda u: torch.mean(engine.residual_autograd(plan, u, batch.y, batch.a_ij) ** 2)
-        idx = torch.where(batch.tags.reshape(batch.tags.shape[0], -1)[:, 0] == 1)[0]
+        idx = torch.where(batch.tags.reshape(batch.tags.shape[0], -1)[:, 1 if self.mixed else 0] == 1)[0]
         U = {"0": batch.x}
         res, mse = {"0": residual(batch.x)}, {"0": self.mse_loss(batch.x, batch.sol)}
         enc, aenc, msd = {}, {}, {}
         H0 = ae.encoder(batch.x)
         sc = _StepCtx(self, batch, H0)
         named = [(n, p) for n, p in self.named_parameters()
-                 if n.startswith(("phi_to.", "phi_from.", "z_k.", "r_k.", "correction."))]
+                 if n.startswith(("phi_to.", "phi_from.", "z_k.", "r_k.", "correction.", "phi_neumann.", "update_neumann."))]
         names, params = tuple(n for n, _ in named), [p for _, p in named]
 
         def frozen(module, fn):
@@ -155,8 +156,13 @@ class ModelDSGPS(nn.Module):
             s = str(t + 1)
             U[s] = u
             res[s], mse[s] = residual(u), self.mse_loss(u, batch.sol)
-            enc[s] = frozen(ae.decoder, lambda: self.mse_loss(ae(h, sens="latent"), h))
-            aenc[s] = frozen(ae.encoder, lambda: self.mse_loss(ae(u, sens="physics"), u))
+            if self.mixed:   # mixed/dsgps/model.py:100-107: detached iterates instead of frozen halves
+                u_d, h_d = u.detach(), h.detach()
+                enc[s] = self.mse_loss(ae.encoder(u_d), h_d)
+                aenc[s] = self.mse_loss(ae.decoder(ae.encoder(u_d).detach()), u_d)
+            else:
+                enc[s] = frozen(ae.decoder, lambda: self.mse_loss(ae(h, sens="latent"), h))
+                aenc[s] = frozen(ae.encoder, lambda: self.mse_loss(ae(u, sens="physics"), u))
             msd[s] = self.mse_loss(u[idx, :], batch.sol[idx, :])
             term = res[s] * gamma ** (k - t - 1) + enc[s] + aenc[s]
             total = term if total is None else total + term

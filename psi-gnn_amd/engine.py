@@ -491,54 +491,64 @@ def dsgps_step_p(plan: "MeshPlan", wflat, hp, h0p, prbp, nrmp=None):
     return out
 
 
-_DSGPS_GRAD_NAMES = ("phi_to", "phi_from")
-
-
 def pack_dsgps_train(sd, device):
-    """(phi weights in the f_theta layout, gate weights [Wz|bz|Wr|br|Wc|bc]) for ``psignn_dsgps_step_backward``."""
+    """(Phi modules -- mixed: and update_neumann -- in the f_theta weight layout, gates [Wz|bz|Wr|br|Wc|bc]) for
+    ``psignn_dsgps_step_backward``.  The f_theta layout is produced by ``pack_weights`` from a state dict that carries the
+    DS-GPS modules under the f_theta names (the remaining f_theta blocks are zero and never read)."""
+    mixed = "phi_neumann.mlp.mlp.0.weight" in sd
+    p = 3 if mixed else 2
+    F = "deqdss.f."
+    fake = {F + "laynorm.weight": torch.ones(D), F + "laynorm.bias": torch.zeros(D),
+            F + "alpha.0.weight": torch.zeros(1, 3 * D + p), F + "alpha.0.bias": torch.zeros(1),
+            F + "update_list.0.mlp.0.weight": torch.zeros(D, 3 * D + p), F + "update_list.0.mlp.0.bias": torch.zeros(D),
+            F + "update_list.0.mlp.2.weight": torch.zeros(D, D), F + "update_list.0.mlp.2.bias": torch.zeros(D)}
+    for src, dst in (("phi_to", "phi_to_list.0"), ("phi_from", "phi_from_list.0")) + ((("phi_neumann", "phi_neumann"),) if mixed else ()):
+        for k in ("mlp.mlp.0.weight", "mlp.mlp.0.bias", "mlp.mlp.2.weight", "mlp.mlp.2.bias"):
+            fake[f"{F}{dst}.{k}"] = sd[f"{src}.{k}"]
+    if mixed:
+        for k in ("mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias"):
+            fake[f"{F}update_neumann.{k}"] = sd[f"update_neumann.{k}"]
+    wf = pack_weights(fake, device)
     g = lambda k: sd[k].detach().to(device, torch.float32).reshape(-1)
-    wf = torch.zeros(int(nat.lib().psignn_weights_size(0, 1)), dtype=torch.float32, device=device)
-    o = 64   # WLayout<2>: shared block, then phi_to{W1,b1,W2,b2} phi_from{...} of layer 0
-    for m in _DSGPS_GRAD_NAMES:
-        blk = torch.cat([g(f"{m}.mlp.mlp.0.weight"), g(f"{m}.mlp.mlp.0.bias"), g(f"{m}.mlp.mlp.2.weight"), g(f"{m}.mlp.mlp.2.bias")])
-        wf[o:o + blk.numel()] = blk
-        o += blk.numel()
-    wg = torch.cat([g(f"{m}.mlp.0.{p}") for m in ("z_k", "r_k", "correction") for p in ("weight", "bias")])
+    wg = torch.cat([g(f"{m}.mlp.0.{q}") for m in ("z_k", "r_k", "correction") for q in ("weight", "bias")])
     return wf, wg
 
 
-def unpack_dsgps_grads(flat):
+def unpack_dsgps_grads(flat, mixed):
     """{state_dict name: gradient} from the flat buffer of ``psignn_dsgps_step_backward``."""
-    out, o = {}, 64
-    for m in _DSGPS_GRAD_NAMES:
-        for name, shape in ((f"{m}.mlp.mlp.0.weight", (D, 2 * D + 3)), (f"{m}.mlp.mlp.0.bias", (D,)),
-                            (f"{m}.mlp.mlp.2.weight", (D, D)), (f"{m}.mlp.mlp.2.bias", (D,))):
-            n = int(np.prod(shape))
-            out[name] = flat[o:o + n].reshape(shape)
-            o += n
-    o = int(nat.lib().psignn_param_grad_size(0, 1))
+    base = int(nat.lib().psignn_param_grad_size(int(mixed), 1))
+    out = {}
+    for k, t in unpack_param_grads(flat[:base], 1, mixed).items():
+        if k.startswith(("phi_to_list.0.", "phi_from_list.0.")):
+            out[k.replace("_list.0.", ".")] = t
+        elif k.startswith(("phi_neumann.", "update_neumann.")):
+            out[k] = t
+    cat = 3 * D + (3 if mixed else 2)
+    o = base
     for m in ("z_k", "r_k", "correction"):
-        out[f"{m}.mlp.0.weight"] = flat[o:o + D * (3 * D + 2)].reshape(D, 3 * D + 2)
-        o += D * (3 * D + 2)
+        out[f"{m}.mlp.0.weight"] = flat[o:o + D * cat].reshape(D, cat)
+        o += D * cat
         out[f"{m}.mlp.0.bias"] = flat[o:o + D]
         o += D
     return out
 
 
-def dsgps_step_backward(plan: "MeshPlan", wf, wg, h, prb, w):
-    """({name: grad}, w^T dh'/dh) of one DS-GPS update (dirichlet family, caller's numbering)."""
+def dsgps_step_backward(plan: "MeshPlan", wf, wg, h, prb, w, nrm=None):
+    """({name: grad}, w^T dh'/dh) of one DS-GPS update (caller's numbering; mixed plans need the unit normals)."""
     hc, wc = _f32c(h), _f32c(w)
     l = nat.lib()
-    grad = torch.empty(int(l.psignn_dsgps_grad_size()), dtype=torch.float32, device=hc.device)
+    mixed = nrm is not None
+    grad = torch.empty(int(l.psignn_dsgps_grad_size(int(mixed))), dtype=torch.float32, device=hc.device)
     out = torch.empty_like(hc)
     if getattr(plan, "_dswork", None) is None:
         plan._dswork = torch.empty(int(l.psignn_dsgps_step_backward_workspace_floats(plan.handle)), dtype=torch.float32,
                                    device=hc.device)
     with torch.cuda.device(hc.device):
         nat.check(l.psignn_dsgps_step_backward(plan.handle, nat.ptr(wf), nat.ptr(wg), nat.ptr(hc), nat.ptr(_f32c(prb)),
-                                               nat.ptr(wc), nat.ptr(grad), nat.ptr(out), nat.ptr(plan._dswork),
-                                               nat.stream_ptr(hc.device)), "psignn_dsgps_step_backward")
-    return unpack_dsgps_grads(grad), out
+                                               nat.ptr(None if nrm is None else _f32c(nrm)), nat.ptr(wc), nat.ptr(grad),
+                                               nat.ptr(out), nat.ptr(plan._dswork), nat.stream_ptr(hc.device)),
+                  "psignn_dsgps_step_backward")
+    return unpack_dsgps_grads(grad, mixed), out
 
 
 def pack_dss(sd, k, device=None) -> torch.Tensor:
