@@ -224,6 +224,17 @@ int psignn_dss_forward(const psignn_plan_t* plan, const float* d_weights, int k,
 /* update t alone, state and b'_norm in plan order (the per-step loop of DeepStatisticalSolver.forward, model.py:77-93) */
 int psignn_dss_step_p(const psignn_plan_t* plan, const float* d_weights, int t, float alpha, const float* d_h,
                       const float* d_bprime_norm_p, float* d_out, void* stream);
+/* Backward of one DSS update h' = h + alpha Psi_t([h | Phi_to_t(h) | Phi_from_t(h) | b'_norm]) (caller's numbering): what
+ * loss.backward() runs per update of DeepStatisticalSolver.forward (dirichlet/dss/model.py:75-83).  d_weights_t: update t's
+ * modules in the f_theta weight layout with three node inputs (psignn_weights_size(1, 1)-style layout without Neumann blocks:
+ * phi W1 padded to (10, 23) with the edge-feature weight in column 22, Psi in the update slots; engine.pack_dss_train builds
+ * it).  d_grad: psignn_dss_grad_size() floats in that layout; d_out_h = w^T dh'/dh.
+ * d_work: psignn_dss_step_backward_workspace_floats(plan). */
+int64_t psignn_dss_grad_size(void);
+int64_t psignn_dss_step_backward_workspace_floats(const psignn_plan_t* plan);
+int psignn_dss_step_backward(const psignn_plan_t* plan, const float* d_weights_t, float alpha, const float* d_h,
+                             const float* d_bprime_norm, const float* d_w, float* d_grad, float* d_out_h, float* d_work,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Small dense pieces around the solve.

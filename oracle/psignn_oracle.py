@@ -590,3 +590,22 @@ def dss_inference(sd, batch, k, alpha, trace=False):
                 res.append(float(dss_residual_loss(_mlp(sd, f"decoder_list.{t}.mlp", h), batch.edge_index, batch.a_ij, batch.b_prime)))
         u = _mlp(sd, f"decoder_list.{k - 1}.mlp", h)
     return (u, h, res) if trace else (u, h)
+
+
+def dss_training_step(sd, batch, k, alpha, gamma):
+    """``DeepStatisticalSolver.forward`` + ``loss.backward()`` on ``train_loss`` (dirichlet/dss/model.py:59-95,
+    training_class.py): sum over the updates of gamma^(k-t-1) residual(decoder_t(H_{t+1})).  Plain autograd through the
+    restated updates.  Returns (train_loss, {name: grad}, last residual)."""
+    p = {n: (t.detach().clone().requires_grad_(True) if torch.is_tensor(t) and t.is_floating_point() and t.dim() > 0 else t)
+         for n, t in sd.items()}
+    h = torch.zeros(batch.x.shape[0], p["phi_to_list.0.mlp.mlp.2.bias"].numel(), dtype=batch.x.dtype)
+    total = None
+    for t in range(k):
+        h = dss_step(p, t, h, batch, alpha)
+        res = dss_residual_loss(_mlp(p, f"decoder_list.{t}.mlp", h), batch.edge_index, batch.a_ij, batch.b_prime)
+        term = res * gamma ** (k - t - 1)
+        total = term if total is None else total + term
+    total.backward()
+    grads = {n: (t.grad if t.grad is not None else torch.zeros_like(t)) for n, t in p.items()
+             if torch.is_tensor(t) and t.requires_grad}
+    return total.detach(), grads, float(res.detach())

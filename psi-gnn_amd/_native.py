@@ -73,6 +73,9 @@ SIGNATURES = {
     "psignn_dss_weights_size": (_I64, [_INT]),
     "psignn_dss_forward": (_INT, [_P, _P, _INT, C.c_float, _P, _P, _P, _P]),
     "psignn_dss_step_p": (_INT, [_P, _P, _INT, C.c_float, _P, _P, _P, _P]),
+    "psignn_dss_grad_size": (_I64, []),
+    "psignn_dss_step_backward_workspace_floats": (_I64, [_P]),
+    "psignn_dss_step_backward": (_INT, [_P, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
     "psignn_mlp2": (_INT, [_P, _I64, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P]),
     "psignn_residual": (_INT, [_P, _P, _P, _P, _P]),
     "psignn_broyden_create": (_INT, [C.POINTER(_P), _P, _INT, _INT]),

@@ -965,3 +965,87 @@ int psignn_dsgps_step_records(const psignn_plan* p, const float* Wf, const float
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// DSS: backward of one update  h' = h + alpha Psi_t([h, Phi_to_t(h), Phi_from_t(h), b'])  (dirichlet/dss/model.py:75-83), for
+// back-propagation through the k updates of DeepStatisticalSolver.forward.  Psi_t is a two-layer MLP: the node-level part is
+// the f_theta update MLP without gate and LayerNorm, so update t's weights come in the f_theta layout with three node
+// inputs (WLayout<3>: phi_to / phi_from with the scalar edge feature in the third attr column, Psi in the update slots) and
+// the records reduce with the f_theta table.  No row is constant: the DSS plan has no Dirichlet flags.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dss_node_bwd(int64_t N, const float* __restrict__ Wf, float alpha,
+                                                      const float* __restrict__ h, const float* __restrict__ bp,
+                                                      const float* __restrict__ wv, const float* __restrict__ cb,
+                                                      float* __restrict__ dir, float* __restrict__ rec) {
+  using L = WLayout<3>;
+  using J = JrDims<false>;
+  int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float* Wu = Wf + L::layer(0) + L::L_UPD;
+  float* r = rec + n * J::REC;
+  float x[D], mt[D], mf[D], w[D], pq[3];
+  load10(h + n * D, x);
+  load10(cb + n * 4 * D, mt);
+  load10(cb + n * 4 * D + D, mf);
+  load10(wv + n * D, w);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) pq[k] = bp[n * 3 + k];
+  jr_group(r, x, D, 1.f);
+  jr_group(r + 16, mt, D, pq[0], pq[1], pq[2]);
+  jr_group(r + 2 * 16, mf, D);
+  float q[D], hid[D], du[D], dq[D], g[D], dmt[D], dmf[D];
+#pragma unroll
+  for (int o = 0; o < D; ++o) q[o] = Wu[L::UPD_B1 + o];
+  PHASE();
+  matvec10<D, true>(Wu + L::UPD_W1, L::CAT, 0, x, q);
+  PHASE();
+  matvec10<D, true>(Wu + L::UPD_W1, L::CAT, D, mt, q);
+  PHASE();
+  matvec10<D, true>(Wu + L::UPD_W1, L::CAT, 2 * D, mf, q);
+  PHASE();
+  matvec10<3, true>(Wu + L::UPD_W1, L::CAT, 3 * D, pq, q);
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    hid[o] = fmaxf(q[o], 0.f);
+    du[o] = alpha * w[o];
+    g[o] = w[o];   // residual path h' = h + ...
+  }
+  PHASE();
+  jr_matvecT<D, false>(Wu + L::UPD_W2, D, 0, du, dq);
+#pragma unroll
+  for (int o = 0; o < D; ++o) dq[o] = q[o] > 0.f ? dq[o] : 0.f;
+  PHASE();
+  jr_matvecT<D, true>(Wu + L::UPD_W1, L::CAT, 0, dq, g);
+  PHASE();
+  jr_matvecT<D, false>(Wu + L::UPD_W1, L::CAT, D, dq, dmt);
+  PHASE();
+  jr_matvecT<D, false>(Wu + L::UPD_W1, L::CAT, 2 * D, dq, dmf);
+  store10(dir + n * D, g);
+  jr_group(r + 5 * 16, hid, D, 1.f);
+  jr_group(r + 6 * 16, dq, D);
+  jr_group(r + 9 * 16, dmt, D);
+  jr_group(r + 10 * 16, dmf, D);
+  jr_group(r + 11 * 16, du, D);
+  jr_zero(r, 14, 16);
+}
+
+// work: P (N, 40) | cb (N, 40) | B (N, 40) | dir (N, 10);  rec: (N, 320);  out_h: (N, 10) = w^T d step / d h
+int psignn_dss_step_records(const psignn_plan* p, const float* Wf, float alpha, const float* h, const float* bp,
+                            const float* w, float* out_h, float* work, float* rec, hipStream_t st) {
+  using J = JrDims<false>;
+  const int64_t N = p->N;
+  const unsigned grid = (unsigned)cdiv(N, 256);
+  float* Pb = work;
+  float* cb = Pb + N * J::PJ;
+  float* B = cb + N * 4 * D;
+  float* dir = B + N * J::NB * D;
+#define JR_CSR p->csr_ptr, p->csr_nbr, p->csr_attr, p->csc_ptr, p->csc_nbr, p->csc_attr
+  LAUNCH("k_jr_project", st, (k_jr_project<3, false><<<grid, 256, 0, st>>>(N, Wf, h, h, Pb)));
+  LAUNCH("k_ds_phi", st, (k_ds_phi<3, false><<<grid, 256, 0, st>>>(N, Wf, JR_CSR, p->flags, h, Pb, cb, rec)));
+  LAUNCH("k_dss_node_bwd", st, (k_dss_node_bwd<<<grid, 256, 0, st>>>(N, Wf, alpha, h, bp, w, cb, dir, rec)));
+  LAUNCH("k_jr_edge_local", st, (k_jr_edge_local<3, false, false><<<grid, 256, 0, st>>>(N, Wf, JR_CSR, p->flags, h, Pb, dir, B, out_h, rec)));
+  LAUNCH("k_jr_edge_remote", st, (k_jr_edge_remote<3, false, false><<<grid, 256, 0, st>>>(N, Wf, JR_CSR, Pb, B, out_h, rec)));
+#undef JR_CSR
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}

@@ -390,6 +390,41 @@ extern "C" int psignn_dsgps_step_backward(const psignn_plan_t* p, const float* d
   return PSIGNN_OK;
 }
 
+// ---- DSS: backward of one update (kernels in fgnn_jacreg.hip); gradient in the f_theta layout with three node inputs
+int psignn_dss_step_records(const psignn_plan* p, const float* Wf, float alpha, const float* h, const float* bp,
+                            const float* w, float* out_h, float* work, float* rec, hipStream_t st);
+
+extern "C" int64_t psignn_dss_grad_size(void) { return WLayout<3>::base_total(1, false); }
+extern "C" int64_t psignn_dss_step_backward_workspace_floats(const psignn_plan_t* p) {
+  if (!p) return 0;
+  int npw;
+  const int nblk = pgrad_blocks(p->N, &npw);
+  return p->N * (13 * D + PGREC) + (int64_t)nblk * TabF::NT * 256;
+}
+
+// w^T (d h' / d theta_t) -> d_grad (psignn_dss_grad_size floats: shared | phi_to{W1 (10x23: columns 20, 21 unused, 22 = the
+// edge feature), b1, W2, b2} | phi_from | psi{W1 (10x33), b1, W2, b2}) and w^T (d h' / d h) -> d_out_h for one DSS update.
+// d_weights_t: update t's modules in the f_theta weight layout (three node inputs, no Neumann blocks).
+extern "C" int psignn_dss_step_backward(const psignn_plan_t* p, const float* d_weights_t, float alpha, const float* h,
+                                        const float* bprime, const float* w, float* d_grad, float* d_out_h, float* work,
+                                        void* stream) {
+  ARG_CHECK(p && d_weights_t && h && bprime && w && d_grad && d_out_h && work, "NULL argument");
+  ARG_CHECK(!p->mixed, "DSS plans carry no boundary-condition tags");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t N = p->N;
+  float* rec = work + N * 13 * D;
+  float* part = rec + N * PGREC;
+  int npw;
+  const int nblk = pgrad_blocks(N, &npw);
+  int rc = psignn_dss_step_records(p, d_weights_t, alpha, h, bprime, w, d_out_h, work, rec, st);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)psignn_dss_grad_size() * 4, st));
+  LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabF><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
+  LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabF::NT, 256, 0, st>>>(nblk, TabF::NT, part, d_grad, MapX())));
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Backward of the two-layer MLP (Encoder / Decoder, model.py:370-392; y = W2 relu(W1 x + b1) + b2) and the
 // transposed residual SpMV -- what autograd runs for the autoencoder / residual terms of the training loss

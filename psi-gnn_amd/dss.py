@@ -6,7 +6,8 @@ reference's module tree (``phi_to_list / phi_from_list / psi_list / decoder_list
 
 * ``inference(batch) -> U_k``   (model.py:97-120)
 * ``forward(batch) -> (U, loss_dic)``: every decoded iterate and the ``residual_loss / mse_loss / mse_dirichlet_loss``
-  traces plus ``train_loss`` (model.py:59-95, tests/model_dss.py:58-104), as diagnostics (no graph)
+  traces plus ``train_loss`` (model.py:59-95, tests/model_dss.py:58-104); in train mode ``train_loss`` carries its gradients
+  (back-propagation through the k updates on ``psignn_dss_step_backward``; trainer: ``training_class.TrainModelDSS``)
 * ``residual_loss(U, edge_index, a_ij, b_prime)``   (model.py:122-139).
 
 The copy under the reference's ``tests/`` names the edge fields ``edge_attr / edge_attr_norm`` instead of
@@ -15,7 +16,6 @@ The copy under the reference's ``tests/`` names the edge fields ``edge_attr / ed
 ``batch`` carries the DSS schema of ``dirichlet/dss/utilities/reader.py:61-92`` (``edge_index`` without self loops,
 ``a_ij``, ``a_ij_norm``, ``b_prime``, ``b_prime_norm``, ``pos``); ``to_dss_batch(mesh)`` derives it from a PSI-GNN
 ``MeshData`` the way ``dirichlet/dataset/generate_data.py:100-128`` derives ``A_prime / b_prime`` from ``A / b``.
-Training DSS (back-propagation through the k updates) is not implemented.
 """
 from __future__ import annotations
 
@@ -45,6 +45,27 @@ def to_dss_batch(mesh) -> MeshData:
     std = torch.tensor(B_STD, dtype=b.dtype, device=b.device)
     return MeshData(x=mesh.sol, sol=mesh.sol, edge_index=ei[:, keep], a_ij=a, a_ij_norm=(a - AIJ_MEAN) / AIJ_STD,
                     b_prime=bp, b_prime_norm=(bp - mean) / std, pos=mesh.pos, tags=mesh.tags)
+
+
+class _DssStepFn(torch.autograd.Function):
+    """Update t, H_t -> H_{t+1} (dirichlet/dss/model.py:75-83), as an autograd node: forward on the tile kernel, backward on
+    ``psignn_dss_step_backward`` (VJP w.r.t. H_t and the gradients of update t's phi_to / phi_from / psi)."""
+
+    @staticmethod
+    def forward(ctx, h, sc, t, names, *params):
+        hp = sc["plan"].permute(h.detach(), True)
+        out = sc["plan"].permute(engine.dss_step_p(sc["plan"], sc["w"], t, sc["alpha"], hp, sc["bp"]), False)
+        ctx.sc, ctx.t, ctx.names = sc, t, names
+        ctx.save_for_backward(h.detach())
+        return out
+
+    @staticmethod
+    def backward(ctx, w):
+        (h,) = ctx.saved_tensors
+        sc, t = ctx.sc, ctx.t
+        wf = engine.pack_dss_train(sc["sd"], t, h.device)
+        grads, dh = engine.dss_step_backward(sc["plan"], wf, t, sc["alpha"], h, sc["b"], w.contiguous())
+        return (dh, None, None, None) + tuple(grads[n] for n in ctx.names)
 
 
 class Psi(nn.Module):
@@ -111,8 +132,47 @@ class DeepStatisticalSolver(nn.Module):
         k = self.config["k"]
         return self.decoder_list[k - 1](self.latent(batch, k))
 
-    @torch.no_grad()
     def forward(self, batch):
+        if self.training and torch.is_grad_enabled():
+            return self._train_forward(batch)
+        with torch.no_grad():
+            return self._eval_forward(batch)
+
+    def _train_forward(self, batch):
+        """model.py:59-95 with gradients: ``train_loss`` = sum_t gamma^(k-t-1) residual(U_t) back-propagates through decoder t
+        and the updates 0..t-1 (``_DssStepFn`` nodes); the residual's sparse product runs on the SpMV kernel of the plan."""
+        nat.require_cuda(batch.x, "batch.x")
+        k, alpha, gamma = self.config["k"], self.config["alpha"], self.config["gamma"]
+        plan, dev = self._plan(batch), batch.x.device
+        a_ij, _ = self._fields(batch)
+        idx = torch.where(batch.b_prime[:, 1] == 1)[0]
+        zeros = torch.zeros((plan.N, 1), dtype=torch.float32, device=dev)
+        rowsum = engine.residual(plan, torch.ones_like(zeros), zeros)
+        B0, B1, B2 = batch.b_prime[:, 0:1], batch.b_prime[:, 1:2], batch.b_prime[:, 2:3]
+
+        def residual(u):   # model.py:122-139: sum_j a_ij (u_j - u_i) = (A' u)_i - rowsum_i u_i
+            r = (1 - B1) * (-B0) + B1 * (u - B2) + engine.residual_autograd(plan, u, zeros, a_ij) - rowsum * u
+            return torch.mean(r ** 2)
+        sc = {"plan": plan, "w": self.packed(dev), "alpha": alpha, "bp": plan.permute(batch.b_prime_norm, True),
+              "b": batch.b_prime_norm, "sd": self.state_dict()}
+        h = torch.zeros((plan.N, engine.D), dtype=torch.float32, device=dev)
+        U = {"0": self.decoder_list[0](h) + batch.x * 0}
+        res, mse = {"0": residual(U["0"])}, {"0": self.mse_loss(U["0"], batch.x)}
+        msd = {"0": self.mse_loss(U["0"][idx, :], batch.x[idx, :])}
+        total = None
+        for t in range(k):
+            named = [(n, p) for n, p in self.named_parameters()
+                     if n.startswith((f"phi_to_list.{t}.", f"phi_from_list.{t}.", f"psi_list.{t}."))]
+            h = _DssStepFn.apply(h, sc, t, tuple(n for n, _ in named), *[p for _, p in named])
+            s = str(t + 1)
+            U[s] = self.decoder_list[t](h)
+            res[s], mse[s] = residual(U[s]), self.mse_loss(U[s], batch.x)
+            msd[s] = self.mse_loss(U[s][idx, :], batch.x[idx, :])
+            term = res[s] * gamma ** (k - t - 1)
+            total = term if total is None else total + term
+        return U, {"train_loss": total, "residual_loss": res, "mse_loss": mse, "mse_dirichlet_loss": msd}
+
+    def _eval_forward(self, batch):
         nat.require_cuda(batch.x, "batch.x")
         k, alpha, gamma = self.config["k"], self.config["alpha"], self.config["gamma"]
         plan, w = self._plan(batch), self.packed(batch.x.device)

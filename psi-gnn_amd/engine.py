@@ -551,6 +551,65 @@ def dsgps_step_backward(plan: "MeshPlan", wf, wg, h, prb, w, nrm=None):
     return unpack_dsgps_grads(grad, mixed), out
 
 
+# f_theta base layout with three node inputs (csrc/common.h WLayout<3>): shared 64 | phi_to 350 | phi_from 350 | update 450 | fold
+_DSS_PHI_TO, _DSS_PHI_FROM, _DSS_PSI = 64, 414, 764
+
+
+def pack_dss_train(sd, t, device):
+    """Update t's modules in the f_theta weight layout for ``psignn_dss_step_backward``: the (10, 21) first Phi layers padded
+    to (10, 23) (edge-feature weight in column 22, the plan carries the scalar feature in the third attr column), Psi in
+    the update slots."""
+    n = int(nat.lib().psignn_dss_grad_size())
+    wf = torch.zeros(n, dtype=torch.float32)
+    g = lambda k: sd[k].detach().to("cpu", torch.float32)
+    for name, o in ((f"phi_to_list.{t}", _DSS_PHI_TO), (f"phi_from_list.{t}", _DSS_PHI_FROM)):
+        w1 = g(f"{name}.mlp.mlp.0.weight")
+        w1p = torch.zeros(D, 2 * D + 3)
+        w1p[:, :2 * D], w1p[:, 2 * D + 2] = w1[:, :2 * D], w1[:, 2 * D]
+        blk = torch.cat([w1p.reshape(-1), g(f"{name}.mlp.mlp.0.bias"), g(f"{name}.mlp.mlp.2.weight").reshape(-1),
+                         g(f"{name}.mlp.mlp.2.bias")])
+        wf[o:o + blk.numel()] = blk
+    psi = f"psi_list.{t}.mlp.mlp"
+    blk = torch.cat([g(f"{psi}.0.weight").reshape(-1), g(f"{psi}.0.bias"), g(f"{psi}.2.weight").reshape(-1), g(f"{psi}.2.bias")])
+    wf[_DSS_PSI:_DSS_PSI + blk.numel()] = blk
+    return wf.to(device)
+
+
+def unpack_dss_grads(flat, t):
+    out = {}
+    for name, o in ((f"phi_to_list.{t}", _DSS_PHI_TO), (f"phi_from_list.{t}", _DSS_PHI_FROM)):
+        w1 = flat[o:o + D * (2 * D + 3)].reshape(D, 2 * D + 3)
+        out[f"{name}.mlp.mlp.0.weight"] = torch.cat([w1[:, :2 * D], w1[:, 2 * D + 2:2 * D + 3]], dim=1)
+        o += D * (2 * D + 3)
+        out[f"{name}.mlp.mlp.0.bias"] = flat[o:o + D]
+        out[f"{name}.mlp.mlp.2.weight"] = flat[o + D:o + D + D * D].reshape(D, D)
+        out[f"{name}.mlp.mlp.2.bias"] = flat[o + D + D * D:o + 2 * D + D * D]
+    o, cat = _DSS_PSI, 3 * D + 3
+    psi = f"psi_list.{t}.mlp.mlp"
+    out[f"{psi}.0.weight"] = flat[o:o + D * cat].reshape(D, cat)
+    out[f"{psi}.0.bias"] = flat[o + D * cat:o + D * cat + D]
+    o += D * cat + D
+    out[f"{psi}.2.weight"] = flat[o:o + D * D].reshape(D, D)
+    out[f"{psi}.2.bias"] = flat[o + D * D:o + D * D + D]
+    return out
+
+
+def dss_step_backward(plan: "MeshPlan", wf_t, t, alpha, h, bprime_norm, w):
+    """({name: grad}, w^T dh'/dh) of DSS update t (caller's numbering)."""
+    hc, wc = _f32c(h), _f32c(w)
+    l = nat.lib()
+    grad = torch.empty(int(l.psignn_dss_grad_size()), dtype=torch.float32, device=hc.device)
+    out = torch.empty_like(hc)
+    if getattr(plan, "_dsswork", None) is None:
+        plan._dsswork = torch.empty(int(l.psignn_dss_step_backward_workspace_floats(plan.handle)), dtype=torch.float32,
+                                    device=hc.device)
+    with torch.cuda.device(hc.device):
+        nat.check(l.psignn_dss_step_backward(plan.handle, nat.ptr(wf_t), float(alpha), nat.ptr(hc), nat.ptr(_f32c(bprime_norm)),
+                                             nat.ptr(wc), nat.ptr(grad), nat.ptr(out), nat.ptr(plan._dsswork),
+                                             nat.stream_ptr(hc.device)), "psignn_dss_step_backward")
+    return unpack_dss_grads(grad, t), out
+
+
 def pack_dss(sd, k, device=None) -> torch.Tensor:
     """Flat per-step weight buffer of the DSS kernels from a ``DeepStatisticalSolver`` state_dict
     (dirichlet/dss/model.py:33-55; layout in csrc/dss_tile.hip)."""

@@ -280,3 +280,23 @@ class TrainModelDSGPS(TrainModel):
             self._write("\nCurrent Learning rate : {}".format(self.opt.param_groups[0]["lr"]))
             if saved:
                 self._write("\nMODEL SAVED")
+
+
+class TrainModelDSS(TrainModelDSGPS):
+    """``dirichlet/dss/training_class.py``: as the DS-GPS trainer with residual / mse statistics only and the optimiser
+    state under ``opt``."""
+    KEYS = ("loss", "residual_loss", "mse_loss")
+    _LINE = "\t Res : {:.4e} \t MSE : {:.4e}"
+    _EPOCH = "\t Res : {:.5e} \t MSE : {:.5e}"
+
+    def checkpoint(self, epoch):
+        ck = super().checkpoint(epoch)
+        ck["opt"] = ck.pop("opt_deq")
+        return ck
+
+    def load_model(self, path):
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        self.net.load_state_dict(ck["state_dict"])
+        self.opt.load_state_dict(ck["opt"])
+        self.hist_train, self.hist_val = ck["hist_train"], ck["hist_val"]
+        self.training_time = ck["training_time"]

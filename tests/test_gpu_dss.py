@@ -64,3 +64,53 @@ def test_dss_forward_diagnostics(dev):
     alt = pkg("data").MeshData(x=b.x, sol=b.sol, edge_index=b.edge_index, edge_attr=b.a_ij, edge_attr_norm=b.a_ij_norm,
                                b_prime=b.b_prime, b_prime_norm=b.b_prime_norm, pos=b.pos, tags=b.tags)
     assert torch.equal(net.inference(alt), U[str(k)])
+
+
+def test_dss_training_step_gradients(dev):
+    """loss.backward() on train_loss (BPTT over the 30 updates, one weight set each) vs autograd on the oracle evaluated in
+    float64: loss and all 480 gradient tensors <= 5e-4 of the largest tensor's norm.  (The fp32 ORACLE is itself 3.6e-3 away
+    from the fp64 one on phi_to_list.17 -- a ReLU mask of a cancelling pre-activation flips -- see the note at the top.)"""
+    sd, net = _net(dev)
+    _, mesh = load_case("hex13_dirichlet_s0")
+    dss = pkg("dss")
+    net.train()
+    U, ld = net(dss.to_dss_batch(mesh).to(dev))
+    assert ld["train_loss"].requires_grad
+    ld["train_loss"].backward()
+    k, alpha, gamma = net.config["k"], net.config["alpha"], net.config["gamma"]
+    ob = orc.dss_batch(mesh)
+    for f in list(vars(ob)):
+        t = getattr(ob, f)
+        if torch.is_tensor(t) and t.is_floating_point():
+            setattr(ob, f, t.double())
+    wl, wg, wres = orc.dss_training_step({n: t.double() for n, t in sd.items()}, ob, k, alpha, gamma)
+    print("train_loss", float(ld["train_loss"].detach()), float(wl))
+    assert abs(float(ld["train_loss"].detach()) - float(wl)) < 1e-3 * abs(float(wl))
+    got = {n: p.grad for n, p in net.named_parameters()}
+    scale = max(float(t.norm()) for t in wg.values())
+    errs = {}
+    for n, w in wg.items():
+        gn = got[n]
+        if gn is None:
+            assert float(w.abs().max()) == 0.0, n    # e.g. decoder_list.0 is also used for U_0 only through H_0 = 0
+            continue
+        errs[n] = float((gn.cpu().double() - w).norm()) / max(float(w.norm()), 1e-3 * scale)
+    print("worst", max(errs, key=errs.get), max(errs.values()), len(errs))
+    assert max(errs.values()) < 5e-4, {n: e for n, e in errs.items() if e >= 5e-4}
+
+
+def test_dss_trainer(dev, tmp_path):
+    TrainModelDSS = pkg("training_class").TrainModelDSS
+    torch.manual_seed(0)
+    cfg = dict(latent_dim=10, k=5, alpha=1e-3, gamma=0.9, path_logs=str(tmp_path))
+    dss = pkg("dss")
+    net = dss.DeepStatisticalSolver(cfg).to(dev)
+    meshes = [dss.to_dss_batch(load_case(n)[1]).to(dev) for n in ("hex13_dirichlet_s0", "original_dirichlet_s0")]
+    tcfg = dict(loader_train=meshes, loader_val=meshes[:1], model=net, config_model=cfg, lr=0.01, path_ckpt=str(tmp_path),
+                min_loss_save=1e9, max_epochs=5, gradient_clip=0.01)
+    tr = TrainModelDSS(tcfg)
+    tr.train_model()
+    assert set(tr.hist_train) == {"loss", "residual_loss", "mse_loss"} and len(tr.hist_train["loss"]) == 5
+    assert all(np.isfinite(tr.hist_train["loss"])) and tr.hist_train["loss"][-1] < tr.hist_train["loss"][0]
+    ck = torch.load(tmp_path / "running_model.pt", weights_only=True)
+    assert set(ck) == {"epoch", "hyperparameters", "state_dict", "hist_train", "hist_val", "opt", "training_time"}
