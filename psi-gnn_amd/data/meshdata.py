@@ -77,7 +77,9 @@ def collate(meshes) -> MeshData:
     offs = [0]
     for m in meshes:
         offs.append(offs[-1] + m.num_nodes)
-    for k in ("x", "edge_attr", "a_ij", "y", "sol", "prb_data", "tags", "pos", "unit_normal_vector"):
+    # the last four: the DSS schema (dirichlet/dss/utilities/reader.py:61-92; tests/model_dss.py spells the edge field edge_attr_norm)
+    for k in ("x", "edge_attr", "a_ij", "y", "sol", "prb_data", "tags", "pos", "unit_normal_vector",
+              "a_ij_norm", "edge_attr_norm", "b_prime", "b_prime_norm"):
         vals = [getattr(m, k, None) for m in meshes]
         if all(v is not None for v in vals):
             setattr(out, k, torch.cat(vals, dim=0))

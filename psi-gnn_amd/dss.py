@@ -43,8 +43,12 @@ def to_dss_batch(mesh) -> MeshData:
     bp = torch.stack([torch.where(diri, zero, b), diri.to(b.dtype), torch.where(diri, b, zero)], dim=1)
     mean = torch.tensor(B_MEAN, dtype=b.dtype, device=b.device)
     std = torch.tensor(B_STD, dtype=b.dtype, device=b.device)
-    return MeshData(x=mesh.sol, sol=mesh.sol, edge_index=ei[:, keep], a_ij=a, a_ij_norm=(a - AIJ_MEAN) / AIJ_STD,
-                    b_prime=bp, b_prime_norm=(bp - mean) / std, pos=mesh.pos, tags=mesh.tags)
+    out = MeshData(x=mesh.sol, sol=mesh.sol, edge_index=ei[:, keep], a_ij=a, a_ij_norm=(a - AIJ_MEAN) / AIJ_STD,
+                   b_prime=bp, b_prime_norm=(bp - mean) / std, pos=mesh.pos, tags=mesh.tags)
+    for k in ("batch", "ptr", "num_graphs"):      # a union batch stays one (the plan tiles graph by graph)
+        if getattr(mesh, k, None) is not None:
+            setattr(out, k, getattr(mesh, k))
+    return out
 
 
 class _DssStepFn(torch.autograd.Function):
@@ -115,6 +119,8 @@ class DeepStatisticalSolver(nn.Module):
                             edge_attr=torch.cat([z, a_norm.reshape(-1, 1).float()], dim=1).contiguous(),
                             tags=torch.zeros((batch.x.shape[0], 1), dtype=torch.float32, device=batch.x.device),
                             pos=batch.pos)
+            if getattr(batch, "batch", None) is not None:
+                view.batch = batch.batch
             plan = engine.MeshPlan(view)
             batch._dss_plan = plan
         return plan

@@ -114,3 +114,18 @@ def test_dss_trainer(dev, tmp_path):
     assert all(np.isfinite(tr.hist_train["loss"])) and tr.hist_train["loss"][-1] < tr.hist_train["loss"][0]
     ck = torch.load(tmp_path / "running_model.pt", weights_only=True)
     assert set(ck) == {"epoch", "hyperparameters", "state_dict", "hist_train", "hist_val", "opt", "training_time"}
+
+
+def test_dss_union_batch(dev):
+    """A PyG-style union batch (data.collate) in the DSS schema: the plan tiles graph by graph (the graph ids travel with the
+    batch), and the union's latent state is the concatenation of the per-graph ones; DSS-schema graphs collate as well."""
+    sd, net = _net(dev)
+    data, dss = pkg("data"), pkg("dss")
+    meshes = [load_case(n)[1] for n in ("hex13_dirichlet_s0", "original_dirichlet_s0", "hex26_dirichlet_s0")]
+    union = dss.to_dss_batch(data.collate(meshes)).to(dev)
+    hk = net.latent(union)
+    parts = torch.cat([net.latent(dss.to_dss_batch(m).to(dev)) for m in meshes], dim=0)
+    assert rel_l2(hk, parts) < 1e-6
+    union2 = data.collate([dss.to_dss_batch(m) for m in meshes]).to(dev)    # collating graphs already in the DSS schema
+    assert torch.equal(union2.b_prime_norm, union.b_prime_norm) and torch.equal(union2.a_ij_norm, union.a_ij_norm)
+    assert rel_l2(net.latent(union2), parts) < 1e-6
