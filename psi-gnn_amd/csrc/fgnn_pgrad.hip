@@ -254,7 +254,7 @@ extern "C" int psignn_f_param_vjp_p(const psignn_plan_t* p, const float* W, int 
   return PSIGNN_OK;
 }
 
-// ---- backward of the VJP (the Jacobian regulariser's gradient; kernels and derivation in fgnn_jacreg.hip)
+// ---- backward of the VJP (the Jacobian regulariser's gradient; kernels and derivation in gather_backward.hip)
 int psignn_jacreg_records(const psignn_plan* p, const float* W, const float* h, const float* prb, const float* nrm,
                           const float* v, const float* gbar, float* out_h, float* work, float* rec, hipStream_t st);
 
@@ -297,8 +297,8 @@ extern "C" int psignn_f_vjp_backward(const psignn_plan_t* p, const float* W, int
   return PSIGNN_OK;
 }
 
-// ---- DS-GPS: backward of one recurrent update (kernels in fgnn_jacreg.hip)
-struct TabG {  // groups: see fgnn_jacreg.hip
+// ---- DS-GPS: backward of one recurrent update (kernels in gather_backward.hip)
+struct TabG {  // groups: see gather_backward.hip
   static constexpr int NG = 20, NT = 19;
   __host__ __device__ static constexpr int a(int t) {
     constexpr int tab[NT] = {6, 6, 6, 7, 8, 9, 10, 11, 12, 13, 11, 11, -1, -1, -1, -1, 14, 14, 14};
@@ -390,7 +390,7 @@ extern "C" int psignn_dsgps_step_backward(const psignn_plan_t* p, const float* d
   return PSIGNN_OK;
 }
 
-// ---- DSS: backward of one update (kernels in fgnn_jacreg.hip); gradient in the f_theta layout with three node inputs
+// ---- DSS: backward of one update (kernels in gather_backward.hip); gradient in the f_theta layout with three node inputs
 int psignn_dss_step_records(const psignn_plan* p, const float* Wf, float alpha, const float* h, const float* bp,
                             const float* w, float* out_h, float* work, float* rec, hipStream_t st);
 

@@ -1,4 +1,11 @@
-// Backward of the vector-Jacobian product of f_theta (gfx950; both families, single layer, caller's numbering).
+// Backward passes built on global-gather kernels with an INJECTED cotangent (gfx950; caller's numbering, no atomics):
+//   * the backward of the vector-Jacobian product of f_theta (the Jacobian regulariser's double backward) -- below;
+//   * the backward of one DS-GPS update and of one DSS update (back-propagation through the baselines' unrolled updates) --
+//     at the end of the file.
+// All three push a node-level cotangent on c = [h, Phi_to(h), Phi_from(h)(, Phi_neumann(h))] through the same edge-level
+// pair k_jr_edge_local / k_jr_edge_remote and leave parameter-gradient records for the MFMA reduction of fgnn_pgrad.hip.
+//
+// ---- Backward of the vector-Jacobian product of f_theta (both families, single layer)
 //
 // The reference's Jacobian regulariser  jac_loss = |v^T J_f(H*)|^2 / (N d)  (jac_loss_estimate, dirichlet/psignn/model.py:
 // 416-435, one Gaussian probe v) is built with autograd.grad(..., create_graph=True) and enters the training loss with

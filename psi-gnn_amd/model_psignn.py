@@ -183,7 +183,7 @@ class _DEQFn(torch.autograd.Function):
 class _JacLossFn(torch.autograd.Function):
     """jac_loss = |v^T J_f(H*)|^2 / (N d) with its gradient w.r.t. the parameters of f: the reference builds the VJP with
     ``create_graph=True`` (jac_loss_estimate, dirichlet/psignn/model.py:416-435) and lets ``loss.backward()`` run the
-    double backward; here backward is the HIP backward-of-the-VJP (csrc/fgnn_jacreg.hip).  H* is a leaf in the
+    double backward; here backward is the HIP backward-of-the-VJP (csrc/gather_backward.hip).  H* is a leaf in the
     reference (model.py:204), so nothing flows back into the solve."""
 
     @staticmethod

@@ -1,4 +1,4 @@
-"""Backward of the VJP (csrc/fgnn_jacreg.hip) on one large mesh: time per call, per-kernel breakdown.
+"""Backward of the VJP (csrc/gather_backward.hip) on one large mesh: time per call, per-kernel breakdown.
 
     python3 scripts/jacreg_bench.py [hex_n=577] [reps=10]
 """

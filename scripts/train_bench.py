@@ -5,7 +5,7 @@ the CPU oracle's restated training step (autograd + restated broyden) timed besi
     python3 scripts/train_bench.py [graphs_per_batch=50] [hex_n=13] [steps=5] [cpu=1] [jac_weight=0] [family=dirichlet|mixed]
 
 jac_weight = 1 is what the reference's launch scripts use (launch_local.sh:24): the step then also runs the backward of
-the VJP (csrc/fgnn_jacreg.hip).
+the VJP (csrc/gather_backward.hip).
 
 The reference trains on ~500-node meshes (hsize 0.08) in PyG batches; hex_n = 13 gives 547 nodes per graph.
 Prints one JSON line."""
