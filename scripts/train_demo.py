@@ -3,7 +3,10 @@ batch 50, lr_deq 0.01, lr_ae 0.05, gradient_clip 0.1, solver broyden, jac_weight
 seed 1234) through the reference's main.py shape (DataListLoader + DataParallel + TrainModel), on synthetic hexagon
 meshes in the reader's schema (the reference's dataset needs FEniCS + gmsh to generate).
 
-    python3 scripts/train_demo.py [graphs=300] [epochs=15] [out_dir=gpurun_out/train_demo]
+    python3 scripts/train_demo.py [graphs=300] [epochs=15] [out_dir=gpurun_out/train_demo] [model=psignn|dsgps|dss]
+
+model = dsgps / dss: the baselines with their launch configurations (dirichlet/dsgps/launch.sh, dirichlet/dss/launch.sh:
+k 30, alpha 1e-3, gamma 0.9, lr 0.01, gradient_clip 0.01, batch 100 -> 50 here) through TrainModelDSGPS / TrainModelDSS.
 
 Prints one JSON line: per-epoch training / validation losses, seconds per epoch, Broyden step statistics.
 """
@@ -25,6 +28,7 @@ def main():
     G = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 15
     out_dir = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "train_demo")
+    which = sys.argv[4] if len(sys.argv) > 4 else "psignn"
     os.makedirs(out_dir, exist_ok=True)
     torch.manual_seed(1234)
     np.random.seed(1234)
@@ -34,6 +38,8 @@ def main():
     n_tr, n_va = int(0.6 * G), int(0.2 * G)            # reader.py split: 60 / 20 / 20
     train, val = graphs[:n_tr], graphs[n_tr:n_tr + n_va]
     dev = torch.device("cuda:0")
+    if which in ("dsgps", "dss"):
+        return baseline(which, train, val, epochs, out_dir, dev, n_tr, n_va)
     cfg = {"latent_dim": 10, "hidden_dim": 10, "n_layers": 1, "fw_tol": 1e-5, "fw_thres": 400, "bw_tol": 1e-8,
            "bw_thres": 400, "solver": solver.broyden, "path_logs": out_dir}
     net = pkg("model_psignn").ModelDEQDSS(cfg)
@@ -64,6 +70,31 @@ def main():
         "train": {k: [round(float(x), 6) for x in v] for k, v in tr.hist_train.items()},
         "val": {k: [round(float(x), 6) for x in v] for k, v in tr.hist_val.items()},
         "forward_solves": steps("forward_iteration.csv"), "backward_solves": steps("backward_iteration.csv")}))
+
+
+def baseline(which, train, val, epochs, out_dir, dev, n_tr, n_va):
+    loader, tc = pkg("loader"), pkg("training_class")
+    cfg = {"latent_dim": 10, "k": 30, "alpha": 1e-3, "gamma": 0.9, "path_logs": out_dir}
+    if which == "dss":
+        dss = pkg("dss")
+        train, val = [dss.to_dss_batch(g) for g in train], [dss.to_dss_batch(g) for g in val]
+        net, Trainer = dss.DeepStatisticalSolver(cfg), tc.TrainModelDSS
+    else:
+        net, Trainer = pkg("dsgps").ModelDSGPS(cfg), tc.TrainModelDSGPS
+    model = loader.DataParallel(net).to(dev)
+    tr = Trainer({"model": model, "config_model": cfg, "loader_train": loader.DataListLoader(train, batch_size=50, shuffle=True),
+                  "loader_val": loader.DataListLoader(val, batch_size=50, shuffle=False), "lr": 0.01, "gradient_clip": 0.01,
+                  "max_epochs": epochs, "min_loss_save": 1e5, "path_ckpt": out_dir})
+    t0 = time.perf_counter()
+    tr.train_model()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({
+        "workload": f"{which}: {n_tr} training / {n_va} validation hexagon meshes (n = 9..14), batch 50, {epochs} epochs from "
+                    f"xavier initialisation, k = 30 unrolled updates, reference launch.sh hyper-parameters",
+        "seconds_total": dt, "seconds_per_epoch": dt / epochs,
+        "train": {k: [round(float(x), 6) for x in v] for k, v in tr.hist_train.items()},
+        "val": {k: [round(float(x), 6) for x in v] for k, v in tr.hist_val.items()}}))
 
 
 if __name__ == "__main__":
