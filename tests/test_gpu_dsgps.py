@@ -159,7 +159,7 @@ def test_dsgps_training_step_gradients(name, dev):
     wl, wg, wres, wmse = orc.dsgps_training_step(sd, mesh, k, gamma)
     print("train_loss", float(ld["train_loss"].detach()), float(wl))
     assert abs(float(ld["train_loss"].detach()) - float(wl)) < 1e-4 * abs(float(wl))
-    assert abs(float(ld["residual_loss"][str(k)]) - wres) < 1e-3 * wres
+    assert abs(float(ld["residual_loss"][str(k)].detach()) - wres) < 1e-3 * wres
     got = {n: p.grad for n, p in net.named_parameters()}
     scale = max(float(t.norm()) for t in wg.values())
     errs = {}
