@@ -20,6 +20,9 @@
 #else
 #define TILE_WPE_ATTR
 #endif
+#ifndef X_RELOAD
+#define X_RELOAD 1    // 1: park the node state in memory during the slot walk (A/B: scripts/ab_edge.sh)
+#endif
 #ifndef EDGE_CLAMP
 #define EDGE_CLAMP 1  // relu folded into the clamp bit of the last edge fma (tile_helpers.h: edge_pass_both_clamp)
 #endif
@@ -269,6 +272,16 @@ __global__ __launch_bounds__(TILE_THREADS) TILE_WPE_ATTR void k_f_tile(FuseArgs 
   float deg_in, deg_out;
 #pragma unroll
   for (int p = 0; p < 5; ++p) S_to[p] = S_fr[p] = splat(0.f);
+#if X_RELOAD
+  // the node state is not needed during the slot walk: park it in memory (the fused step writes x_next to its slot of the
+  // iterate buffer anyway) and read it back afterwards -- ten VGPRs less in the loop
+  const float* xsrc = h + n * D;
+  if (FUSED) {
+    float* xn = fa.xbuf + (int64_t)fa.st[fa.off_nxt] * fa.M + n * D;
+    store10(xn, x);
+    xsrc = xn;
+  }
+#endif
 #if EDGE_BOTH
   {
     v2f Pi2[5];
@@ -286,6 +299,9 @@ __global__ __launch_bounds__(TILE_THREADS) TILE_WPE_ATTR void k_f_tile(FuseArgs 
 #endif
     PHASE();
   }
+#if X_RELOAD
+  load10(xsrc, x);
+#endif
 #else
   ld5(T + L::T_B1_TO, Pi);
   PHASE();
@@ -409,7 +425,7 @@ __global__ __launch_bounds__(TILE_THREADS) TILE_WPE_ATTR void k_f_tile(FuseArgs 
     }
     store10(fa.gx + n * D, gn);
     store10(fa.dg + n * D, go);
-    store10(fa.xbuf + (int64_t)fa.st[fa.off_nxt] * fa.M + n * D, x);
+    if (!X_RELOAD || dirichlet) store10(fa.xbuf + (int64_t)fa.st[fa.off_nxt] * fa.M + n * D, x);
   }
   // one partial pair per tile: wave shuffles, then the 4 wave sums through LDS in a fixed order
   sg = wave_sum_f(sg);

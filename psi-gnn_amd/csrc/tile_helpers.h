@@ -115,6 +115,9 @@ __device__ __forceinline__ float edge_pass(const uint4* __restrict__ slots, int 
 // value underflows below 2^-126, i.e. |z| < 2^-86) turns relu(z) = 2^40 clamp(2^-40 z) for every |z| < 2^40 ~ 1e12.
 // NaN clamps to 0, as v_max(NaN, 0) did.  The attr values a0, a1, a2 are broadcast from the halves of two register
 // pairs with op_sel (the compiler would spend six v_mov per slot on duplicating them).
+#ifndef CLAMP_PD
+#define CLAMP_PD 1    // slot records loaded this many rounds ahead in edge_pass_both_clamp (1 or 2)
+#endif
 #define RELU_SCALE 9.094947017729282e-13f   // 2^-40
 #define RELU_UNSCALE 1099511627776.f        // 2^40
 __device__ __forceinline__ v2f pk_fma_lo(v2f w, v2f a, v2f z) {  // z + w * (a.x, a.x)
@@ -154,9 +157,11 @@ __device__ __forceinline__ void edge_pass_both_clamp(const uint4* __restrict__ s
   deg_in = deg_out = 0.f;
   if (nslots <= 0) return;
   uint4 c0 = slots[0];
+#if CLAMP_PD == 2
   uint4 c1 = slots[(int64_t)min(1, nslots - 1) * 64];
+#endif
   for (int r = 0; r < nslots; ++r) {
-    const uint4 nx = slots[(int64_t)min(r + 2, nslots - 1) * 64];
+    const uint4 nx = slots[(int64_t)min(r + CLAMP_PD, nslots - 1) * 64];
     const unsigned w = c0.x;
     if ((w & 0xFFFFu) != ELL_EMPTY) {
       const v2f a01 = (v2f){__uint_as_float(c0.y), __uint_as_float(c0.z)} * sc;
@@ -192,8 +197,12 @@ __device__ __forceinline__ void edge_pass_both_clamp(const uint4* __restrict__ s
         for (int p = 0; p < 5; ++p) S_fr[p] += z[p];
       }
     }
+#if CLAMP_PD == 2
     c0 = c1;
     c1 = nx;
+#else
+    c0 = nx;
+#endif
   }
   const v2f us = splat(RELU_UNSCALE);
 #pragma unroll
