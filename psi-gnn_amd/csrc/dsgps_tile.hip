@@ -115,7 +115,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_dsgps_tile(int n_tiles, int ch
   PHASE();
   mv2<D>(W + dsl::W1I_FR, x, Pi2);
   PHASE();
-  edge_pass_both<RS>(slots, nslots, lds, W + dsl::A_TO, W + dsl::A_FR, Pi, Pi2, S_to, S_fr, deg_in, deg_out);
+  edge_pass_both_clamp<RS>(slots, nslots, lds, W + dsl::A_TO, W + dsl::A_FR, Pi, Pi2, S_to, S_fr, deg_in, deg_out);
+  // the node state is dead during the slot walk (five waves per SIMD instead of four): read it back, as k_f_tile does
+  PHASE();
+  load10(h + n * D, x);
   PHASE();
   if (MIXED && (fl & FLAG_NEUMANN)) {
     // H[update+1][index_neumann] = update_neumann([h | Phi_neumann(h) | prb | normal])   (mixed/dsgps/model.py:88-93)

@@ -77,7 +77,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_dss_tile(int n_tiles, int chun
   PHASE();
   mv2<D>(W + dss::W1I_FR, x, Pi2);
   PHASE();
-  edge_pass_both<RS>(slots, nslots, lds, W + dss::A_TO, W + dss::A_FR, Pi, Pi2, S_to, S_fr, deg_in, deg_out);
+  edge_pass_both_clamp<RS>(slots, nslots, lds, W + dss::A_TO, W + dss::A_FR, Pi, Pi2, S_to, S_fr, deg_in, deg_out);
+  // the node state is dead during the slot walk (five waves per SIMD instead of four): read it back, as k_f_tile does
+  PHASE();
+  load10(h + n * D, x);
   PHASE();
   v2f mt[5], mf[5], b[5];
   ld5(W + dss::B2_TO, b);
