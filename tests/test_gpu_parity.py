@@ -881,7 +881,8 @@ def test_broyden_stop_mode_abs(dev):
 def test_random_graphs_plan_tiles_and_f(seed, dev):
     """Randomised sweep: graphs with duplicate edges, one-directional edges, self loops, partly mirrored attrs, random
     tags (both families) and random positions.  Integer structures bit-exact vs the numpy statements (plan_ref.py), tile
-    structures bit-exact when the plan tiles, f vs the oracle."""
+    structures bit-exact when the plan tiles, f and VJP vs the oracle, and the training-side kernels (parameter VJP, backward
+    of the VJP, DS-GPS step backward) vs autograd on the oracle."""
     from plan_ref import tile_reference
     data, eng = pkg("data"), pkg("engine")
     rng = np.random.default_rng(100 + seed)
@@ -931,6 +932,28 @@ def test_random_graphs_plan_tiles_and_f(seed, dev):
     assert rel_l2(fm(h.to(dev)), want) < 5e-6, (seed, plan.tiled)
     w = t(rng.standard_normal((N, 10)).astype(np.float32))
     assert rel_l2(fm.vjp(h.to(dev), w.to(dev)), orc.function_vjp(sd, h, h0, m, w)) < 5e-5
+    # training-side kernels on the same graph: parameter VJP, backward of the VJP (double backward), DS-GPS step backward
+    def close(got, want, tol):
+        scale = max(float(v.norm()) for v in want.values())
+        errs = {k: float((got[k].cpu() - want[k]).norm()) / max(float(want[k].norm()), 1e-3 * scale) for k in want}
+        assert max(errs.values()) < tol, (seed, {k: e for k, e in errs.items() if e >= tol})
+    pg, _ = fm.param_vjp(h.to(dev), w.to(dev))
+    close(pg, orc.function_param_vjp(sd, h, h0, m, w)[0], 1e-4)
+    gbar = t(rng.standard_normal((N, 10)).astype(np.float32)) / N
+    g2, dh2 = fm.vjp_backward(h.to(dev), w.to(dev), gbar.to(dev))
+    want2, wdh2, _ = orc.function_vjp_backward(sd, h, h0, m, w, gbar)
+    close(g2, want2, 5e-4)
+    assert rel_l2(dh2, wdh2) < 5e-4
+    wd = np.load(os.path.join(os.path.dirname(__file__), "golden", "weights_dsgps_mixed.npz" if mixed else "weights_dsgps.npz"))
+    sdd = {n: torch.from_numpy(wd[n]) for n in wd.files if n != "k"}
+    names = [k for k in sdd if not k.startswith(("autoencoder", "laynorm"))]
+    pp = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sdd.items()}
+    hh = h.clone().requires_grad_(True)
+    gr = torch.autograd.grad(orc.dsgps_step(pp, hh, h0, m), [pp[k] for k in names] + [hh], w)
+    wf, wg = eng.pack_dsgps_train(sdd, dev)
+    g3, dh3 = eng.dsgps_step_backward(plan, wf, wg, h.to(dev), md.prb_data, w.to(dev), getattr(md, "unit_normal_vector", None))
+    close(g3, dict(zip(names, gr[:-1])), 1e-4)
+    assert rel_l2(dh3, gr[-1]) < 5e-5
 
 
 def test_broyden_line_search(dev):
