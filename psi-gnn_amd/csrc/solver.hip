@@ -68,6 +68,10 @@ struct psignn_broyden {
   int64_t ld = 0;           // row pitch (floats) of U and V
   int stop_abs = 0;         // stop_mode of the next solve
   int plan_order = 1;       // 0 while iterates are kept in the caller's numbering (adjoint solve on the gather kernels)
+  // PSIGNN_GRAPH=1 (experiment): the launches of each poll_every-iteration chunk captured into a HIP
+  // graph, cached per chunk and re-used by later solves with the same arguments
+  std::vector<hipGraphExec_t> graphs;
+  uint64_t graph_key = 0;
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -656,6 +660,8 @@ extern "C" void psignn_broyden_destroy(psignn_broyden_t* s) {
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (s->h_st) (void)hipHostFree(s->h_st);
+  for (hipGraphExec_t g : s->graphs)
+    if (g) (void)hipGraphExecDestroy(g);
   delete s;
 }
 
@@ -803,6 +809,42 @@ extern "C" int psignn_broyden_solve(psignn_broyden_t* s, const float* W, int nl,
   VPLAIN(s->vec, k_begin, (g, TB, 0, st), s->M, s->h0p, s->fx, s->xbuf, s->gx, s->upd);
   const bool fused = p->tiled && (nl == 1 || p->mixed);
   const int32_t* st_words = reinterpret_cast<const int32_t*>(s->st);
+  static const bool use_graph = [] { const char* e = getenv("PSIGNN_GRAPH"); return e && atoi(e) != 0; }();
+  if (use_graph && fused && !g_prof_on) {
+    // one graph per chunk of poll_every iterations (the iteration index is a kernel argument); every kernel returns at once
+    // when the device-side done flag is set, so a chunk that overshoots the stop is harmless
+    uint64_t key = (uint64_t)(uintptr_t)W * 1000003u ^ (uint64_t)(uintptr_t)nrmp * 7919u ^ (uint64_t)nl * 31u ^ (uint64_t)poll_every;
+    double e = eps;
+    key ^= *reinterpret_cast<uint64_t*>(&e);
+    if (key != s->graph_key) {
+      for (hipGraphExec_t g : s->graphs)
+        if (g) (void)hipGraphExecDestroy(g);
+      s->graphs.clear();
+      s->graph_key = key;
+    }
+    const int nchunk = (int)cdiv(s->thr, poll_every);
+    s->graphs.resize(nchunk, nullptr);
+    for (int c = 0; c < nchunk; ++c) {
+      if (!s->graphs[c]) {
+        hipGraph_t graph;
+        HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int it = c * poll_every; it < std::min(s->thr, (c + 1) * poll_every); ++it) {
+          rc = psignn_f_tile_fused(p, W, nl, s->xbuf, s->M, st_words, offsetof(Status, done) / 4, sel_off_cur(), sel_off_nxt(),
+                                   s->upd, s->gx, s->dg, s->h0p, s->prbp, nrmp, s->nrm_part, st);
+          if (rc >= 0) launch_update(s, it, eps, st, rc);
+        }
+        HIP_TRY(hipStreamEndCapture(st, &graph));
+        if (rc < 0) return rc;
+        HIP_TRY(hipGraphInstantiate(&s->graphs[c], graph, nullptr, nullptr, 0));
+        HIP_TRY(hipGraphDestroy(graph));
+      }
+      HIP_TRY(hipGraphLaunch(s->graphs[c], st));
+      rc = read_status(s, st);
+      if (rc) return rc;
+      if (s->h_st->done) break;
+    }
+    return finish(s, d_result, info, h_rel, h_abs, st);
+  }
   for (int it = 0; it < s->thr; ++it) {
     if (fused) {
       // one kernel: x_next = x_cur + update, f(x_next), g_new, dg, x_next and the norm partials
