@@ -1016,3 +1016,34 @@ def test_several_initial_guesses(dev):
     assert min(outs[2]["res_dic"]) < 2 * min(outs[0]["res_dic"])
     # the +-1000 start is far outside the trained range: the call completes with finite diagnostics
     assert all(np.isfinite(outs[1]["res_dic"]))
+
+
+def test_hip_graph_replay_is_bitwise_identical(dev, tmp_path):
+    """PSIGNN_GRAPH=1 (read once at library load, hence a child process): the solver's iteration chunks replayed from HIP
+    graphs give bit-identical iterates, also when the same solver object is re-used (cached graphs) and when the stop fires
+    inside a chunk."""
+    import subprocess
+    import sys
+    code = f"""
+import sys, numpy as np, torch
+sys.path.insert(0, {os.path.dirname(__file__)!r}); sys.path.insert(0, {os.path.dirname(os.path.dirname(__file__))!r})
+from conftest import load_case, load_weights, pkg
+eng, solver = pkg("engine"), pkg("utilities.solver")
+dev = torch.device("cuda:0")
+torch.cuda.set_stream(torch.cuda.Stream())
+g, mesh = load_case("hex13_dirichlet_s0")
+md = mesh.to(dev)
+fmap = eng.FixedPointMap(eng.plan_for(md), eng.PackedWeights(load_weights("dirichlet"), dev), torch.from_numpy(g["h0"]).to(dev), md.prb_data, None)
+sv = eng.DeviceBroyden(plan=fmap.plan, threshold=300, keep_trace=False)
+outs = [solver.broyden(fmap, fmap.h0, threshold=300, eps=1e-5, keep_trace=False, solver_obj=sv) for _ in range(2)]
+assert torch.equal(outs[0]["result"], outs[1]["result"])
+np.savez(sys.argv[1], result=outs[1]["result"].cpu().numpy(), nstep=outs[1]["nstep"], n_iter=outs[1]["n_iter"], rel=np.array(outs[1]["rel_trace"]))
+"""
+    res = {}
+    for flag in ("0", "1"):
+        out = tmp_path / f"g{flag}.npz"
+        env = dict(os.environ, PSIGNN_GRAPH=flag)
+        subprocess.run([sys.executable, "-c", code, str(out)], check=True, env=env, timeout=300)
+        res[flag] = np.load(out)
+    assert int(res["0"]["nstep"]) == int(res["1"]["nstep"]) and int(res["0"]["n_iter"]) == int(res["1"]["n_iter"])
+    assert np.array_equal(res["0"]["result"], res["1"]["result"]) and np.array_equal(res["0"]["rel"], res["1"]["rel"])
