@@ -198,3 +198,42 @@ def test_loader_stand_ins():
     assert dp.module is not None
     assert dp([ds[0]]) == (ds[0].num_nodes, 1)
     assert dp(ds[:3]) == (3 * ds[0].num_nodes, 3)
+
+
+def test_baseline_training_layouts_round_trip():
+    """The weight buffers handed to psignn_dsgps_step_backward / psignn_dss_step_backward use the layout their gradients come
+    back in: unpacking a packed weight buffer as if it were a gradient returns the state dict's tensors (both DS-GPS
+    families, DSS with its (10, 21) first Phi layers padded to 23 columns)."""
+    eng, nat = pkg("engine"), pkg("_native")
+    gold = os.path.join(ROOT, "tests", "golden")
+    for fn, mixed in (("weights_dsgps.npz", False), ("weights_dsgps_mixed.npz", True)):
+        w = np.load(os.path.join(gold, fn))
+        sd = {n: torch.from_numpy(w[n]) for n in w.files if n != "k"}
+        wf, wg = eng.pack_dsgps_train(sd, "cpu")
+        base = int(nat.lib().psignn_param_grad_size(int(mixed), 1))
+        assert wf.numel() == nat.lib().psignn_weights_size(int(mixed), 1)
+        assert base + wg.numel() == nat.lib().psignn_dsgps_grad_size(int(mixed))
+        back = eng.unpack_dsgps_grads(torch.cat([wf[:base], wg]), mixed)
+        want = {n: t for n, t in sd.items() if not n.startswith(("autoencoder", "laynorm"))}
+        assert set(back) == set(want)
+        assert all(torch.equal(back[n], want[n]) for n in want)
+    w = np.load(os.path.join(gold, "weights_dss.npz"))
+    sd = {n: torch.from_numpy(w[n]) for n in w.files if n not in ("k", "alpha")}
+    for t in (0, 7, int(w["k"]) - 1):
+        wf = eng.pack_dss_train(sd, t, "cpu")
+        assert wf.numel() == nat.lib().psignn_dss_grad_size()
+        back = eng.unpack_dss_grads(wf, t)
+        assert set(back) == {n for n in sd if n.startswith((f"phi_to_list.{t}.", f"phi_from_list.{t}.", f"psi_list.{t}."))}
+        assert all(torch.equal(back[n], sd[n]) for n in back)
+
+
+def test_dss_schema_collates():
+    """Graphs in the DSS schema (reader.py:61-92) keep their fields through data.collate, and a union batch converted with
+    to_dss_batch keeps its graph ids (the plan tiles graph by graph)."""
+    data, dss = pkg("data"), pkg("dss")
+    meshes = [data.make_hex_problem(n, seed=n) for n in (5, 7)]
+    a = data.collate([dss.to_dss_batch(m) for m in meshes])
+    b = dss.to_dss_batch(data.collate(meshes))
+    for k in ("a_ij_norm", "b_prime", "b_prime_norm", "edge_index", "batch"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert a.num_graphs == 2 and int(b.batch.max()) == 1
