@@ -119,10 +119,25 @@ def prof_collect():
 _lib = None
 
 
+def _build_once():
+    """A source checkout without the built library (the .so is kept out of git): compile it in place when hipcc is there.
+    Nothing else is attempted -- without the library every entry point raises."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = os.path.join(os.path.dirname(LIB_PATH), "csrc")
+    if not (os.path.exists(hipcc) and os.path.exists(os.path.join(csrc, "Makefile"))):
+        return
+    print(f"[psi-gnn_amd] {os.path.basename(LIB_PATH)} missing: building it with {hipcc} (make -C {csrc})", flush=True)
+    subprocess.run(["make", "-C", csrc, "-j8", f"HIPCC={hipcc}"], check=False, stdout=subprocess.DEVNULL)
+
+
 def lib():
     """Load the shared library (once).  Raises NativeError if it has not been built."""
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            _build_once()
         if not os.path.exists(LIB_PATH):
             raise NativeError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
