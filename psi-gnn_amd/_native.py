@@ -128,8 +128,12 @@ def _build_once():
     csrc = os.path.join(os.path.dirname(LIB_PATH), "csrc")
     if not (os.path.exists(hipcc) and os.path.exists(os.path.join(csrc, "Makefile"))):
         return
-    print(f"[psi-gnn_amd] {os.path.basename(LIB_PATH)} missing: building it with {hipcc} (make -C {csrc})", flush=True)
-    subprocess.run(["make", "-C", csrc, "-j8", f"HIPCC={hipcc}"], check=False, stdout=subprocess.DEVNULL)
+    import fcntl
+    with open(os.path.join(csrc, ".build.lock"), "w") as lock:   # one builder when several ranks start together
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not os.path.exists(LIB_PATH):
+            print(f"[psi-gnn_amd] {os.path.basename(LIB_PATH)} missing: building it with {hipcc} (make -C {csrc})", flush=True)
+            subprocess.run(["make", "-C", csrc, "-j8", f"HIPCC={hipcc}"], check=False, stdout=subprocess.DEVNULL)
 
 
 def lib():
