@@ -192,22 +192,22 @@ struct MapM {  // flat [W1 (hid, din) | b1 | W2 (dout, hid) | b2]
   }
 };
 
-// sum of the per-block partial tiles (fixed order, fp64) scattered to the flat gradient
+// sum of the per-block partial tiles scattered to the flat gradient: 8 lanes per entry, each adds every 8th partial in
+// fp64, then three xor-shuffle steps -- a fixed order, so the result is reproducible.  Grid: nt * 8 blocks of 256.
 template <class Map>
 __global__ __launch_bounds__(256) void k_pgrad_reduce(int nblk, int nt, const float* __restrict__ part,
                                                       float* __restrict__ grad, Map map) {
-  const int e = blockIdx.x * 256 + threadIdx.x;  // < nt * 256
+  const int e = blockIdx.x * 32 + (threadIdx.x >> 3);  // < nt * 256
+  const int sub = threadIdx.x & 7;
   const int t = e >> 8, i = (e >> 4) & 15, j = e & 15;
   const int off = map(t, i, j);
-  if (off < 0) return;
-  double s0 = 0.0, s1 = 0.0;
-  int b = 0;
-  for (; b + 1 < nblk; b += 2) {
-    s0 += (double)part[(int64_t)b * nt * 256 + e];
-    s1 += (double)part[(int64_t)(b + 1) * nt * 256 + e];
-  }
-  if (b < nblk) s0 += (double)part[(int64_t)b * nt * 256 + e];
-  grad[off] = (float)(s0 + s1);
+  double s = 0.0;
+  if (off >= 0)
+    for (int b = sub; b < nblk; b += 8) s += (double)part[(int64_t)b * nt * 256 + e];
+  s += __shfl_xor(s, 4);
+  s += __shfl_xor(s, 2);
+  s += __shfl_xor(s, 1);
+  if (sub == 0 && off >= 0) grad[off] = (float)s;
 }
 
 static inline int pgrad_blocks(int64_t N, int* nodes_per_wave) {
@@ -249,7 +249,7 @@ extern "C" int psignn_f_param_vjp_p(const psignn_plan_t* p, const float* W, int 
   if (rc) return rc;
   HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)WLayout<2>::base_total(nl, false) * 4, st));
   LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabF><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
-  LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabF::NT, 256, 0, st>>>(nblk, TabF::NT, part, d_grad, MapF())));
+  LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabF::NT * 8, 256, 0, st>>>(nblk, TabF::NT, part, d_grad, MapF())));
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }
@@ -286,12 +286,12 @@ extern "C" int psignn_f_vjp_backward(const psignn_plan_t* p, const float* W, int
     float* part = rec + 2 * N * TabX::NG * 16;
     HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)WLayout<3>::base_total(nl, true) * 4, st));
     LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabX><<<nblk, 256, 0, st>>>(2 * N, npw, rec, part)));
-    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabX::NT, 256, 0, st>>>(nblk * 4, TabX::NT, part, d_grad, MapX())));
+    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabX::NT * 8, 256, 0, st>>>(nblk * 4, TabX::NT, part, d_grad, MapX())));
   } else {
     float* part = rec + 2 * N * TabF::NG * 16;
     HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)WLayout<2>::base_total(nl, false) * 4, st));
     LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabF><<<nblk, 256, 0, st>>>(2 * N, npw, rec, part)));
-    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabF::NT, 256, 0, st>>>(nblk, TabF::NT, part, d_grad, MapF())));
+    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabF::NT * 8, 256, 0, st>>>(nblk, TabF::NT, part, d_grad, MapF())));
   }
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
@@ -380,11 +380,11 @@ extern "C" int psignn_dsgps_step_backward(const psignn_plan_t* p, const float* d
   if (p->mixed) {
     float* part = rec + N * TabGX::NG * 16;
     LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabGX><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
-    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabGX::NT, 256, 0, st>>>(nblk * 4, TabGX::NT, part, d_grad, MapG<3>())));
+    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabGX::NT * 8, 256, 0, st>>>(nblk * 4, TabGX::NT, part, d_grad, MapG<3>())));
   } else {
     float* part = rec + N * TabG::NG * 16;
     LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabG><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
-    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabG::NT, 256, 0, st>>>(nblk * 4, TabG::NT, part, d_grad, MapG<2>())));
+    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabG::NT * 8, 256, 0, st>>>(nblk * 4, TabG::NT, part, d_grad, MapG<2>())));
   }
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
@@ -420,7 +420,7 @@ extern "C" int psignn_dss_step_backward(const psignn_plan_t* p, const float* d_w
   if (rc) return rc;
   HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)psignn_dss_grad_size() * 4, st));
   LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabF><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
-  LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabF::NT, 256, 0, st>>>(nblk, TabF::NT, part, d_grad, MapX())));
+  LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabF::NT * 8, 256, 0, st>>>(nblk, TabF::NT, part, d_grad, MapX())));
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }
@@ -506,7 +506,7 @@ extern "C" int psignn_mlp2_backward(const float* x, const float* gy, int64_t n, 
   const int nblk = pgrad_blocks(n, &npw);
   LAUNCH("k_mlp2_bwd", st, (k_mlp2_bwd<<<(unsigned)cdiv(n, (int64_t)256), 256, 0, st>>>(n, din, hid, dout, x, gy, w1, b1, w2, d_gx, rec)));
   LAUNCH("k_pgrad_outer_mlp", st, (k_pgrad_outer<TabM><<<nblk, 256, 0, st>>>(n, npw, rec, part)));
-  LAUNCH("k_pgrad_reduce_mlp", st, (k_pgrad_reduce<<<TabM::NT, 256, 0, st>>>(nblk, TabM::NT, part, d_gflat, MapM{din, hid, dout})));
+  LAUNCH("k_pgrad_reduce_mlp", st, (k_pgrad_reduce<<<TabM::NT * 8, 256, 0, st>>>(nblk, TabM::NT, part, d_gflat, MapM{din, hid, dout})));
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }
@@ -567,12 +567,12 @@ extern "C" int psignn_f_param_vjp(const psignn_plan_t* p, const float* W, int nl
     float* part = rec + N * TabX::NG * 16;
     HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)WLayout<3>::base_total(nl, true) * 4, st));
     LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabX><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
-    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabX::NT, 256, 0, st>>>(nblk * 4, TabX::NT, part, d_grad, MapX())));
+    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabX::NT * 8, 256, 0, st>>>(nblk * 4, TabX::NT, part, d_grad, MapX())));
   } else {
     float* part = rec + N * TabF::NG * 16;
     HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)WLayout<2>::base_total(nl, false) * 4, st));
     LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabF><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
-    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabF::NT, 256, 0, st>>>(nblk, TabF::NT, part, d_grad, MapF())));
+    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabF::NT * 8, 256, 0, st>>>(nblk, TabF::NT, part, d_grad, MapF())));
   }
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;

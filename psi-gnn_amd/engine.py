@@ -491,25 +491,29 @@ def dsgps_step_p(plan: "MeshPlan", wflat, hp, h0p, prbp, nrmp=None):
     return out
 
 
+# f_theta layouts (csrc/common.h WLayout<P>): shared 64 | layer 0 = phi_to 350 | phi_from 350 | update 10 (30+P) + 120 | fold 244
+# [| phi_neumann 350 | update_neumann 370 | nfold 112]
+_FL_PHI_TO, _FL_PHI_FROM = 64, 414
+_FL_MIXED_PHI_NEU, _FL_MIXED_UPD_NEU = 64 + 700 + 450 + 244, 64 + 700 + 450 + 244 + 350
+
+
 def pack_dsgps_train(sd, device):
     """(Phi modules -- mixed: and update_neumann -- in the f_theta weight layout, gates [Wz|bz|Wr|br|Wc|bc]) for
-    ``psignn_dsgps_step_backward``.  The f_theta layout is produced by ``pack_weights`` from a state dict that carries the
-    DS-GPS modules under the f_theta names (the remaining f_theta blocks are zero and never read)."""
+    ``psignn_dsgps_step_backward``.  Assembled on the device (no host round trip: this runs once per training forward); only
+    the blocks the backward kernels read are filled."""
     mixed = "phi_neumann.mlp.mlp.0.weight" in sd
-    p = 3 if mixed else 2
-    F = "deqdss.f."
-    fake = {F + "laynorm.weight": torch.ones(D), F + "laynorm.bias": torch.zeros(D),
-            F + "alpha.0.weight": torch.zeros(1, 3 * D + p), F + "alpha.0.bias": torch.zeros(1),
-            F + "update_list.0.mlp.0.weight": torch.zeros(D, 3 * D + p), F + "update_list.0.mlp.0.bias": torch.zeros(D),
-            F + "update_list.0.mlp.2.weight": torch.zeros(D, D), F + "update_list.0.mlp.2.bias": torch.zeros(D)}
-    for src, dst in (("phi_to", "phi_to_list.0"), ("phi_from", "phi_from_list.0")) + ((("phi_neumann", "phi_neumann"),) if mixed else ()):
-        for k in ("mlp.mlp.0.weight", "mlp.mlp.0.bias", "mlp.mlp.2.weight", "mlp.mlp.2.bias"):
-            fake[f"{F}{dst}.{k}"] = sd[f"{src}.{k}"]
-    if mixed:
-        for k in ("mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias"):
-            fake[f"{F}update_neumann.{k}"] = sd[f"update_neumann.{k}"]
-    wf = pack_weights(fake, device)
     g = lambda k: sd[k].detach().to(device, torch.float32).reshape(-1)
+    n = int(nat.lib().psignn_weights_size(int(mixed), 1))
+    if mixed and int(nat.lib().psignn_param_grad_size(1, 1)) != _FL_MIXED_UPD_NEU + 370 + 112:
+        raise nat.NativeError("f_theta weight layout changed: update engine._FL_* offsets")
+    wf = torch.zeros(n, dtype=torch.float32, device=device)
+    blocks = [("phi_to", _FL_PHI_TO), ("phi_from", _FL_PHI_FROM)] + ([("phi_neumann", _FL_MIXED_PHI_NEU)] if mixed else [])
+    for m, o in blocks:
+        blk = torch.cat([g(f"{m}.mlp.mlp.0.weight"), g(f"{m}.mlp.mlp.0.bias"), g(f"{m}.mlp.mlp.2.weight"), g(f"{m}.mlp.mlp.2.bias")])
+        wf[o:o + blk.numel()] = blk
+    if mixed:
+        blk = torch.cat([g(f"update_neumann.mlp.{q}") for q in ("0.weight", "0.bias", "2.weight", "2.bias")])
+        wf[_FL_MIXED_UPD_NEU:_FL_MIXED_UPD_NEU + blk.numel()] = blk
     wg = torch.cat([g(f"{m}.mlp.0.{q}") for m in ("z_k", "r_k", "correction") for q in ("weight", "bias")])
     return wf, wg
 
@@ -558,13 +562,13 @@ _DSS_PHI_TO, _DSS_PHI_FROM, _DSS_PSI = 64, 414, 764
 def pack_dss_train(sd, t, device):
     """Update t's modules in the f_theta weight layout for ``psignn_dss_step_backward``: the (10, 21) first Phi layers padded
     to (10, 23) (edge-feature weight in column 22, the plan carries the scalar feature in the third attr column), Psi in
-    the update slots."""
+    the update slots.  Assembled on the device (it runs once per update in the backward pass)."""
     n = int(nat.lib().psignn_dss_grad_size())
-    wf = torch.zeros(n, dtype=torch.float32)
-    g = lambda k: sd[k].detach().to("cpu", torch.float32)
+    wf = torch.zeros(n, dtype=torch.float32, device=device)
+    g = lambda k: sd[k].detach().to(device, torch.float32)
     for name, o in ((f"phi_to_list.{t}", _DSS_PHI_TO), (f"phi_from_list.{t}", _DSS_PHI_FROM)):
         w1 = g(f"{name}.mlp.mlp.0.weight")
-        w1p = torch.zeros(D, 2 * D + 3)
+        w1p = torch.zeros(D, 2 * D + 3, dtype=torch.float32, device=device)
         w1p[:, :2 * D], w1p[:, 2 * D + 2] = w1[:, :2 * D], w1[:, 2 * D]
         blk = torch.cat([w1p.reshape(-1), g(f"{name}.mlp.mlp.0.bias"), g(f"{name}.mlp.mlp.2.weight").reshape(-1),
                          g(f"{name}.mlp.mlp.2.bias")])
@@ -572,7 +576,7 @@ def pack_dss_train(sd, t, device):
     psi = f"psi_list.{t}.mlp.mlp"
     blk = torch.cat([g(f"{psi}.0.weight").reshape(-1), g(f"{psi}.0.bias"), g(f"{psi}.2.weight").reshape(-1), g(f"{psi}.2.bias")])
     wf[_DSS_PSI:_DSS_PSI + blk.numel()] = blk
-    return wf.to(device)
+    return wf
 
 
 def unpack_dss_grads(flat, t):
