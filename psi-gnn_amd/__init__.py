@@ -31,6 +31,8 @@ def load_reference_checkpoint(path, map_location="cpu"):
     install_reference_aliases()
     from .utilities import solver
     # the pickle names the function by the reference's module path; map that path to our implementation
-    torch.serialization.add_safe_globals(
-        [(getattr(solver, n), f"utilities.solver.{n}") for n in ("broyden", "anderson", "forward_iteration", "newton")])
+    fns = [getattr(solver, n) for n in ("broyden", "anderson", "forward_iteration", "newton")]
+    # the reference pickles the solver as utilities.solver.<name>; checkpoints written by training_class.TrainModel here carry
+    # this package's own module path
+    torch.serialization.add_safe_globals(fns + [(f, f"utilities.solver.{f.__name__}") for f in fns])
     return torch.load(path, map_location=map_location, weights_only=True)

@@ -29,6 +29,7 @@ def main():
     epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 15
     out_dir = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "train_demo")
     which = sys.argv[4] if len(sys.argv) > 4 else "psignn"
+    sched = float(sys.argv[5]) if len(sys.argv) > 5 else 0.5   # 0.8 in the recorded run of the reference's checkpoint
     os.makedirs(out_dir, exist_ok=True)
     torch.manual_seed(1234)
     np.random.seed(1234)
@@ -48,8 +49,8 @@ def main():
     tr = TrainModel({"model": model, "config_model": cfg,
                      "loader_train": loader.DataListLoader(train, batch_size=50, shuffle=True),
                      "loader_val": loader.DataListLoader(val, batch_size=50, shuffle=False),
-                     "sup_weight": 0.0, "jac_weight": 1.0, "gradient_clip": 0.1, "lr_deq": 0.01, "sched_step_deq": 0.5,
-                     "lr_ae": 0.05, "sched_step_ae": 0.5, "max_epochs": epochs, "min_loss_save": 1e5, "path_ckpt": out_dir})
+                     "sup_weight": 0.0, "jac_weight": 1.0, "gradient_clip": 0.1, "lr_deq": 0.01, "sched_step_deq": sched,
+                     "lr_ae": 0.05, "sched_step_ae": sched, "max_epochs": epochs, "min_loss_save": 1e5, "path_ckpt": out_dir})
     t0 = time.perf_counter()
     tr.train_model()
     torch.cuda.synchronize()
@@ -63,7 +64,19 @@ def main():
         n = [int(r[1]) for r in rows if len(r) == 2]
         return {"solves": len(n), "mean_nstep": float(np.mean(n)), "max_nstep": int(np.max(n))} if n else None
     nodes = sum(int(g.x.shape[0]) for g in train)
-    print(json.dumps({
+    # held-out test split (the last 20 %), protocol of test_func.py:68-120: the model just trained (best checkpoint by
+    # validation residual) next to the reference's checkpoint on the same graphs
+    ev = pkg("evaluation")
+    test = graphs[n_tr + n_va:]
+    report = {}
+    best = pkg().load_reference_checkpoint(os.path.join(out_dir, "best_model.pt"))["state_dict"]   # weights_only=True
+    w = np.load(os.path.join(ROOT, "tests", "golden", "weights_dirichlet.npz"))
+    for tag, sd in (("trained_here", best), ("reference_checkpoint", {k: torch.from_numpy(w[k]) for k in w.files})):
+        m = pkg("model_psignn").ModelPSIGNN(dict(latent_dim=10, n_layers=1, fw_tol=1e-5, fw_thres=500))
+        m.load_state_dict(sd)
+        rep = ev.test_dataset(m.to(dev).eval(), test, dev, batch_size=50)
+        report[tag] = {"mean": rep["mean"], "std": rep["std"], "graphs": rep["graphs"]}
+    print(json.dumps({"test_set": report,
         "workload": f"{n_tr} training / {n_va} validation hexagon meshes (n = 9..14, {nodes} training nodes), batch 50, "
                     f"{epochs} epochs from xavier initialisation, reference launch_local.sh hyper-parameters (jac_weight 1.0)",
         "seconds_total": dt, "seconds_per_epoch": dt / epochs,
