@@ -240,3 +240,18 @@ def test_dss_schema_collates():
     for k in ("a_ij_norm", "b_prime", "b_prime_norm", "edge_index", "batch"):
         assert torch.equal(getattr(a, k), getattr(b, k)), k
     assert a.num_graphs == 2 and int(b.batch.max()) == 1
+
+
+def test_checkpoints_written_here_load_with_weights_only(tmp_path):
+    """TrainModel pickles config_model["solver"] by this package's module path, the reference by ``utilities.solver.broyden``:
+    ``load_reference_checkpoint`` (weights_only=True) accepts both."""
+    top, solver = pkg(""), pkg("utilities.solver")
+    cfg = dict(latent_dim=10, n_layers=1, solver=solver.broyden, fw_tol=1e-5, fw_thres=10, bw_tol=1e-6, bw_thres=10, path_logs=None)
+    net = pkg("model_psignn").ModelDEQDSS(cfg)
+    tr = pkg("training_class").TrainModel(dict(loader_train=[], loader_val=[], model=net, config_model=cfg, lr_deq=1e-3, lr_ae=1e-3,
+                                              sched_step_deq=0.5, sched_step_ae=0.5, path_ckpt=str(tmp_path), min_loss_save=1e9,
+                                              max_epochs=0, gradient_clip=0.1, sup_weight=0.0, jac_weight=1.0))
+    tr.save_model(tr.checkpoint(0), dirName=str(tmp_path), model_name="m")
+    ck = top.load_reference_checkpoint(str(tmp_path / "m.pt"))
+    assert ck["hyperparameters"]["solver"] is solver.broyden
+    assert set(ck["state_dict"]) == set(net.state_dict())
