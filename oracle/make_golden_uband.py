@@ -1,0 +1,60 @@
+"""Spread of the reference CPU path's OWN decoded-solution error at the tight tolerance (fw_tol = 1e-7).
+
+Test infrastructure (build container only).  north_star asks for the converged solution within 1e-5 relative L2 and an
+error <= the reference's.  At eps = 1e-7 the Broyden iteration stops somewhere inside a ball of radius ~ eps / (1 - rho(J))
+~ 1e-5 around the fixed point, and WHERE depends on the fp32 trajectory: the reference CPU path's error is one sample of a
+distribution, not a number.  This script measures that distribution: the oracle's broyden (bit-identical to the reference's
+solver.py on these fixtures, oracle/make_golden.py) is run on each fixture from the encoder state perturbed by 1e-7
+relative noise (one fp32 ulp), 12 seeds; the decoded u and the node states h are compared with the fp64 fixed point stored
+in the golden file.  Output: tests/golden/u_error_band.json {fixture: {"u": [errors], "h": [errors]}} -- the gate in
+tests/test_gpu_parity.py::test_converged_solution_within_1e5_of_fp64_fixed_point uses max(u) as "the reference's error".
+
+    python oracle/make_golden_uband.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import CASES, load_case, load_weights, rel_l2  # noqa: E402
+from oracle import psignn_oracle as orc  # noqa: E402
+
+FIXTURES = ["original_dirichlet_s0", "hex13_dirichlet_s0", "hex13_mixed_s1", "hex26_dirichlet_s0"]
+SEEDS = 12
+
+
+def main():
+    torch.set_num_threads(8)
+    out = {}
+    for name in FIXTURES:
+        g, mesh = load_case(name)
+        sd = load_weights(CASES[name])
+        h0 = torch.from_numpy(g["h0"])
+        eu, eh, ns, low = [], [], [], []
+        for seed in range(SEEDS):
+            gen = torch.Generator().manual_seed(1000 + seed)
+            x0 = h0 if seed == 0 else h0 * (1 + 1e-7 * torch.randn(h0.shape, generator=gen))
+            with torch.no_grad():
+                r = orc.broyden(lambda H: orc.function_forward(sd, H, h0, mesh), x0, threshold=1000, eps=1e-7)
+                u = orc.decoder(sd, r["result"])
+            eu.append(rel_l2(u, g["fp64_u"]))
+            eh.append(rel_l2(r["result"], g["fp64_result"]))
+            ns.append(int(r["nstep"]))
+            low.append(float(r["lowest"]))
+        print(f"{name}: u error {min(eu):.2e} .. {max(eu):.2e} (unperturbed {eu[0]:.2e}); h {min(eh):.2e} .. {max(eh):.2e}; nstep {min(ns)}..{max(ns)}")
+        conv = [i for i in range(SEEDS) if low[i] < 1e-7]   # runs that met the tolerance (a plateau stop is not a sample)
+        out[name] = {"u": eu, "h": eh, "nstep": ns, "lowest": low, "converged": conv,
+                     "u_max_converged": max(eu[i] for i in conv), "h_max_converged": max(eh[i] for i in conv)}
+        print(f"   converged {len(conv)}/{SEEDS}: u max {out[name]['u_max_converged']:.2e}, h max {out[name]['h_max_converged']:.2e}")
+    with open(os.path.join(ROOT, "tests", "golden", "u_error_band.json"), "w") as f:
+        json.dump({"_doc": "oracle/make_golden_uband.py: reference-CPU-path errors vs the fp64 fixed point at eps=1e-7, "
+                           "seed 0 = unperturbed start, others = 1e-7 relative noise on x0", **out}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

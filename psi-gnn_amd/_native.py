@@ -133,7 +133,11 @@ def _build_once():
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not os.path.exists(LIB_PATH):
             print(f"[psi-gnn_amd] {os.path.basename(LIB_PATH)} missing: building it with {hipcc} (make -C {csrc})", flush=True)
-            subprocess.run(["make", "-C", csrc, "-j8", f"HIPCC={hipcc}"], check=False, stdout=subprocess.DEVNULL)
+            r = subprocess.run(["make", "-C", csrc, "-j8", f"HIPCC={hipcc}"], stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0 or not os.path.exists(LIB_PATH):
+                raise NativeError(f"building {LIB_PATH} failed (make exit code {r.returncode}); last lines of its output:\n"
+                                  + "\n".join(r.stdout.splitlines()[-25:]))
 
 
 def lib():

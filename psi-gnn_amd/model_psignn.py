@@ -349,9 +349,10 @@ class _Base(nn.Module):
         return h_initial, out
 
     @torch.no_grad()
-    def _diagnostics(self, u_final, h_final, batch, key_dir):
+    def _diagnostics(self, u_final, h_final, batch, key_dir, idx=None):
         enc = self.autoencoder.encoder(u_final)
-        idx = self._dirichlet_index(batch)
+        if idx is None:
+            idx = self._dirichlet_index(batch)
         return {
             "residual_loss": self.residual_loss(u_final, batch),
             "encoder_loss": self.mse_loss(enc, h_final),
@@ -424,7 +425,9 @@ class ModelDEQDSS(_Base):
             h_initial = self.autoencoder.encoder(batch.x)
             h_final, jacobian_loss = self.deqdss.train_forward(h_initial, batch)
             u_final = self.autoencoder.decoder(h_final)
-            loss_dic = self._diagnostics(u_final, h_final, batch, "mse_dirichlet")
+            # ModelDEQDSS.forward is ONE function for both modes: its Dirichlet statistic uses where(tags == 1)[0] also on
+            # the mixed family's one-hot (N, 3) tags, i.e. every row (mixed/psignn/model.py:87) -- as _train_forward below
+            loss_dic = self._diagnostics(u_final, h_final, batch, "mse_dirichlet", idx=torch.where(batch.tags == 1)[0])
             loss_dic["jacobian_loss"] = jacobian_loss
             return u_final, loss_dic
 

@@ -145,15 +145,35 @@ class TrainModel:
         dist.all_reduce(t)
         return (t / dist.get_world_size()).tolist()
 
+    @staticmethod
+    def _common_batches(n_local, what):
+        """Batches every rank steps through this epoch.  Each train step ends in a gradient all-reduce, so all ranks must
+        run the SAME number of steps; round-robin shards differ by up to one batch (5 meshes over 2 ranks: 3 and 2).  The
+        epoch is cut to the smallest shard (drop_last semantics, one MIN/MAX all-reduce per epoch); a rank without any
+        batch is an error, not a hang."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return n_local
+        t = torch.tensor([float(n_local), -float(n_local)], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        n_min, n_max = int(t[0].item()), int(-t[1].item())
+        if n_min <= 0:
+            raise RuntimeError(f"{what}: a rank holds no batch (local {n_local}, max over ranks {n_max}); "
+                               "give every rank at least one batch")
+        return n_min
+
     def train_loop(self, current_epoch):
         self.model.train()
-        n = len(self.loader_train)
+        n = self._common_batches(len(self.loader_train), "train_loop")
         KEYS = self.KEYS
         cumul = dict.fromkeys(KEYS, 0.0)
         run = dict.fromkeys(KEYS, 0.0)
         cnt = 0
         marks = {ceil(0.25 * n), ceil(0.5 * n), ceil(0.75 * n)}
         for i, batch in enumerate(self.loader_train):
+            if i >= n:
+                break   # uneven shards: the extra batch of the longer shards is dropped this epoch
             loss, loss_dic = self.train_step(batch)
             vals = {"loss": loss.item(), **{k: self._value(loss_dic, k) for k in KEYS[1:]}}
             for k in KEYS:
@@ -212,6 +232,10 @@ class TrainModel:
             self._write("\nCurrent Learning rate AUTOENC : {}".format(self.opt_ae.param_groups[0]["lr"]))
             if saved:
                 self._write("\nMODEL SAVED")
+        # the reference saves the last checkpoint once more as final_model and returns the model (training_class.py:332-335)
+        if self._rank() == 0 and self.path_ckpt and self.max_epochs > 0 and len(self.hist_train["loss"]) > 0:
+            self.save_model(self.checkpoint(len(self.hist_train["loss"]) - 1), dirName=self.path_ckpt, model_name="final_model")
+        return self.model
 
 
 class TrainModelDSGPS(TrainModel):
@@ -280,6 +304,9 @@ class TrainModelDSGPS(TrainModel):
             self._write("\nCurrent Learning rate : {}".format(self.opt.param_groups[0]["lr"]))
             if saved:
                 self._write("\nMODEL SAVED")
+        if self._rank() == 0 and self.path_ckpt and len(self.hist_train["loss"]) > 0:
+            self.save_model(self.checkpoint(len(self.hist_train["loss"]) - 1), dirName=self.path_ckpt, model_name="final_model")
+        return self.model
 
 
 class TrainModelDSS(TrainModelDSGPS):

@@ -77,11 +77,20 @@ def split_indices(n, mode, shuffle=False, seed=None):
     return {"train": train, "val": val, "test": test, "all": idx}[mode]
 
 
-def load_raw_dir(root, mode="test", mixed=False, shuffle=None, seed=None, dtype=torch.float32):
-    """``<root>/data/*.npy`` as written by the reference's ``generate_data.py`` -> list of ``MeshData``."""
+def load_raw_dir(root, mode="test", mixed=False, shuffle=None, seed=None, dtype=torch.float32, allow_pickle=False):
+    """``<root>/data/*.npy`` as written by the reference's ``generate_data.py`` -> list of ``MeshData``.
+
+    Those files are pickled object arrays (lists of scipy CSR matrices and ragged arrays), which numpy can only read by
+    UNPICKLING -- i.e. by running code from the file.  That is never done implicitly: the default ``allow_pickle=False``
+    makes numpy refuse such files with its own error, and only a caller who generated the files themselves opts in with
+    ``allow_pickle=True``.  Plain numeric ``.npy`` / ``.npz`` exports load without it."""
     raw = os.path.join(root, "data")
     names = RAW_FILES_MIXED if mixed else RAW_FILES
-    lists = [np.load(os.path.join(raw, f), allow_pickle=True) for f in names]  # the user's own generated files
+    try:
+        lists = [np.load(os.path.join(raw, f), allow_pickle=bool(allow_pickle)) for f in names]
+    except ValueError as e:
+        raise ValueError(f"{e}.  The reference's raw dataset files are pickled object arrays; pass allow_pickle=True only for "
+                         "files you generated yourself") from e
     n = len(lists[0])
     if shuffle is None:
         shuffle = mixed

@@ -1,0 +1,149 @@
+"""GPU parity at the sizes BASELINE.json names (configs[1..4]), through the C ABI, against the CPU oracle.
+
+configs[2]  mixed/psignn, 100k-node mesh, full on-device Broyden        -> test_config2_mixed_100k
+configs[3]  64 x 50k-node dirichlet meshes, 8 per GPU                   -> test_config3_shard_of_eight_50k_meshes
+configs[4]  single 1M-node mesh                                          -> test_config4_1m_f_vs_oracle,
+                                                                            test_mixed_two_group_launch_at_natural_size
+The oracle is evaluated in full at these sizes (one CPU f call: 0.1 s at 100k nodes, ~1-2 s at 1M)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_weights, pkg, rel_l2
+from oracle import psignn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _fmap(mesh, sd, dev):
+    eng = pkg("engine")
+    md = mesh.to(dev)
+    with torch.no_grad():
+        h0 = orc.encoder(sd, mesh.x)
+    plan = eng.MeshPlan(md)
+    fm = eng.FixedPointMap(plan, eng.PackedWeights(sd, dev), h0.to(dev), md.prb_data, getattr(md, "unit_normal_vector", None))
+    return md, h0, plan, fm
+
+
+def test_config2_mixed_100k(dev):
+    """BASELINE configs[2]: mixed/psignn on the 99 919-node hexagon (alternating Dirichlet / Neumann sides).
+    One f vs the full oracle <= 2e-6; the first iterations of the on-device Broyden solve follow the oracle's solver
+    (reference utilities/solver.py:116-207, mixed/psignn/model.py:216-245) on the same mesh."""
+    data, solver = pkg("data"), pkg("utilities.solver")
+    sd = load_weights("mixed")
+    mesh = data.make_hex_problem(182, seed=0, mixed=True, compute_sol=False)
+    assert mesh.num_nodes == 99919 and mesh.tags.shape[1] == 3
+    md, h0, plan, fm = _fmap(mesh, sd, dev)
+    assert plan.tiled and plan.mixed
+    f_cpu = lambda H: orc.function_forward(sd, H, h0, mesh)
+    with torch.no_grad():
+        want1 = f_cpu(h0.clone())
+        want2 = f_cpu(want1)
+    got1 = fm(fm.h0)
+    assert rel_l2(got1, want1) < 2e-6, rel_l2(got1, want1)
+    assert rel_l2(fm(want1.to(dev)), want2) < 2e-6
+    # Neumann rows are REPLACED by update_neumann (mixed/psignn/model.py:236,241), Dirichlet rows copied bit-exactly (:243)
+    d_idx = (mesh.tags[:, 1] == 1).nonzero()[:, 0]
+    n_idx = (mesh.tags[:, 2] == 1).nonzero()[:, 0]
+    assert len(d_idx) > 100 and len(n_idx) > 100
+    assert torch.equal(got1.cpu()[d_idx], h0[d_idx])
+    assert rel_l2(got1.cpu()[n_idx], want1[n_idx]) < 2e-6
+    # full on-device Broyden: K = 12 iterations against the oracle's solver on the same mesh
+    K = 12
+    with torch.no_grad():
+        ref = orc.broyden(f_cpu, h0, threshold=K, eps=1e-12)
+    out = solver.broyden(fm, fm.h0, threshold=K, eps=1e-12, keep_trace=True)
+    assert out["n_iter"] == K and out["stop_reason"] == 0
+    np.testing.assert_allclose(out["rel_trace"][:8], ref["rel_trace"][:8], rtol=5e-3)
+    np.testing.assert_allclose(out["rel_trace"][:K], ref["rel_trace"][:K], rtol=5e-2)
+    assert rel_l2(out["xest_trace"][3], ref["xest_trace"][3]) < 1e-5      # early iterates: same trajectory
+    assert out["rel_trace"][K - 1] < 0.2 * out["rel_trace"][0]
+    # a real solve at the reference's operating point converges and reproduces its own residual
+    run = solver.broyden(fm, fm.h0, threshold=300, eps=1e-3, keep_trace=False)
+    fx = fm(run["result"])
+    rel = float((fx - run["result"]).norm() / (fx.norm() + 1e-9))
+    assert abs(rel - run["lowest"]) < 1e-3 * run["lowest"] + 1e-9
+
+
+def test_mixed_two_group_launch_at_natural_size(dev, monkeypatch):
+    """A mixed mesh large enough (>= 2 048 tiles without Neumann nodes) that the f kernel takes the two-group launch on
+    its own (csrc/fgnn_tile.hip launch_mixed): bit-equal to the single-launch form, and <= 2e-6 from the oracle."""
+    data, eng, solver = pkg("data"), pkg("engine"), pkg("utilities.solver")
+    sd = load_weights("mixed")
+    mesh = data.make_hex_problem(440, seed=2, mixed=True, compute_sol=False)      # 582 121 nodes
+    md, h0, plan, fm = _fmap(mesh, sd, dev)
+    has_neu = np.zeros(plan.n_tiles, dtype=bool)
+    tp, flags_p = plan.export("tile_ptr"), plan.export("node_flags")[plan.export("perm")]
+    for t in range(plan.n_tiles):
+        has_neu[t] = bool((flags_p[tp[t]:tp[t + 1]] & 2).any())
+    assert (~has_neu).sum() >= 2048 and has_neu.sum() > 0, ((~has_neu).sum(), has_neu.sum())
+    monkeypatch.delenv("PSIGNN_MIXED_SPLIT_MIN", raising=False)
+    x = 0.7 * fm.h0
+    two = fm(x)                                              # natural: two-group launch
+    s2 = solver.broyden(fm, fm.h0, threshold=6, eps=1e-12, keep_trace=False)
+    monkeypatch.setenv("PSIGNN_MIXED_SPLIT_MIN", "100000000")
+    one = fm(x)                                              # forced single launch (full kernel on every tile)
+    s1 = solver.broyden(fm, fm.h0, threshold=6, eps=1e-12, keep_trace=False)
+    monkeypatch.delenv("PSIGNN_MIXED_SPLIT_MIN")
+    assert torch.equal(one, two)
+    assert s1["rel_trace"][:6] == s2["rel_trace"][:6] and torch.equal(s1["result"], s2["result"])
+    with torch.no_grad():
+        want = orc.function_forward(sd, 0.7 * h0, h0, mesh)
+    assert rel_l2(two, want) < 2e-6, rel_l2(two, want)
+
+
+def test_config3_shard_of_eight_50k_meshes(dev):
+    """BASELINE configs[3]: one GPU's share of the 64 x 50k batch = 8 independent 50 311-node meshes.  The concurrent
+    form (8 HIP streams / host threads) and the batched device solver give bit-identical results to solving the meshes
+    one after the other; one of them is checked against the oracle's f and the oracle's first Broyden iterations."""
+    data, batch = pkg("data"), pkg("batch")
+    sd = load_weights("dirichlet")
+    net = pkg("model_psignn").ModelPSIGNN(dict(latent_dim=10, n_layers=1, fw_tol=1e-4, fw_thres=60))
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    meshes = [data.make_hex_problem(129, seed=s, compute_sol=False, phase=0.37 * s) for s in range(8)]
+    assert all(m.num_nodes == 50311 for m in meshes)
+    seq = batch.solve_shard(net, meshes, dev)
+    par = batch.solve_shard(net, meshes, dev, streams=8)
+    assert [r[0] for r in par] == list(range(8))
+    for a, b in zip(seq, par):
+        assert torch.equal(a[1], b[1]) and a[2]["nsteps"] == b[2]["nsteps"]
+        assert float(a[2]["residual_loss"]) == float(b[2]["residual_loss"])
+    assert len({r[2]["nsteps"] for r in seq}) > 1 or len({float(r[2]["residual_loss"]) for r in seq}) == 8  # distinct problems
+    # mesh 5 against the oracle: f, and the first Broyden iterations of the full solve
+    m = meshes[5]
+    md, h0, plan, fm = _fmap(m, sd, dev)
+    f_cpu = lambda H: orc.function_forward(sd, H, h0, m)
+    with torch.no_grad():
+        assert rel_l2(fm(fm.h0), f_cpu(h0.clone())) < 2e-6
+        ref = orc.broyden(f_cpu, h0, threshold=10, eps=1e-12)
+    out = pkg("utilities.solver").broyden(fm, fm.h0, threshold=10, eps=1e-12, keep_trace=False)
+    np.testing.assert_allclose(out["rel_trace"][:8], ref["rel_trace"][:8], rtol=5e-3)
+
+
+def test_config4_1m_f_vs_oracle(dev):
+    """BASELINE configs[4] size: the 1 000 519-node Dirichlet mesh of the headline bench.  One f evaluation against the
+    full oracle (dirichlet/psignn/model.py:279-300 restated), in the caller's numbering and in plan order; Dirichlet rows
+    bit-exact; the analytic JVP against the oracle's autograd JVP."""
+    data = pkg("data")
+    sd = load_weights("dirichlet")
+    mesh = data.make_hex_problem(577, seed=0, compute_sol=False)
+    assert mesh.num_nodes == 1000519
+    md, h0, plan, fm = _fmap(mesh, sd, dev)
+    assert plan.tiled
+    with torch.no_grad():
+        want = orc.function_forward(sd, h0.clone(), h0, mesh)
+    got = fm(fm.h0)
+    e = rel_l2(got, want)
+    print("1M-node f vs oracle:", e)
+    assert e < 2e-6, e
+    assert rel_l2(fm.from_plan(fm.fp(fm.to_plan(fm.h0))), want) < 2e-6
+    d_idx = (mesh.tags[:, 0] == 1).nonzero()[:, 0]
+    assert torch.equal(got.cpu()[d_idx], h0[d_idx])
+    # a second point away from the encoder state (f of f), the state a solver iteration actually sees
+    with torch.no_grad():
+        want2 = orc.function_forward(sd, want, h0, mesh)
+    assert rel_l2(fm(want.to(dev)), want2) < 2e-6
+    v = torch.randn(mesh.num_nodes, 10, generator=torch.Generator().manual_seed(7))
+    jv_ref = orc.function_jvp(sd, want, h0, mesh, v)
+    assert rel_l2(fm.jvp(want.to(dev), v.to(dev)), jv_ref) < 1e-5

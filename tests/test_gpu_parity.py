@@ -232,22 +232,26 @@ def test_device_broyden_reference_operating_point(name, dev):
 def test_converged_solution_within_1e5_of_fp64_fixed_point(name, dev):
     """north_star gate: <= 1e-5 relative L2 on the converged node solution, error <= the reference CPU path's.
 
-    Measured on MI355X (scripts/calib_tolerances.py): node states h land 2e-7..6e-6 from the fp64 fixed point.
-    The decoded u amplifies that ~6x, and on two fixtures the reference CPU path itself (golden
-    broyden_e7_u, produced by the reference solver) is 3e-5..5e-5 away — the fp32 floor of f, not a solver
-    effect — so u is gated at max(1e-5, 2 x the reference CPU path's own error)."""
+    The solver's output -- the converged node states h* -- is gated at 1e-5 outright (measured 2e-7 .. 6e-6).
+    "<= the reference's error" needs a definition: at eps = 1e-7 the iteration stops somewhere inside a ball of radius
+    ~ eps / (1 - rho(J)) around the fixed point, and where depends on the chaotic fp32 trajectory, so the reference CPU
+    path's error is a sample of a distribution.  oracle/make_golden_uband.py measured it: the reference path started
+    from the encoder state +- one fp32 ulp of noise (12 runs per fixture) lands 8.3e-6 .. 1.12e-5 (decoded u, hex13) from
+    the fp64 fixed point; tests/golden/u_error_band.json holds the runs.  Gates: h <= 1e-5 and <= the worst converged
+    reference run; decoded u <= max(1e-5, worst converged reference run) -- no factor on top."""
+    import json
     g, mesh, md, sd, fmap = bind(name, dev)
     solver = pkg("utilities.solver")
     out = solver.broyden(fmap, fmap.h0, threshold=1000, eps=1e-7)
-    ref_h = rel_l2(g["broyden_e7_result"], g["fp64_result"])  # the reference CPU path's own error
-    ref_u = rel_l2(g["broyden_e7_u"], g["fp64_u"])
+    band = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "u_error_band.json")))[name]
+    ref_h, ref_u = band["h_max_converged"], band["u_max_converged"]
     err_h = rel_l2(out["result"], g["fp64_result"])
     err_u = rel_l2(orc.decoder(sd, out["result"].cpu()), g["fp64_u"])
+    print(f"{name}: h {err_h:.2e} (reference runs <= {ref_h:.2e}); u {err_u:.2e} (reference runs <= {ref_u:.2e})")
+    assert out["lowest"] < 1e-7
     assert err_h < 1e-5, (err_h, ref_h)
-    assert err_h <= max(1.6 * ref_h, 2e-6), (err_h, ref_h)
-    # where inside the eps = 1e-7 ball the iteration stops depends on the (chaotic) trajectory: the decoded error of
-    # the reference CPU path is itself one such sample, so it is a scale (x2), not a bound
-    assert err_u <= max(1e-5, 2.0 * ref_u), (err_u, ref_u)
+    assert err_h <= max(ref_h, 2e-6), (err_h, ref_h)
+    assert err_u <= max(1e-5, ref_u), (err_u, ref_u)
 
 
 def test_generic_callable_broyden_matches_oracle(dev):

@@ -161,6 +161,38 @@ def test_reader_reproduces_the_reference_schema():
     assert reader.split_indices(10, "test") == [8, 9]
 
 
+def test_raw_dir_loader_never_unpickles_by_default(tmp_path):
+    """The reference's raw dataset files are pickled object arrays (parity of the reader on such files is UNPINNED: the
+    reference ships none).  load_raw_dir must not unpickle unless the caller opts in."""
+    import pytest
+    import scipy.sparse as sp
+    data, reader = pkg("data"), pkg("utilities.reader")
+    hm = pkg("data.hexmesh")
+    raw = tmp_path / "data"
+    raw.mkdir()
+    cols = {n: [] for n in reader.RAW_FILES}
+    for seed in range(5):
+        m = data.make_hex_problem(3, seed=seed)
+        N = m.num_nodes
+        r, c = m.edge_index.numpy()
+        pos = m.pos.double().numpy()
+        d = pos[r] - pos[c]
+        vals = [sp.csr_matrix((m.a_ij[:, 0].double().numpy(), (r, c)), shape=(N, N)), m.y.numpy(), m.sol.numpy(),
+                m.prb_data.double().numpy() * hm.DIR_PRB_STD + hm.DIR_PRB_MEAN, m.tags.numpy(), pos,
+                np.concatenate([d, np.sqrt((d ** 2).sum(1, keepdims=True))], axis=1)]
+        for n, v in zip(reader.RAW_FILES, vals):
+            cols[n].append(v)
+    for n, v in cols.items():
+        a = np.empty(len(v), dtype=object)
+        a[:] = v
+        np.save(raw / n, a, allow_pickle=True)      # the reference's np.save of a Python list (generate_data.py:104-128)
+    with pytest.raises(ValueError, match="allow_pickle"):
+        reader.load_raw_dir(str(tmp_path), mode="all")
+    got = reader.load_raw_dir(str(tmp_path), mode="all", allow_pickle=True)   # our own files, written above
+    assert len(got) == 5 and torch.equal(got[2].edge_index, data.make_hex_problem(3, seed=2).edge_index)
+    assert len(reader.load_raw_dir(str(tmp_path), mode="test", allow_pickle=True)) == 1
+
+
 def test_dsgps_state_dict_and_packing():
     """ModelDSGPS has the reference's module tree (dirichlet/dsgps/model.py:28-45) and packs to the kernel layout."""
     w = np.load(os.path.join(os.path.dirname(__file__), "golden", "weights_dsgps.npz"))

@@ -99,3 +99,67 @@ def test_gradient_allreduce_two_ranks_gloo():
     (_, g0, s0), (_, g1, s1) = res
     assert g0 == g1 == [1.5 * (i + 1) for i in range(4)]
     assert s0 == s1 == [0.5, 15.0]
+
+
+class _ToyModel(torch.nn.Module):
+    """CPU stand-in with the trainer's surface: .deqdss / .autoencoder parameter groups and the loss dictionary of
+    ModelDEQDSS.forward (dirichlet/psignn/model.py:58-99).  The trainer's control flow is what is under test."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.deqdss = torch.nn.Linear(2, 1)
+        self.autoencoder = torch.nn.Linear(2, 1)
+        self.steps = 0
+
+    def forward(self, batch):
+        self.steps += 1
+        u = self.deqdss(batch) + self.autoencoder(batch)
+        z = torch.zeros(())
+        return u, {"residual_loss": (u ** 2).mean(), "jacobian_loss": z, "encoder_loss": (self.autoencoder(batch) ** 2).mean(),
+                   "autoencoder_loss": z, "mse_loss": z, "mse_dirichlet": z}
+
+
+def _uneven_worker(rank, world, port, tmp, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tc, batch = pkg("training_class"), pkg("batch")
+    g = torch.Generator().manual_seed(3)
+    data = [torch.randn(6, 2, generator=g) for _ in range(5)]
+    mine = [data[i] for i in batch.shard_indices(5, rank, world)]     # rank 0: 3 batches, rank 1: 2
+    net = _ToyModel()
+    tr = tc.TrainModel(dict(loader_train=mine, loader_val=mine[:1], model=net, config_model={}, lr_deq=1e-2, lr_ae=1e-2,
+                            sched_step_deq=0.5, sched_step_ae=0.5, path_ckpt=tmp, min_loss_save=1e9, max_epochs=2,
+                            gradient_clip=1.0, sup_weight=0.0, jac_weight=0.0))
+    ret = tr.train_model()
+    q.put((rank, len(mine), net.steps, [p.detach().reshape(-1).tolist() for p in net.parameters()],
+           len(tr.hist_train["loss"]), ret is net))
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_do_not_hang_two_ranks_gloo(tmp_path):
+    """5 batches over 2 ranks = 3 and 2: every train step ends in a gradient all-reduce, so both ranks must take the same
+    number of steps (the epoch is cut to the smallest shard); the weights stay identical across ranks; rank 0 writes
+    running / best / final checkpoints and train_model returns the model (reference training_class.py:296-335)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, n0, steps0, w0, h0, ret0), (_, n1, steps1, w1, h1, ret1) = res
+    assert (n0, n1) == (3, 2)
+    # per epoch: 2 train steps (the common count) + 1 validation forward
+    assert steps0 == steps1 == 2 * (2 + 1)
+    assert w0 == w1
+    assert h0 == h1 == 2 and ret0 and ret1
+    for f in ("running_model.pt", "best_model.pt", "final_model.pt"):
+        assert (tmp_path / f).exists(), f
+    ck = torch.load(tmp_path / "final_model.pt", weights_only=True)
+    assert ck["epoch"] == 1 and len(ck["hist_train"]["loss"]) == 2
