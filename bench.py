@@ -15,10 +15,20 @@ resident in HBM when the clock starts.  edges/s = E' x iterations/s (each edge c
 Phi_to and Phi_from both process it).  N > 1: every rank solves its own mesh (same topology, its own
 problem seed) with no data-path collective -> weak scaling; value = sum over ranks.
 
+The timed region (exactly K iterations, barrier + synchronize on both sides, MAX over ranks) is repeated --repeats times
+(default 5); `value` / `ms_per_step` are the MEDIAN repeat, the spread is reported beside them.  `value` depends on K --
+iteration k sweeps k stored pairs, as in the reference -- so the k-independent figures of the GNN block are in the same
+line: `f_only` (plain f, back-to-back evaluations) and `roofline_f`.
+
 One JSON line on stdout (rank 0).  Extra objects:
   roofline      dominant kernel (by time) : algorithmic bytes per launch / average launch duration
-                (HIP events on the launch stream, instrumented repeat of the same K steps)
-  roofline_f    the same for the GNN block f (k_project + k_node), the kernel north_star's 60 % target is about
+                (HIP events on the launch stream, instrumented repeat of the same K steps); `traffic` = HBM bytes per launch
+                from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes (profiles/pmc_traffic_model.json: per kernel a
+                linear model a + b k in the number of stored pairs, evaluated for this run's K)
+  roofline_f    the same for the GNN block f inside the loop (k_f_tile_fused: x + update, f, g, dg, norms in one kernel) --
+                the kernel north_star's 60 % target is about
+  f_only        plain f (k_f_tile), 100 back-to-back evaluations: us per evaluation, edges/s, fraction of the HBM peak
+  roofline_jvp  the analytic JVP kernel of the Newton-Krylov path (k_jvp_tile), 50 back-to-back products
   roofline_iter whole-iteration algorithmic bytes / un-instrumented wall time
   cpu_baseline  the CPU oracle (port of the reference path) timed on this box's host cores on a bounded sample
 """
@@ -63,6 +73,7 @@ def parse():
     ap.add_argument("--nodes", type=int, default=None, help="override the preset's per-mesh node count")
     ap.add_argument("--bc", choices=["dirichlet", "mixed"], default=None)
     ap.add_argument("--meshes-per-gpu", type=int, default=None)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps iterations each; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -82,6 +93,7 @@ def algorithmic_bytes(N, Ep, K, mixed):
         # f is two launches; the pair is priced with the fused-op figure B_f
         "f(k_project+k_node)": b_f,
         "k_xnext": 3 * M * 4, "k_resid": 5 * M * 4, "k_final": 4 * M * 4,
+        "jvp": b_f + 40 * N,                                        # + the tangent v (B_jvp)
     }
     # k-dependent sweeps: iteration it (0-based) has k = it stored pairs
     dots = [2 * k * M * 4 + 3 * M * 4 for k in range(1, K)]     # launched only when k > 0
@@ -90,6 +102,16 @@ def algorithmic_bytes(N, Ep, K, mixed):
     # whole iteration, BASELINE.md: B_broyden(k) = 16 k M + 48 M + B_f  (U and V swept twice, ~12 state-vector passes)
     total_iter = sum(16 * k * M + 48 * M + b_f for k in range(K)) + b_f
     return per_launch, dots, axpy, total_iter
+
+
+def _time_picard(fmap, xp, n, dev):
+    """ms per evaluation of n back-to-back x <- f(x) in plan order (one library call, no host work in between)."""
+    fmap.picard_p(xp, 3)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    fmap.picard_p(xp, n)
+    torch.cuda.synchronize(dev)
+    return 1e3 * (time.perf_counter() - t0) / n
 
 
 def main():
@@ -191,10 +213,15 @@ def main():
     solver = solvers[0]
     streams = [torch.cuda.Stream(dev) for _ in range(MPG)] if MPG > 1 else [None]
 
+    use_streams = os.environ.get("PSIGNN_BENCH_STREAMS", "0") == "1"   # round 1's form: one HIP stream + host thread per mesh
+
     def run_all():
-        """Exactly K Broyden iterations on every mesh of this rank; meshes run on their own HIP streams."""
+        """Exactly K Broyden iterations on every mesh of this rank.  Several meshes per GPU (configs[3]) go through the
+        batched device solver: one launch per pass over all of them (PSIGNN_BENCH_STREAMS=1: concurrent streams instead)."""
         if MPG == 1:
             return [solver.solve(fmap, eps=0.0, poll_every=max(K, 1))]
+        if not use_streams:
+            return eng.broyden_solve_batch(solvers, fmaps, 0.0, poll_every=max(K, 1))
         import concurrent.futures as cf
 
         def one(j):
@@ -204,22 +231,28 @@ def main():
         with cf.ThreadPoolExecutor(MPG) as ex:  # ctypes releases the GIL inside the library calls
             return list(ex.map(one, range(MPG)))
 
-    # ---- timed region: exactly K iterations (per mesh)
-    barrier()
-    t0 = time.perf_counter()
-    outs = run_all()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    barrier()
+    # ---- timed regions: each exactly K iterations (per mesh), barrier + synchronize on both sides, MAX over ranks
+    R = max(1, args.repeats)
+    times = []
+    for _ in range(R):
+        barrier()
+        t0 = time.perf_counter()
+        outs = run_all()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        barrier()
+        for o in outs:
+            assert o["n_iter"] == K, f"solver stopped after {o['n_iter']} of {K} iterations (reason {o['stop_reason']})"
+            assert np.all(np.isfinite(o["rel_trace"][:K]))
+        t_rep = elapsed
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_rep = float(t.item())
+        times.append(t_rep)
     out = outs[0]
-    for o in outs:
-        assert o["n_iter"] == K, f"solver stopped after {o['n_iter']} of {K} iterations (reason {o['stop_reason']})"
-        assert np.all(np.isfinite(o["rel_trace"][:K]))
-    t_max = elapsed
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_max = float(t.item())
+    t_max = float(np.median(times))
+    elapsed = t_max
     iters_per_s = world * MPG * K / t_max
     edges_per_s = world * Ep_rank * K / t_max
 
@@ -229,11 +262,16 @@ def main():
                   else f"fixed-point edges/sec (E' x Broyden iterations/sec), workload {args.workload}",
         "value": edges_per_s, "unit": "edges/s", "iters_per_sec": iters_per_s,
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * t_max / K,
+        "repeats": R, "ms_per_step_all": [round(1e3 * t / K, 5) for t in times],
+        "ms_per_step_spread": [1e3 * min(times) / K, 1e3 * max(times) / K],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {args.bc}/psignn, {MPG} x {N}-node hexagon Poisson mesh per GPU "
-                               f"(BASELINE {cfg_name}), on-device Broyden iterations 1..{K} per mesh, trained checkpoint weights",
+                               f"(BASELINE {cfg_name}), on-device Broyden iterations 1..{K} per mesh (iteration k sweeps k stored "
+                               f"pairs: value depends on K; k-independent f figures in f_only / roofline_f), trained checkpoint weights",
                    "nodes": N, "edges_nonself": Ep, "edges_total": E, "solver": "broyden", "latent_dim": D,
-                   "meshes_per_gpu": MPG, "parallelism": f"independent meshes x{world * MPG}, {MPG} concurrent streams per GPU",
+                   "meshes_per_gpu": MPG, "parallelism": f"independent meshes x{world * MPG}, " + ("one mesh per GPU" if MPG == 1 else
+                                   (f"{MPG} concurrent streams per GPU" if use_streams else
+                                    f"{MPG} per GPU in one batched device solve (one launch per pass over all meshes)")),
                    "tiled_plan": bool(fmap.plan.tiled), "tiles": fmap.plan.n_tiles,
                    "max_tile_rows": fmap.plan.max_tile_rows, "ell_rows": fmap.plan.ell_rows},
         "rel_residual_after_K": out["rel_trace"][K - 1], "setup_s": round(t_setup, 2),
@@ -296,20 +334,54 @@ def main():
                                 "avg_launch_us": fr["avg_us"], "alg_bytes_per_launch": fr["alg_bytes_per_launch"],
                                 "f_evals_per_sec": 1e6 / fr["avg_us"], "edges_per_sec_f_only": Ep * 1e6 / fr["avg_us"]}
         result["kernels"] = table
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        # HBM traffic per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate passes, gfx950
+        # read-side correction as MI355X_MICROARCH.md prescribes; scripts/collect_profiles.sh + summarise_pmc.py).  The sweeps'
+        # traffic grows with the number of stored pairs k, so the summary is a per-kernel linear model  a + b k  fitted over
+        # the launches of a K = 50 solve; it is evaluated here for THIS run's launches (k = 0 .. K-1), whatever K is.
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic_model.json")
+        if os.path.exists(pmc) and args.workload == "mesh1m":
             try:
-                # committed summary of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over THIS command
-                # (scripts/collect_profiles.sh; gfx950 read-side correction applied as MI355X_MICROARCH.md prescribes)
                 t = json.load(open(pmc))
-                if t.get("_bench_args") == {"steps": K, "warmup": W, "workload": args.workload}:
+                if t.get("_nodes") == N:
+                    ks = {"k_dots": range(1, K), "k_axpy": range(0, K)}
                     for key, row in (("roofline", dom), ("roofline_f", fr)):
-                        e = t.get(row["kernel"])
+                        e = t["kernels"].get(row["kernel"])
                         if e:
-                            result[key]["traffic"] = e["hbm_bytes_per_launch"]
+                            kk = list(ks.get(row["kernel"], [0]))
+                            result[key]["traffic"] = float(np.mean([e["a"] + e["b"] * k for k in kk]))
                             result[key]["traffic_note"] = e["note"]
-            except Exception:
-                pass
+                            result[key]["traffic_over_algorithmic"] = result[key]["traffic"] / row["alg_bytes_per_launch"]
+            except Exception as ex:   # a malformed summary must not take the bench line down
+                result["traffic_error"] = repr(ex)
+
+    # ---- k-independent figures of the GNN block: plain f and the analytic JVP, back-to-back launches in plan order
+    if rank == 0 and MPG == 1 and not args.no_kernel_timing:
+        def timed(fn, reps):
+            fn()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            return 1e3 * e0.elapsed_time(e1) / reps   # us per call (torch's current stream = the launch stream here)
+        xp = fmap.to_plan(out["result"] if "result" in out else fmap.h0)
+        us_f = 1e3 * _time_picard(fmap, xp, 100, dev)
+        b_f = per_launch["f(k_project+k_node)"]
+        result["f_only"] = {"kernel": "k_f_tile", "us_per_eval": us_f, "f_evals_per_sec": 1e6 / us_f,
+                            "edges_per_sec": Ep * 1e6 / us_f, "alg_bytes_per_launch": b_f,
+                            "achieved": b_f / us_f * 1e-3, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                            "frac": b_f / us_f * 1e-3 / HBM_PEAK_GBS, "bound": "hbm",
+                            "note": "100 back-to-back evaluations x <- f(x) on the device (psignn_picard_p), wall time / 100"}
+        if fmap.plan.tiled and not mixed:
+            vp = torch.randn_like(xp)
+            us_j = timed(lambda: fmap.jvp_p(xp, vp), 50)
+            result["roofline_jvp"] = {"kernel": "k_jvp_tile", "bound": "hbm", "achieved": per_launch["jvp"] / us_j * 1e-3,
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_launch["jvp"] / us_j * 1e-3 / HBM_PEAK_GBS,
+                                      "traffic": None, "avg_launch_us": us_j, "alg_bytes_per_launch": per_launch["jvp"],
+                                      "note": "analytic J_f(x) v of the Newton-Krylov path (BASELINE configs[4]); 50 back-to-back "
+                                              "products, HIP events on the launch stream (includes the host's launch overhead)"}
     for sv in solvers:
         sv.close()
 

@@ -281,6 +281,18 @@ int psignn_broyden_solve(psignn_broyden_t* s, const float* d_weights, int n_laye
                          const float* d_h_initial, const float* d_prb, const float* d_normals,
                          double eps, int poll_every, float* d_result, psignn_solve_info_t* h_info,
                          double* h_rel_trace, double* h_abs_trace, void* stream);
+/* Batched solve of n independent meshes (one GPU's share of a batch: BASELINE configs[3], 8 x 50k-node meshes): the meshes
+ * iterate in lockstep and every per-iteration pass (fused f step, dots, reduce + stop tests, axpy, final) is ONE launch over
+ * all of them; each mesh keeps its own status block, traces and stop test, and its result is bit-identical to
+ * psignn_broyden_solve on that mesh alone.  solvers[i] was created from mesh i's plan (tiled dirichlet plans, one
+ * threshold and vector-size class for the shard; otherwise PSIGNN_EINVAL and the caller solves them one by one).
+ * replaces: the reference's one-union-Batch-per-device DataParallel call (dirichlet/psignn/main.py:106,
+ *           dirichlet/psignn/test/test_func.py:68-120) for independent per-mesh solves.
+ * Arrays of n device / host pointers; h_rel_trace[i] / h_abs_trace[i]: `threshold` doubles each (arrays may be NULL). */
+int psignn_broyden_solve_batch(int n, psignn_broyden_t** solvers, const float* d_weights, int n_layers,
+                               const float* const* d_h_initial, const float* const* d_prb, double eps, int poll_every,
+                               float* const* d_results, psignn_solve_info_t* h_infos, double* const* h_rel_trace,
+                               double* const* h_abs_trace, void* stream);
 /* Adjoint fixed point y = J_f(h*)^T y + grad with the same Broyden machinery, the VJP kernel as the map, y_0 = 0.
  * replaces: the backward hook of DeepEquilibrium.forward (dirichlet/psignn/model.py:210-223), i.e.
  *           solver(lambda y: autograd.grad(new_H, H, y) + grad, zeros, bw_thres, bw_tol).
@@ -311,6 +323,43 @@ int psignn_broyden_ext_finish(psignn_broyden_t* s, float* d_result, psignn_solve
 int psignn_broyden_create_n(psignn_broyden_t** out, int64_t n_elems, int seq_len, int threshold, int keep_trace);
 
 /* ------------------------------------------------------------------------------------------
+ * Picard iteration and Anderson acceleration: the vector work, norms, stop tests and the small bordered solve on the
+ * device; the caller evaluates f between the calls (the HIP GNN block, or any function of device tensors).
+ * replaces: forward_iteration (dirichlet/psignn/utilities/solver.py:301-341) and anderson (:215-293, m = 2, lam = 1e-4,
+ *           beta = 1 at every call site) -- their torch.linalg.norm / .item() per iteration, bmm, linalg.solve and the
+ *           alpha @ F mixing.
+ * n_elems = N * d.  m: history length of Anderson (1..8; Picard ignores it).  threshold: the reference's `threshold`.
+ * keep_trace != 0 stores every iterate (threshold + 2 vectors) for xest_trace.  Device status block: after the stop test
+ * has fired every later call is a no-op, so a caller may run a few iterations ahead of psignn_fpiter_poll.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct psignn_fpiter psignn_fpiter_t;
+int psignn_fpiter_create(psignn_fpiter_t** out, int64_t n_elems, int m, int threshold, int keep_trace);
+void psignn_fpiter_destroy(psignn_fpiter_t* s);
+size_t psignn_fpiter_bytes(const psignn_fpiter_t* s);
+int psignn_fpiter_poll(psignn_fpiter_t* s, int* h_done, void* stream);     /* synchronous read of the done flag */
+/* Picard: begin(z0); then repeat { current_x -> x ; fx = f(x) ; update(fx) }: abs = |x - fx|, rel = abs / |fx| appended
+ * to the traces, stop when rel <= eps or after threshold + 1 evaluations, the current iterate becomes fx.
+ * h_done may be NULL (no host read). */
+int psignn_picard_begin(psignn_fpiter_t* s, const float* d_x0, void* stream);
+int psignn_picard_current_x(psignn_fpiter_t* s, float* d_x, void* stream);
+int psignn_picard_update(psignn_fpiter_t* s, const float* d_fx, double eps, int* h_done, void* stream);
+/* Anderson: begin(x0, f(x0), f(f(x0))); then for k = 2 .. threshold - 1 { next_x -> x_k ; fx = f(x_k) ; update(fx) }.
+ * next_x: Gram matrix of the residual history, alpha from the bordered system [[0, 1^T], [1, G G^T + lam I]], x_k =
+ * beta sum alpha_i F_i + (1 - beta) sum alpha_i X_i.  update: rel = |fx - x_k| / (1e-5 + |fx|), traces, lowest iterate
+ * by stop_mode (stop_abs: 0 "rel", 1 "abs"), stop when the objective < eps. */
+int psignn_anderson_begin(psignn_fpiter_t* s, const float* d_x0, const float* d_f0, const float* d_f1, double lam, double beta,
+                          int stop_abs, void* stream);
+int psignn_anderson_next_x(psignn_fpiter_t* s, float* d_x_new, void* stream);
+int psignn_anderson_update(psignn_fpiter_t* s, const float* d_fx_new, double eps, int* h_done, void* stream);
+/* Result (Picard: the last iterate, nstep = ite, lowest = last rel; Anderson: the lowest iterate, nstep = its loop index),
+ * traces (n_iter entries each; arrays of threshold + 2 doubles) and, for Anderson, per loop iteration the loop index of the
+ * lowest iterate so far (h_low_idx, threshold + 2 int32, may be NULL).  Synchronous. */
+int psignn_fpiter_finish(psignn_fpiter_t* s, float* d_result, psignn_solve_info_t* h_info, double* h_rel_trace,
+                         double* h_abs_trace, int32_t* h_low_idx, void* stream);
+/* Iterate i of the last run (keep_trace): Picard z_i; Anderson the trial point of loop index i (i >= 2). */
+int psignn_fpiter_get_iterate(const psignn_fpiter_t* s, int i, float* d_dst, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline line;
  * replaces: the reference's only instrumentation, time.time() around the model call,
  * tests/special_geo/spec_geo_2.py:313-317).  Off by default.
@@ -318,6 +367,10 @@ int psignn_broyden_create_n(psignn_broyden_t** out, int64_t n_elems, int seq_len
 void psignn_prof_enable(int on);
 int psignn_prof_collect(void);   /* sync + aggregate per kernel name; returns the number of names */
 int psignn_prof_get(int i, char* name, int cap, int64_t* calls, double* total_ms);
+/* Diagnostics: d_buf = device array of n_tiles * 4 * 8 int64 (or NULL to switch off).  While set, every wave of the f tile
+ * kernel stores shader-clock stamps at its phase boundaries (0 start, 1 stage 1 done, 2 past the barrier, 3 neighbour sums
+ * done, 4 node update done, 5 stored) -- scripts/tile_phases.py turns them into a per-phase time budget. */
+void psignn_prof_tile_stamps(void* d_buf);
 
 #ifdef __cplusplus
 }

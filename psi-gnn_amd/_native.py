@@ -87,6 +87,9 @@ SIGNATURES = {
                                     C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
     "psignn_broyden_solve_adjoint": (_INT, [_P, _P, _INT, _P, _P, _P, _P, C.c_double, _INT, _P, C.POINTER(SolveInfo),
                                             C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
+    "psignn_broyden_solve_batch": (_INT, [_INT, C.POINTER(_P), _P, _INT, C.POINTER(_P), C.POINTER(_P), C.c_double, _INT,
+                                          C.POINTER(_P), C.POINTER(SolveInfo), C.POINTER(C.POINTER(C.c_double)),
+                                          C.POINTER(C.POINTER(C.c_double)), _P]),
     "psignn_broyden_get_iterate": (_INT, [_P, _INT, _P, _P]),
     "psignn_broyden_ext_begin": (_INT, [_P, _P, _P, _P]),
     "psignn_broyden_ext_next_x": (_INT, [_P, _P, _P]),
@@ -95,7 +98,21 @@ SIGNATURES = {
     "psignn_broyden_ext_update": (_INT, [_P, _P, C.c_double, C.POINTER(_INT), _P]),
     "psignn_broyden_ext_finish": (_INT, [_P, _P, C.POINTER(SolveInfo), C.POINTER(C.c_double),
                                          C.POINTER(C.c_double), _P]),
+    "psignn_fpiter_create": (_INT, [C.POINTER(_P), _I64, _INT, _INT, _INT]),
+    "psignn_fpiter_destroy": (None, [_P]),
+    "psignn_fpiter_bytes": (C.c_size_t, [_P]),
+    "psignn_fpiter_poll": (_INT, [_P, C.POINTER(_INT), _P]),
+    "psignn_picard_begin": (_INT, [_P, _P, _P]),
+    "psignn_picard_current_x": (_INT, [_P, _P, _P]),
+    "psignn_picard_update": (_INT, [_P, _P, C.c_double, C.POINTER(_INT), _P]),
+    "psignn_anderson_begin": (_INT, [_P, _P, _P, _P, C.c_double, C.c_double, _INT, _P]),
+    "psignn_anderson_next_x": (_INT, [_P, _P, _P]),
+    "psignn_anderson_update": (_INT, [_P, _P, C.c_double, C.POINTER(_INT), _P]),
+    "psignn_fpiter_finish": (_INT, [_P, _P, C.POINTER(SolveInfo), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int32), _P]),
+    "psignn_fpiter_get_iterate": (_INT, [_P, _INT, _P, _P]),
     "psignn_prof_enable": (None, [_INT]),
+    "psignn_prof_tile_stamps": (None, [_P]),
     "psignn_prof_collect": (_INT, []),
     "psignn_prof_get": (_INT, [_INT, C.c_char_p, _INT, C.POINTER(_I64), C.POINTER(C.c_double)]),
 }

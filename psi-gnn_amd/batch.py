@@ -18,6 +18,47 @@ def shard_indices(n_items: int, rank: int, world: int):
     return list(range(rank, n_items, world))
 
 
+def solve_shard_batched(model, meshes, device, indices=None, group=8):
+    """``solve_shard`` with the device's share of the batch solved in LOCKSTEP: ``group`` meshes at a time go through one
+    batched device solve (``engine.broyden_solve_batch``: every per-iteration pass is one launch over all of them, own stop
+    test per mesh).  Results are bit-identical to ``solve_shard``; meshes the batched solver cannot take together (mixed
+    family, untiled plans, different size classes) fall back to one solve each."""
+    import importlib
+    from . import _native as nat
+    eng = importlib.import_module(__package__ + ".engine")
+    slv = importlib.import_module(__package__ + ".utilities.solver")
+    net = getattr(model, "module", model)
+    cfg = net.deqdss.config_deq
+    idx = list(range(len(meshes)) if indices is None else indices)
+    out = []
+    with torch.no_grad():
+        for g0 in range(0, len(idx), group):
+            ids = idx[g0:g0 + group]
+            mds = [meshes[i].to(device) for i in ids]
+            h0s = [net.autoencoder.encoder(md.x) for md in mds]
+            fmaps = [net.deqdss.f.bind(h0, md) for h0, md in zip(h0s, mds)]
+            solved = None
+            if cfg["solver"] is slv.broyden and len(ids) > 1:
+                solvers = [eng.DeviceBroyden(plan=f.plan, threshold=cfg["fw_thres"], keep_trace=False) for f in fmaps]
+                try:
+                    solved = eng.broyden_solve_batch(solvers, fmaps, cfg["fw_tol"])
+                except nat.NativeError:
+                    solved = None          # not one size class / not tiled dirichlet: one solve per mesh below
+                for sv in solvers:
+                    sv.close()
+            for k, i in enumerate(ids):
+                if solved is not None:
+                    h_final, nstep = solved[k]["result"], solved[k]["nstep"]
+                else:
+                    o = net.deqdss(h0s[k], mds[k])
+                    h_final, nstep = o["result"], o["nstep"]
+                u = net.autoencoder.decoder(h_final)
+                loss = net._diagnostics(u, h_final, mds[k], "mse_dirichlet_loss")
+                loss["nsteps"] = nstep
+                out.append((i, u, loss))
+    return out
+
+
 def solve_shard(model, meshes, device, indices=None, streams=1):
     """Solve the given meshes on `device`; returns [(index, u_final, loss_dic)] in index order.
 

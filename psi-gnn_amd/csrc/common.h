@@ -114,6 +114,20 @@ struct psignn_plan {
   int64_t n_tiles_plain = 0;                   // tiles in the first group
   float cell_size = 0.f, xmin = 0.f, ymin = 0.f;
   int nx = 0, ny = 0;
+  struct TileCtx* d_ctx = nullptr;             // device copy of the tile pointers (one kernel argument instead of eight)
+  int32_t* d_tile_ctr = nullptr;               // work queues of the persistent tile kernels: 8 per-XCD counters + an exit
+                                               // counter, one 128-byte line each; zero between launches (self-resetting)
+};
+
+// Iteration-invariant pointers of a tiled plan, kept in DEVICE memory and handed to the tile kernels as one pointer.
+// As separate kernel arguments they are all live from the kernel's first instruction; the f kernel needs ~60 SGPRs for
+// weights in its hot phases, so the compiler parked those arguments in VGPR lanes (v_writelane / v_readlane: VALU issue
+// slots).  Behind a pointer each one is a scalar load next to its use.
+struct TileCtx {
+  const int32_t *tile_ptr, *tile_slice, *halo, *halo_cnt, *slice_off;
+  const uint8_t* slice_deg;
+  const uint4* ell;
+  const uint8_t* flags_p;
 };
 
 #define TILE_MAX 256      // nodes per tile = threads per block of the tile kernel
@@ -139,3 +153,19 @@ void prof_end(hipStream_t st);
 
 #define FLAG_DIRICHLET 1
 #define FLAG_NEUMANN 2
+
+// ---------------------------------------------------------------------------------------------
+// Batched Broyden (solver.hip psignn_broyden_solve_batch): one descriptor per mesh of a shard, in device memory.  Every
+// per-iteration kernel is launched ONCE for the whole shard with blockIdx.z = mesh; a block loads its mesh's descriptor
+// and then runs exactly the code (same block -> element mapping, same partial-sum shapes) of the single-mesh kernels, so
+// each mesh's result is bit-identical to its own solve.
+// ---------------------------------------------------------------------------------------------
+struct BatchDesc {
+  int64_t M, ld;
+  int32_t nblk, npart, nblk_ax, jgroups, thr, seq_len, keep_trace, n_tiles, tile_base;
+  int32_t* st;                 // the mesh's Status block, int32 view
+  float *U, *V, *xbuf, *gx, *dg, *upd, *part, *coef, *nrm_part, *jpart;
+  double *rel_trace, *abs_trace;
+  const struct TileCtx* ctx;
+  const float *h0p, *prbp;
+};

@@ -13,7 +13,7 @@
 // the host (WLayout fold block).  All node tensors are in PLAN order; the solver keeps its state there.
 #include "tile_helpers.h"
 #ifndef TILE_WPE
-#define TILE_WPE 0    // > 0: __attribute__((amdgpu_waves_per_eu(TILE_WPE))) on k_f_tile (A/B: scripts/ab_edge.sh)
+#define TILE_WPE 5    // > 0: __attribute__((amdgpu_waves_per_eu(TILE_WPE, TILE_WPE))) on k_f_tile: the register allocator is held to 96 VGPRs (5 waves per SIMD)
 #endif
 #if TILE_WPE
 #define TILE_WPE_ATTR __attribute__((amdgpu_waves_per_eu(TILE_WPE, TILE_WPE)))
@@ -72,6 +72,7 @@ __device__ __forceinline__ void lds_load10at(const float* __restrict__ p, float*
 // matrix cores (v_mfma_f32_16x16x4_f32) or packed VALU.
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 // Default form: packed VALU everywhere.  A/Bs on one box (1M-node mesh) after the scalar-load phase barriers removed the
 // SGPR spills of the VALU form: dirichlet plain f 64.6 us (valu) vs 67.7 us (mfma); fused Broyden step 102 us (valu) vs
 // 122-125 us (mfma: it has to re-load x and update for stage 2, which the VALU form gets for free from its stage-1
@@ -102,7 +103,24 @@ struct FuseArgs {
   int64_t M;
   float* part;
   int npart;
+  long long* stamps;  // diagnostics (psignn_prof_tile_stamps): per tile and wave 8 constant-rate (100 MHz) clock stamps, else NULL
 };
+
+// In-kernel phase stamps (diagnostics only; one lane per wave writes s_memtime values)
+#ifndef TILE_STAMPS
+#define TILE_STAMPS 0   // build with -DTILE_STAMPS=1 for scripts/tile_phases.py (the stamps cost registers and issue slots)
+#endif
+#if !TILE_STAMPS
+#define STAMP(i) do { } while (0)
+#else
+#define STAMP(i)                                                                                        \
+  do {                                                                                                  \
+    if (fa.stamps && (threadIdx.x & 63) == 0)                                                           \
+      fa.stamps[((int64_t)tile * 4 + (threadIdx.x >> 6)) * 8 + (i)] = (long long)wall_clock64(); \
+  } while (0)
+#endif
+static long long* g_tile_stamps = nullptr;
+extern "C" void psignn_prof_tile_stamps(void* d_buf) { g_tile_stamps = (long long*)d_buf; }
 
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
@@ -110,31 +128,25 @@ __device__ __forceinline__ float wave_sum_f(float v) {
   return v;
 }
 
+// One tile: body of k_f_tile.  `slot` = position in the launch's tile list.  Every thread of the workgroup reaches the
+// stage-1 barrier; returns happen after it (the caller's loop barrier is outside).
 template <int P, bool MIXED, bool FUSED, bool MFMA1>
-__global__ __launch_bounds__(TILE_THREADS) TILE_WPE_ATTR void k_f_tile(FuseArgs fa, int n_tiles, int chunk, const int32_t* __restrict__ tile_list,
-                                                const int32_t* __restrict__ tile_ptr,
-                                                const int32_t* __restrict__ tile_slice, const int32_t* __restrict__ halo,
-                                                const int32_t* __restrict__ halo_cnt, const int32_t* __restrict__ slice_off,
-                                                const uint8_t* __restrict__ slice_deg, const uint4* __restrict__ ell,
-                                                const uint8_t* __restrict__ flags, const float* __restrict__ W, int lofs, int tofs,
-                                                int tnofs, int apply_ln, const float* __restrict__ h,
-                                                const int32_t* __restrict__ hsel, int64_t hstride,
-                                                const float* __restrict__ h0, const float* __restrict__ prb,
-                                                const float* __restrict__ nrm, float* __restrict__ out) {
+__device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, const int32_t* __restrict__ tile_list,
+                                            const TileCtx* __restrict__ C, const float* __restrict__ W, int lofs, int tofs,
+                                            int tnofs, int apply_ln, const float* __restrict__ h,
+                                            const int32_t* __restrict__ hsel, int64_t hstride,
+                                            const float* __restrict__ h0, const float* __restrict__ prb,
+                                            const float* __restrict__ nrm, float* __restrict__ out, float* __restrict__ lds) {
   using L = WLayout<P>;
   constexpr int RS = TileRow<MIXED>::RS;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of tiles so that
-  // neighbouring tiles' halo rows hit the same L2.  Speed only; any mapping is correct.
-  const int slot = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (slot >= n_tiles) return;
-  if (FUSED && fa.st[fa.off_done]) return;
   const int tile = tile_list ? tile_list[slot] : slot;   // mixed plans: a sub-list of the tiles (see launch_mixed)
+  STAMP(0);
   const int tid = threadIdx.x;
+  const int32_t* __restrict__ tile_ptr = C->tile_ptr;
   const int32_t t0 = tile_ptr[tile];
   const int n_t = tile_ptr[tile + 1] - t0;
-  const int n_h = halo_cnt[tile];
-  const int32_t* hl = halo + (int64_t)tile * HALO_CAP;
+  const int n_h = C->halo_cnt[tile];
+  const int32_t* hl = C->halo + (int64_t)tile * HALO_CAP;
   if (hsel) h += (int64_t)(*hsel) * hstride;
   if (FUSED) h = fa.xbuf + (int64_t)fa.st[fa.off_cur] * fa.M;
 
@@ -143,6 +155,8 @@ __global__ __launch_bounds__(TILE_THREADS) TILE_WPE_ATTR void k_f_tile(FuseArgs 
 
   // ---- stage 1: neighbour-side projections of tile + halo rows -> LDS
   float x[D];
+  uint4 slot0 = make_uint4(ELL_EMPTY, 0u, 0u, 0u);   // slot row 0 of this lane / prefetch witness (SLOT_PREFETCH below)
+  unsigned slot_touch = 0;
   if constexpr (MFMA1) {
     // Dense node-feature x weight product on the matrix cores: out[row][o] = sum_k x[row][k] W1j[o][k] as
     // v_mfma_f32_16x16x4_f32 tiles with the WEIGHTS as the A operand (A[i = output][k]) and the node rows as B
@@ -206,7 +220,138 @@ __global__ __launch_bounds__(TILE_THREADS) TILE_WPE_ATTR void k_f_tile(FuseArgs 
   // mixed family: the Phi_neumann projections are only read by Neumann lanes, i.e. in the few boundary tiles -- every
   // other tile skips a third of its stage-1 work
   bool tile_neu = false;
-  if (MIXED) tile_neu = __syncthreads_or(tid < n_t ? (flags[t0 + tid] & FLAG_NEUMANN) : 0) != 0;
+  if (MIXED) tile_neu = __syncthreads_or(tid < n_t ? (C->flags_p[t0 + tid] & FLAG_NEUMANN) : 0) != 0;
+#ifndef HALO_SPLIT
+#define HALO_SPLIT 1   // 1: halo rows of stage 1 shared out as half rows over all four waves (see below); 0: round 1's loop
+#endif
+#ifndef SLOT_PREFETCH
+#define SLOT_PREFETCH 1   // 1: the wave's slot rows are requested before stage 1 (row 0 kept, the rest pulled towards L2)
+#endif
+#if HALO_SPLIT
+#if SLOT_PREFETCH
+  // The slot walk of stage 2 streams 16-byte records that nobody has touched before: an HBM miss (~0.4 us under load) per
+  // slot row, with one row's arithmetic (~0.15 us of issue time) to hide it -- stamps put the walk at 7.7 us per wave where
+  // its instructions account for 4.  Every wave therefore requests its slot rows NOW, ahead of the h rows: row 0 stays in
+  // registers for the walk, the others are only pulled towards L2 / L1 (their first words are folded into a value that is
+  // looked at once after stage 1 and never acted on), so that the walk's loads are cache hits.
+  if ((tid & ~63) < n_t) {
+    const int pslice = C->tile_slice[tile] + (tid >> 6);
+    const uint4* pslots = C->ell + (int64_t)C->slice_off[pslice] * 64 + (tid & 63);
+    const int pn = C->slice_deg[pslice];
+    if (pn > 0) {   // (the fused Broyden step has no four registers to spare across stage 1: it only touches row 0 as well)
+      if (FUSED) slot_touch ^= pslots[0].x;
+      else slot0 = pslots[0];
+    }
+#pragma unroll
+    for (int r = 1; r < 8; ++r)
+      if (r < pn) slot_touch ^= pslots[(int64_t)r * 64].x;
+  }
+#endif
+  // own row first: every lane's loads are in flight before any projection starts
+  const int32_t hidx_w = (tid >> 6 & 1) * 64 + (tid & 63);   // this lane's halo slot inside a 128-row batch
+  int32_t hnode = 0;
+  if (hidx_w < n_h) hnode = hl[hidx_w];                        // halo index of the first batch, ahead of its use
+  if (tid < n_t) {
+    float xr[D];
+    load10(h + (int64_t)(t0 + tid) * D, xr);
+    if (FUSED) {  // x_next = x_cur + update (line_search with on=False: step 1, solver.py:85-94)
+      float ur[D];
+      load10(fa.upd + (int64_t)(t0 + tid) * D, ur);
+#pragma unroll
+      for (int o = 0; o < D; ++o) xr[o] += ur[o];
+    }
+#pragma unroll
+    for (int o = 0; o < D; ++o) x[o] = xr[o];
+#if SLOT_PREFETCH
+    // the prefetch loads were issued before the h row and return in order: looking at their witness here costs no extra
+    // wait and frees its register before the projections (never true: slot words are < 2^18)
+    if (slot_touch == 0xDEADBEEFu) xr[0] = 0.f;
+#endif
+    v2f ta[5], tb[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) ta[p] = tb[p] = splat(0.f);
+    PHASE();
+    mv2<D>(T + L::T_W1J_TO, xr, ta);
+    PHASE();
+    mv2<D>(T + L::T_W1J_FR, xr, tb);
+    float4* q = reinterpret_cast<float4*>(lds + tid * RS);
+    q[0] = make_float4(ta[0].x, ta[0].y, ta[1].x, ta[1].y);
+    q[1] = make_float4(ta[2].x, ta[2].y, ta[3].x, ta[3].y);
+    q[2] = make_float4(ta[4].x, ta[4].y, tb[0].x, tb[0].y);
+    q[3] = make_float4(tb[1].x, tb[1].y, tb[2].x, tb[2].y);
+    q[4] = make_float4(tb[3].x, tb[3].y, tb[4].x, tb[4].y);
+    if (MIXED && tile_neu) {
+#pragma unroll
+      for (int p = 0; p < 5; ++p) ta[p] = splat(0.f);
+      PHASE();
+      mv2<D>(TN + L::N_W1J, xr, ta);
+      q[5] = make_float4(ta[0].x, ta[0].y, ta[1].x, ta[1].y);
+      q[6] = make_float4(ta[2].x, ta[2].y, ta[3].x, ta[3].y);
+      reinterpret_cast<float2*>(q + 7)[0] = make_float2(ta[4].x, ta[4].y);
+    }
+  }
+  // Halo rows.  A tile of 256 nodes has ~110 of them: as whole rows they are a second round for waves 0 and 1 only, with
+  // the other two waves parked at the barrier (stamps: 4.0 vs 2.5 us in stage 1, 1.7 us of barrier wait).  Shared out as
+  // HALF rows instead -- waves 0, 1 project the Phi_to half of halo rows [64 (w & 1), +64), waves 2, 3 the Phi_from half --
+  // every wave does one 10 x 10 block per 128 halo rows: the same number of wave instructions, half the critical path.
+  {
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 7);   // wave-uniform: 0 Phi_to columns, 1 Phi_from columns
+    for (int hb = 0; hb < n_h; hb += 128) {
+      const int idx = hb + hidx_w;
+      if (hb > 0 && idx < n_h) hnode = hl[idx];
+      if (idx < n_h) {
+        float xr[D];
+        load10(h + (int64_t)hnode * D, xr);
+        if (FUSED) {
+          float ur[D];
+          load10(fa.upd + (int64_t)hnode * D, ur);
+#pragma unroll
+          for (int o = 0; o < D; ++o) xr[o] += ur[o];
+        }
+        v2f ta[5];
+#pragma unroll
+        for (int p = 0; p < 5; ++p) ta[p] = splat(0.f);
+        PHASE();
+        float* rowp = lds + (n_t + idx) * RS;
+        if (half == 0) {
+          mv2<D>(T + L::T_W1J_TO, xr, ta);
+          float4* q = reinterpret_cast<float4*>(rowp);                 // floats 0..9: b128, b128, b64
+          q[0] = make_float4(ta[0].x, ta[0].y, ta[1].x, ta[1].y);
+          q[1] = make_float4(ta[2].x, ta[2].y, ta[3].x, ta[3].y);
+          reinterpret_cast<float2*>(rowp + 8)[0] = make_float2(ta[4].x, ta[4].y);
+        } else {
+          mv2<D>(T + L::T_W1J_FR, xr, ta);
+          reinterpret_cast<float2*>(rowp + 10)[0] = make_float2(ta[0].x, ta[0].y);   // floats 10..19: b64, b128, b128
+          float4* q = reinterpret_cast<float4*>(rowp + 12);
+          q[0] = make_float4(ta[1].x, ta[1].y, ta[2].x, ta[2].y);
+          q[1] = make_float4(ta[3].x, ta[3].y, ta[4].x, ta[4].y);
+        }
+      }
+    }
+    if (MIXED && tile_neu) {   // boundary tiles of the mixed family: Phi_neumann columns of the halo rows
+      for (int idx = tid; idx < n_h; idx += TILE_THREADS) {
+        const int64_t node = hl[idx];
+        float xr[D];
+        load10(h + node * D, xr);
+        if (FUSED) {
+          float ur[D];
+          load10(fa.upd + node * D, ur);
+#pragma unroll
+          for (int o = 0; o < D; ++o) xr[o] += ur[o];
+        }
+        v2f ta[5];
+#pragma unroll
+        for (int p = 0; p < 5; ++p) ta[p] = splat(0.f);
+        PHASE();
+        mv2<D>(TN + L::N_W1J, xr, ta);
+        float4* q = reinterpret_cast<float4*>(lds + (n_t + idx) * RS);
+        q[5] = make_float4(ta[0].x, ta[0].y, ta[1].x, ta[1].y);
+        q[6] = make_float4(ta[2].x, ta[2].y, ta[3].x, ta[3].y);
+        reinterpret_cast<float2*>(q + 7)[0] = make_float2(ta[4].x, ta[4].y);
+      }
+    }
+  }
+#else
   for (int row = tid; row < n_t + n_h; row += TILE_THREADS) {
     const int64_t node = row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t];
     float xr[D];
@@ -244,14 +389,17 @@ __global__ __launch_bounds__(TILE_THREADS) TILE_WPE_ATTR void k_f_tile(FuseArgs 
       reinterpret_cast<float2*>(q + 7)[0] = make_float2(ta[4].x, ta[4].y);
     }
   }
+#endif
   }
+  STAMP(1);
   __syncthreads();
+  STAMP(2);
   if (!FUSED && tid >= n_t) return;
 
   // ---- stage 2: one tile node per lane
   const bool active = tid < n_t;
   const int64_t n = (int64_t)t0 + (active ? tid : 0);
-  const uint8_t fl = flags[n];
+  const uint8_t fl = C->flags_p[n];
   float y[D];
   const bool dirichlet = fl & FLAG_DIRICHLET;
   if (dirichlet) {  // Dirichlet rows <- h_initial rows (model.py:298)
@@ -263,9 +411,9 @@ __global__ __launch_bounds__(TILE_THREADS) TILE_WPE_ATTR void k_f_tile(FuseArgs 
   }
   if (!dirichlet && active) {
   const int lane = tid & 63;
-  const int slice = tile_slice[tile] + (tid >> 6);
-  const uint4* slots = ell + (int64_t)slice_off[slice] * 64 + lane;
-  const int nslots = slice_deg[slice];
+  const int slice = C->tile_slice[tile] + (tid >> 6);
+  const uint4* slots = C->ell + (int64_t)C->slice_off[slice] * 64 + lane;
+  const int nslots = C->slice_deg[slice];
 
   // target-side projection (bias included) + neighbour sum
   v2f Pi[5], S_to[5], S_fr[5];
@@ -293,12 +441,18 @@ __global__ __launch_bounds__(TILE_THREADS) TILE_WPE_ATTR void k_f_tile(FuseArgs 
     mv2<D>(T + L::T_W1I_FR, x, Pi2);
     PHASE();
 #if EDGE_CLAMP
+#if HALO_SPLIT && SLOT_PREFETCH
+    edge_pass_both_clamp<RS>(slots, nslots, lds, T + L::T_A_TO, T + L::T_A_FR, Pi, Pi2, S_to, S_fr, deg_in, deg_out,
+                             (MFMA1 || FUSED) ? nullptr : &slot0);
+#else
     edge_pass_both_clamp<RS>(slots, nslots, lds, T + L::T_A_TO, T + L::T_A_FR, Pi, Pi2, S_to, S_fr, deg_in, deg_out);
+#endif
 #else
     edge_pass_both<RS>(slots, nslots, lds, T + L::T_A_TO, T + L::T_A_FR, Pi, Pi2, S_to, S_fr, deg_in, deg_out);
 #endif
     PHASE();
   }
+  STAMP(3);
 #if X_RELOAD
   load10(xsrc, x);
 #endif
@@ -407,8 +561,10 @@ __global__ __launch_bounds__(TILE_THREADS) TILE_WPE_ATTR void k_f_tile(FuseArgs 
     for (int o = 0; o < D; ++o) y[o] = fmaf((y[o] - mu) * rs, W[L::LN_G + o], W[L::LN_B + o]);
   }
   }  // !dirichlet && active
+  STAMP(4);
   if (!FUSED) {
     store10(out + n * D, y);
+    STAMP(5);
     return;
   }
   // ---- fused Broyden epilogue
@@ -442,6 +598,104 @@ __global__ __launch_bounds__(TILE_THREADS) TILE_WPE_ATTR void k_f_tile(FuseArgs 
   }
 }
 
+// Kernel: workgroups are PERSISTENT -- the grid holds at most as many workgroups as fit on the chip at once and each walks
+// several tiles.  blocks b and b+8 share an XCD (round-robin dispatch): each XCD owns a contiguous run of `chunk` tiles
+// (neighbouring tiles' halo rows hit the same L2).  A workgroup's first tile is fixed (its index in the XCD); every further
+// one comes from the XCD's queue -- an atomic counter fetched while the current tile is being computed -- so that a
+// workgroup whose tiles ran fast takes more of them.  Why: per-phase stamps of the one-workgroup-per-tile form on the 1M-node
+// mesh showed tile lifetimes of 10 .. 21 us (p10 .. p90) and only 78 % of the chip's workgroup slots occupied on average --
+// the last quarter of the kernel's duration is a tail of late tiles.  The last workgroup to leave resets the counters, so they
+// are zero between launches.  Any tile -> workgroup mapping gives the same results.
+template <int P, bool MIXED, bool FUSED, bool MFMA1>
+__global__ __launch_bounds__(TILE_THREADS) TILE_WPE_ATTR void k_f_tile(FuseArgs fa, int n_tiles, int chunk, const int32_t* __restrict__ tile_list,
+                                                const TileCtx* __restrict__ C, int32_t* __restrict__ ctr,
+                                                const float* __restrict__ W, int lofs, int tofs,
+                                                int tnofs, int apply_ln, const float* __restrict__ h,
+                                                const int32_t* __restrict__ hsel, int64_t hstride,
+                                                const float* __restrict__ h0, const float* __restrict__ prb,
+                                                const float* __restrict__ nrm, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ int s_next[2];
+  if (FUSED && fa.st[fa.off_done]) return;
+  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+  const bool queued = per_xcd < chunk;   // else one workgroup per tile: nothing to queue
+  int j = blockIdx.x >> 3;
+  int b = 0;
+  for (;;) {
+    int nxt = 0;
+    if (queued && threadIdx.x == 0) nxt = atomicAdd(&ctr[xcd * 32], 1);   // in flight while this tile is computed
+    const int slot = xcd * chunk + j;
+    if (j < chunk && slot < n_tiles)
+      f_tile_body<P, MIXED, FUSED, MFMA1>(fa, slot, tile_list, C, W, lofs, tofs, tnofs, apply_ln, h, hsel, hstride, h0, prb, nrm,
+                                          out, lds);
+    if (!queued) return;
+    if (threadIdx.x == 0) s_next[b] = per_xcd + nxt;
+    __syncthreads();   // also: the next tile's stage 1 overwrites the LDS rows this tile's lanes were reading
+    j = __builtin_amdgcn_readfirstlane(s_next[b]);
+    b ^= 1;
+    if (j >= chunk) break;
+  }
+  if (threadIdx.x == 0 && atomicAdd(&ctr[8 * 32], 1) == (int)gridDim.x - 1) {   // last one out: queues back to zero
+#pragma unroll
+    for (int q = 0; q < 9; ++q) ctr[q * 32] = 0;
+  }
+}
+
+static unsigned tile_grid(int chunk);
+
+// Batched fused Broyden step (solver.hip psignn_broyden_solve_batch; dirichlet, single layer): ONE launch evaluates the
+// fused step of every mesh of a shard.  The tiles of all meshes form one list (mesh m owns slots [tile_base[m],
+// tile_base[m] + n_tiles[m])); a workgroup looks its slot's mesh up, loads that mesh's pointers from its descriptor and runs
+// the same tile body as the single-mesh kernel -- same arithmetic per node, same per-tile norm partials.  A mesh whose stop
+// test has fired is skipped tile by tile.
+template <int P>
+__global__ __launch_bounds__(TILE_THREADS) void k_f_tile_batch(const BatchDesc* __restrict__ descs, int n_mesh, int n_slots, int chunk,
+                                                              int32_t* __restrict__ ctr, int off_done, int off_cur, int off_nxt,
+                                                              const float* __restrict__ W, int lofs, int tofs) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ int s_next[2];
+  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+  const bool queued = per_xcd < chunk;
+  int j = blockIdx.x >> 3;
+  int b = 0;
+  for (;;) {
+    int nxt = 0;
+    if (queued && threadIdx.x == 0) nxt = atomicAdd(&ctr[xcd * 32], 1);
+    const int slot = xcd * chunk + j;
+    if (j < chunk && slot < n_slots) {
+      int m = 0;
+      while (m + 1 < n_mesh && descs[m + 1].tile_base <= slot) ++m;   // wave-uniform scalar walk (a shard has few meshes)
+      const BatchDesc& d = descs[m];
+      if (!d.st[off_done]) {
+        FuseArgs fa{d.upd, d.gx, d.dg, d.xbuf, d.st, off_done, off_cur, off_nxt, d.M, d.nrm_part, d.n_tiles, nullptr};
+        f_tile_body<P, false, true, false>(fa, slot - d.tile_base, nullptr, d.ctx, W, lofs, tofs, 0, 1, d.xbuf, nullptr, 0, d.h0p,
+                                           d.prbp, nullptr, nullptr, lds);
+      }
+    }
+    if (!queued) return;
+    if (threadIdx.x == 0) s_next[b] = per_xcd + nxt;
+    __syncthreads();
+    j = __builtin_amdgcn_readfirstlane(s_next[b]);
+    b ^= 1;
+    if (j >= chunk) break;
+  }
+  if (threadIdx.x == 0 && atomicAdd(&ctr[8 * 32], 1) == (int)gridDim.x - 1) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) ctr[q * 32] = 0;
+  }
+}
+
+// descs: device array of n_mesh descriptors; max_rows: largest tile + halo row count over the meshes (LDS size).
+int psignn_f_tile_fused_batch(const BatchDesc* d_descs, int n_mesh, int n_slots, int max_rows, int32_t* d_ctr, const float* W,
+                              int off_done, int off_cur, int off_nxt, hipStream_t st) {
+  using L = WLayout<2>;
+  const int chunk = (int)cdiv(n_slots, 8);
+  LAUNCH("k_f_tile_fused", st, (k_f_tile_batch<2><<<tile_grid(chunk), TILE_THREADS, (size_t)max_rows * TileRow<false>::RS * 4, st>>>(
+      d_descs, n_mesh, n_slots, chunk, d_ctr, off_done, off_cur, off_nxt, W, L::layer(0), L::tp_layer(1, false, 0))));
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+
 // gather of node rows between the caller's numbering and the plan order: dst[i] = src[map[i]]
 __global__ void k_permute_rows(int64_t N, int cols, const int32_t* __restrict__ map, const float* __restrict__ src,
                                float* __restrict__ dst) {
@@ -452,7 +706,33 @@ __global__ void k_permute_rows(int64_t N, int cols, const int32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------ host
-#define TILE_ARGS p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell, p->flags_p
+#define TILE_ARGS p->d_ctx, p->d_tile_ctr
+
+// Grid of a tile-kernel launch over `chunk` tiles per XCD.  Default: one workgroup per tile.  PSIGNN_WG_PER_CU = n > 0 caps
+// the grid at n workgroups per CU (a multiple of 8, so that every XCD gets the same share); the workgroups are then
+// persistent and take further tiles from a per-XCD queue (see k_f_tile).  Measured on the 1M-node mesh (round 2, one box,
+// plain f): one workgroup per tile 57.7 - 58.7 us; persistent with static striding 60.9 - 62.2 us; persistent with the
+// atomic queue 62.6 - 64.8 us (5 per CU), 61.1 - 62.6 us (6 per CU) -- the hardware dispatcher refills a CU faster than a
+// loop whose next index is an atomic's return value sitting in front of the tile's first loads.  Kept for A/B runs.
+static unsigned tile_grid(int chunk) {
+  static const int cap = [] {
+    const char* e = getenv("PSIGNN_WG_PER_CU");
+    const int per_cu = e ? atoi(e) : 0;
+    if (per_cu <= 0) return 0;
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    return std::max(8, per_cu * cus / 8 * 8);
+  }();
+  const int full = chunk * 8;
+  return (unsigned)((cap > 0 && full > cap) ? cap : full);
+}
+
+static FuseArgs plain_args() {
+  FuseArgs a{};
+  a.stamps = g_tile_stamps;
+  return a;
+}
 
 // Mixed family: two launches over disjoint tile groups.  Tiles without Neumann nodes (all but the boundary tiles) run the
 // kernel WITHOUT the Neumann branch and with 80-byte LDS rows (the Phi_neumann columns are only read by Neumann lanes);
@@ -474,12 +754,12 @@ static void launch_mixed(const psignn_plan* p, const FuseArgs& fa, const char* n
   const int32_t* list_b = na > 0 ? p->tile_order + na : nullptr;
   if (na > 0) {
     const int chunk = (int)cdiv(na, 8);
-    LAUNCH(name, st, (k_f_tile<3, false, FUSED, false><<<(unsigned)(chunk * 8), TILE_THREADS, (size_t)p->max_rows * TileRow<false>::RS * 4, st>>>(
+    LAUNCH(name, st, (k_f_tile<3, false, FUSED, false><<<tile_grid(chunk), TILE_THREADS, (size_t)p->max_rows * TileRow<false>::RS * 4, st>>>(
         fa, na, chunk, p->tile_order, TILE_ARGS, W, lofs, tofs, tnofs, 1, h, hsel, hstride, h0, prb, nrm, out)));
   }
   if (nb > 0) {
     const int chunk = (int)cdiv(nb, 8);
-    LAUNCH(name, st, (k_f_tile<3, true, FUSED, false><<<(unsigned)(chunk * 8), TILE_THREADS, (size_t)p->max_rows * TileRow<true>::RS * 4, st>>>(
+    LAUNCH(name, st, (k_f_tile<3, true, FUSED, false><<<tile_grid(chunk), TILE_THREADS, (size_t)p->max_rows * TileRow<true>::RS * 4, st>>>(
         fa, nb, chunk, list_b, TILE_ARGS, W, lofs, tofs, tnofs, 1, h, hsel, hstride, h0, prb, nrm, out)));
   }
 }
@@ -492,16 +772,16 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
   ARG_CHECK(W && h && h0 && prb && out, "NULL argument");
   ARG_CHECK(!p->mixed || nrm, "mixed plan needs unit normals");
   const int chunk = (int)cdiv(p->n_tiles, 8);
-  const unsigned grid = (unsigned)(chunk * 8);
+  const unsigned grid = tile_grid(chunk);
   if (p->mixed) {
     using L = WLayout<3>;
     if (stage1_mfma(false, true)) {  // single launch, MFMA stage 1 (PSIGNN_STAGE1=mfma)
       size_t lds = (size_t)p->max_rows * TileRow<true>::RS * 4;
       LAUNCH("k_f_tile", st, (k_f_tile<3, true, false, true><<<grid, TILE_THREADS, lds, st>>>(
-        FuseArgs{}, (int)p->n_tiles, chunk, nullptr, TILE_ARGS, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), L::tp_neu(nl), 1,
+        plain_args(), (int)p->n_tiles, chunk, nullptr, TILE_ARGS, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), L::tp_neu(nl), 1,
         h, hsel, hstride, h0, prb, nrm, out)));
     } else {
-      launch_mixed<false>(p, FuseArgs{}, "k_f_tile", W, nl, h, hsel, hstride, h0, prb, nrm, out, st);
+      launch_mixed<false>(p, plain_args(), "k_f_tile", W, nl, h, hsel, hstride, h0, prb, nrm, out, st);
     }
   } else {
     using L = WLayout<2>;
@@ -513,11 +793,11 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
       float* dst = (l == nl - 1) ? out : pp[l & 1];
       if (stage1_mfma(false, false))
         LAUNCH("k_f_tile", st, (k_f_tile<2, false, false, true><<<grid, TILE_THREADS, lds, st>>>(
-            FuseArgs{}, (int)p->n_tiles, chunk, nullptr, TILE_ARGS, W, L::layer(l), L::tp_layer(nl, false, l), 0, l == nl - 1, cur,
+            plain_args(), (int)p->n_tiles, chunk, nullptr, TILE_ARGS, W, L::layer(l), L::tp_layer(nl, false, l), 0, l == nl - 1, cur,
             l == 0 ? hsel : nullptr, hstride, h0, prb, nrm, dst)));
       else
         LAUNCH("k_f_tile", st, (k_f_tile<2, false, false, false><<<grid, TILE_THREADS, lds, st>>>(
-            FuseArgs{}, (int)p->n_tiles, chunk, nullptr, TILE_ARGS, W, L::layer(l), L::tp_layer(nl, false, l), 0, l == nl - 1, cur,
+            plain_args(), (int)p->n_tiles, chunk, nullptr, TILE_ARGS, W, L::layer(l), L::tp_layer(nl, false, l), 0, l == nl - 1, cur,
             l == 0 ? hsel : nullptr, hstride, h0, prb, nrm, dst)));
       cur = dst;
     }
@@ -534,9 +814,9 @@ int psignn_f_tile_fused(const psignn_plan* p, const float* W, int nl, float* xbu
   ARG_CHECK(p && p->tiled, "plan has no tile structures");
   ARG_CHECK(nl == 1 || p->mixed, "fused step supports single-layer evaluation");
   const int chunk = (int)cdiv(p->n_tiles, 8);
-  const unsigned grid = (unsigned)(chunk * 8);
+  const unsigned grid = tile_grid(chunk);
   const int npart = (int)p->n_tiles;
-  FuseArgs fa{upd, gx, dg, xbuf, st_words, off_done, off_cur, off_nxt, M, part, npart};
+  FuseArgs fa{upd, gx, dg, xbuf, st_words, off_done, off_cur, off_nxt, M, part, npart, g_tile_stamps};
   if (p->mixed) {
     using L = WLayout<3>;
     if (stage1_mfma(true, true)) {

@@ -14,15 +14,11 @@
 // (norms, traces, lowest iterate, the three stop tests of solver.py:176-183) lives in a device-side
 // status block; the host only polls a done flag.  Reductions use fixed-shape partial sums ->
 // bitwise reproducible run to run.
-#include "common.h"
+#include "vec_helpers.h"
 #include <stdlib.h>
 #include <math.h>
 #include <algorithm>
 #include <vector>
-
-// The vector kernels are templated on VEC = elements per thread (16 for long vectors, 4 when N*d is small so that
-// the grid still covers the 256 CUs; chosen at solver creation).
-#define TB 256           // threads per block
 
 struct Status {
   int32_t n_iter;       // iterations done
@@ -73,87 +69,6 @@ struct psignn_broyden {
   std::vector<hipGraphExec_t> graphs;
   uint64_t graph_key = 0;
 };
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-// Two per-lane values -> ONE pair per block (wave shuffles, then the 4 wave sums through LDS, fixed order).
-__device__ __forceinline__ void block_pair_store(float a, float b, float* __restrict__ part, int n) {
-  __shared__ float red[2][TB / 64];
-  a = wave_sum(a);
-  b = wave_sum(b);
-  if ((threadIdx.x & 63) == 0) {
-    red[0][threadIdx.x >> 6] = a;
-    red[1][threadIdx.x >> 6] = b;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    part[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    part[n + blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-  }
-}
-
-
-// Thread -> element mapping of every vector kernel: a wave owns 64*VEC contiguous floats and reads them as VEC/4
-// fully coalesced float4 rows (lane l takes floats [256*i + 4*l, +4) of the wave's span), so one load instruction
-// covers 8 whole 128-byte lines instead of a quarter of 32 lines.  elem0 is the thread's lowest element.
-template <int VEC>
-__device__ __forceinline__ int64_t elem0() {
-  return ((int64_t)blockIdx.x * TB + (threadIdx.x & ~63)) * VEC + (threadIdx.x & 63) * 4;
-}
-template <int VEC>
-__device__ __forceinline__ void ldv(const float* __restrict__ p, int64_t e0, int64_t M, float* r) {
-#pragma unroll
-  for (int i = 0; i < VEC / 4; ++i) {
-    const int64_t o = e0 + i * 256;
-    if (o + 4 <= M) {
-      float4 t = *reinterpret_cast<const float4*>(p + o);
-      r[4 * i] = t.x; r[4 * i + 1] = t.y; r[4 * i + 2] = t.z; r[4 * i + 3] = t.w;
-    } else {  // tail
-#pragma unroll
-      for (int c = 0; c < 4; ++c) r[4 * i + c] = (o + c < M) ? p[o + c] : 0.f;
-    }
-  }
-}
-// Loads of the U / V sweeps.  Non-temporal loads were measured and REJECTED: although every byte is read once
-// per pass, k_dots / k_axpy at N = 1M, k = 0..49 took 557 / 550 us per launch with nt against 365 / 382 us with
-// default-policy loads (round 1, MI355X).  -DPSIGNN_NT_SWEEPS=1 rebuilds the nt variant for A/B timing.
-#ifndef PSIGNN_NT_SWEEPS
-#define PSIGNN_NT_SWEEPS 0
-#endif
-typedef float f4v __attribute__((ext_vector_type(4)));
-template <int VEC>
-__device__ __forceinline__ void ldv_stream(const float* __restrict__ p, int64_t e0, int64_t M, float* r) {
-#if PSIGNN_NT_SWEEPS
-  if (e0 + (VEC / 4 - 1) * 256 + 4 <= M) {
-#pragma unroll
-    for (int i = 0; i < VEC / 4; ++i) {
-      f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p + e0 + i * 256));
-      r[4 * i] = t.x; r[4 * i + 1] = t.y; r[4 * i + 2] = t.z; r[4 * i + 3] = t.w;
-    }
-    return;
-  }
-#endif
-  ldv<VEC>(p, e0, M, r);
-}
-
-template <int VEC>
-__device__ __forceinline__ void stv(float* __restrict__ p, int64_t e0, int64_t M, const float* r) {
-#pragma unroll
-  for (int i = 0; i < VEC / 4; ++i) {
-    const int64_t o = e0 + i * 256;
-    if (o + 4 <= M) {
-      *reinterpret_cast<float4*>(p + o) = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
-    } else {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (o + c < M) p[o + c] = r[4 * i + c];
-    }
-  }
-}
 
 __global__ void k_init_status(Status* st, double* rel_trace, double* abs_trace, int thr, int stop_abs = 0) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -250,28 +165,6 @@ __global__ __launch_bounds__(TB) void k_resid(int64_t M, const Status* __restric
   block_pair_store(sg, sf, part, npart);
 }
 
-__device__ double block_sum_partials(const float* __restrict__ p, int n, double* sh) {
-  // fixed summation shape (lane-strided, 4 independent accumulators, then a tree): reproducible, and the
-  // loads of one lane do not wait on each other (a dependent scalar loop here cost 20-30 us per call)
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int i = threadIdx.x;
-  for (; i + 3 * TB < n; i += 4 * TB) {
-    float a = p[i], b = p[i + TB], c = p[i + 2 * TB], d = p[i + 3 * TB];
-    s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
-  }
-  for (; i < n; i += TB) s0 += (double)p[i];
-  double s = (s0 + s1) + (s2 + s3);
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = TB / 2; o > 0; o >>= 1) {
-    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-    __syncthreads();
-  }
-  double r = sh[0];
-  __syncthreads();
-  return r;
-}
-
 // One block: finish the norms, append to the traces, track the lowest iterate, run the stop tests
 // (solver.py:160-183) and rotate the iterate buffers.
 __device__ void check_block(Status* st, const float* __restrict__ part, int npart, double* __restrict__ rel_trace,
@@ -344,7 +237,7 @@ __device__ void check_block(Status* st, const float* __restrict__ part, int npar
 
 // dots pass: per-wave partials of a_j = dx.U_j, c_j = V_j.dg, b_j = V_j.g   for j < k
 template <int VEC>
-__global__ __launch_bounds__(TB) void k_dots(int64_t M, int k, const Status* __restrict__ st,
+__device__ __forceinline__ void dots_body(int64_t M, int k, const Status* __restrict__ st,
                                              const float* __restrict__ U, const float* __restrict__ V,
                                              const float* __restrict__ dxv, const float* __restrict__ dgv,
                                              const float* __restrict__ gv, float* __restrict__ part, int npart, int thr,
@@ -390,17 +283,24 @@ __global__ __launch_bounds__(TB) void k_dots(int64_t M, int k, const Status* __r
     }
   }
 }
+template <int VEC>
+__global__ __launch_bounds__(TB) void k_dots(int64_t M, int k, const Status* __restrict__ st,
+                                             const float* __restrict__ U, const float* __restrict__ V,
+                                             const float* __restrict__ dxv, const float* __restrict__ dgv,
+                                             const float* __restrict__ gv, float* __restrict__ part, int npart, int thr,
+                                             int jstride, int64_t ld) {
+  dots_body<VEC>(M, k, st, U, V, dxv, dgv, gv, part, npart, thr, jstride, ld);
+}
 
 // One launch after the dots pass, grid = (max(k, 1), 4):
 //   blocks (j, c < 3), j < k: coef[c][j] = sum of the dots partials;
 //   block (0, 3): the iteration's bookkeeping (check_block) from the norm partials of the f / residual kernel.
 // The check used to be its own launch before the dots pass; running it here saves a launch per iteration.  The dots
 // pass of the final iteration then runs once more than needed (its results are ignored: every later kernel sees done).
-__global__ __launch_bounds__(TB) void k_reduce_check(Status* st, const float* __restrict__ part, int npart, int thr, int k,
+__device__ __forceinline__ void reduce_check_body(Status* st, const float* __restrict__ part, int npart, int thr, int k,
                                                      float* __restrict__ coef, const float* __restrict__ nrm_part, int nn,
                                                      double* __restrict__ rel_trace, double* __restrict__ abs_trace,
-                                                     double eps, int seq_len, int keep_trace) {
-  __shared__ double sh[TB];
+                                                     double eps, int seq_len, int keep_trace, double* sh) {
   if (blockIdx.y == 3) {
     if (blockIdx.x == 0) check_block(st, nrm_part, nn, rel_trace, abs_trace, eps, thr, seq_len, keep_trace, sh);
     return;
@@ -410,6 +310,13 @@ __global__ __launch_bounds__(TB) void k_reduce_check(Status* st, const float* __
   if (j >= k) return;
   double s = block_sum_partials(part + ((int64_t)c * thr + j) * npart, npart, sh);
   if (threadIdx.x == 0) coef[c * thr + j] = (float)s;
+}
+__global__ __launch_bounds__(TB) void k_reduce_check(Status* st, const float* __restrict__ part, int npart, int thr, int k,
+                                                     float* __restrict__ coef, const float* __restrict__ nrm_part, int nn,
+                                                     double* __restrict__ rel_trace, double* __restrict__ abs_trace,
+                                                     double eps, int seq_len, int keep_trace) {
+  __shared__ double sh[TB];
+  reduce_check_body(st, part, npart, thr, k, coef, nrm_part, nn, rel_trace, abs_trace, eps, seq_len, keep_trace, sh);
 }
 
 // axpy pass.  Writes vT (NaN->0) to V[k], D1 to U[k] (unscaled), D2 to upd, partials of vT.dg, vT.g.
@@ -431,13 +338,12 @@ __device__ __forceinline__ void axpy_finish(int64_t M, int k, int64_t e0, float*
 }
 
 template <int VEC>
-__global__ __launch_bounds__(TB) void k_axpy(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
+__device__ __forceinline__ void axpy_body(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
                                              float* __restrict__ V, float* __restrict__ upd /* in: dx, out: D2 */,
                                              const float* __restrict__ dgv, const float* __restrict__ gv,
                                              const float* __restrict__ coef, int thr, float* __restrict__ part, int npart,
-                                             int jstride, float* __restrict__ jpart, int64_t ld) {
+                                             int jstride, float* __restrict__ jpart, int64_t ld, const bool split) {
   if (st->done) return;
-  const bool split = gridDim.y > 1;
   const int j0 = blockIdx.y * jstride, j1 = min(k, j0 + jstride);
   int64_t e0 = elem0<VEC>();
   float p1 = 0.f, p2 = 0.f;
@@ -481,10 +387,18 @@ __global__ __launch_bounds__(TB) void k_axpy(int64_t M, int k, const Status* __r
   if (split) return;
   block_pair_store(p1, p2, part, npart);
 }
+template <int VEC>
+__global__ __launch_bounds__(TB) void k_axpy(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
+                                             float* __restrict__ V, float* __restrict__ upd /* in: dx, out: D2 */,
+                                             const float* __restrict__ dgv, const float* __restrict__ gv,
+                                             const float* __restrict__ coef, int thr, float* __restrict__ part, int npart,
+                                             int jstride, float* __restrict__ jpart, int64_t ld) {
+  axpy_body<VEC>(M, k, st, U, V, upd, dgv, gv, coef, thr, part, npart, jstride, jpart, ld, gridDim.y > 1);
+}
 
 // second half of a split axpy pass: init terms + the G partial sums, in group order
 template <int VEC>
-__global__ __launch_bounds__(TB) void k_axpy_combine(int64_t M, int k, int G, const Status* __restrict__ st,
+__device__ __forceinline__ void axpy_combine_body(int64_t M, int k, int G, const Status* __restrict__ st,
                                                      const float* __restrict__ jpart, float* __restrict__ U,
                                                      float* __restrict__ V, float* __restrict__ upd,
                                                      const float* __restrict__ dgv, const float* __restrict__ gv,
@@ -519,15 +433,22 @@ __global__ __launch_bounds__(TB) void k_axpy_combine(int64_t M, int k, int G, co
   }
   block_pair_store(p1, p2, part, npart);
 }
+template <int VEC>
+__global__ __launch_bounds__(TB) void k_axpy_combine(int64_t M, int k, int G, const Status* __restrict__ st,
+                                                     const float* __restrict__ jpart, float* __restrict__ U,
+                                                     float* __restrict__ V, float* __restrict__ upd,
+                                                     const float* __restrict__ dgv, const float* __restrict__ gv,
+                                                     float* __restrict__ part, int npart, int64_t ld) {
+  axpy_combine_body<VEC>(M, k, G, st, jpart, U, V, upd, dgv, gv, part, npart, ld);
+}
 
 // u = D1 / s (NaN -> 0) -> U[k] ;  update = D2 - u * beta
 template <int VEC>
-__global__ __launch_bounds__(TB) void k_final(int64_t M, int k, Status* __restrict__ st, float* __restrict__ U,
+__device__ __forceinline__ void final_body(int64_t M, int k, Status* __restrict__ st, float* __restrict__ U,
                                               float* __restrict__ upd, int64_t ld, const float* __restrict__ part,
-                                              int npart) {
+                                              int npart, double* sh) {
   // every block first finishes s = vT.dg and beta = vT.g from the axpy pass's per-block partials (fixed order, fp64,
   // rounded to fp32 like the reference's .item() values) -- formerly a single-block launch of its own
-  __shared__ double sh[TB];
   if (st->done) return;
   const float s = (float)block_sum_partials(part, npart, sh);
   const float beta = (float)block_sum_partials(part + npart, npart, sh);
@@ -551,6 +472,13 @@ __global__ __launch_bounds__(TB) void k_final(int64_t M, int k, Status* __restri
   stv<VEC>(Uk, e0, M, u);
   stv<VEC>(upd, e0, M, d2);
 }
+template <int VEC>
+__global__ __launch_bounds__(TB) void k_final(int64_t M, int k, Status* __restrict__ st, float* __restrict__ U,
+                                              float* __restrict__ upd, int64_t ld, const float* __restrict__ part,
+                                              int npart) {
+  __shared__ double sh[TB];
+  final_body<VEC>(M, k, st, U, upd, ld, part, npart, sh);
+}
 
 template <int VEC>
 __global__ __launch_bounds__(TB) void k_copy_sel(int64_t M, const float* __restrict__ xb, const int32_t* __restrict__ sel,
@@ -562,15 +490,6 @@ __global__ __launch_bounds__(TB) void k_copy_sel(int64_t M, const float* __restr
   ldv<VEC>(xb + (int64_t)idx * M, e0, M, a);
   stv<VEC>(dst, e0, M, a);
 }
-
-// launch a VEC-templated kernel with the solver's vector width
-#define VPLAIN(vec, kern, cfg, ...)                                     \
-  do {                                                                  \
-    if ((vec) == 16) kern<16><<<VCFG cfg>>>(__VA_ARGS__);               \
-    else kern<4><<<VCFG cfg>>>(__VA_ARGS__);                            \
-  } while (0)
-#define VCFG(...) __VA_ARGS__
-#define VLAUNCH(name, st, vec, kern, cfg, ...) LAUNCH(name, st, VPLAIN(vec, kern, cfg, __VA_ARGS__))
 
 // ------------------------------------------------------------------------------------------ host
 // f kernels with a device-selected input buffer (fgnn.hip)
@@ -865,6 +784,172 @@ extern "C" int psignn_broyden_solve(psignn_broyden_t* s, const float* W, int nl,
     }
   }
   return finish(s, d_result, info, h_rel, h_abs, st);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Batched solve: the meshes of one shard (BASELINE configs[3]: 8 independent 50k-node meshes per GPU) iterate in lockstep,
+// every per-iteration pass is ONE launch over all of them (blockIdx.z = mesh).  Eight concurrent single-mesh solves on
+// eight streams reach 3.7 TB/s aggregate -- barely more than one solve alone: each of their kernels spans the chip and pays
+// its own ramp and tail.  A block runs the single-mesh kernels' bodies on its mesh's descriptor: same block -> element
+// mapping, same partial-sum shapes, own status block and stop test per mesh  =>  bit-identical to the mesh's own solve.
+// ------------------------------------------------------------------------------------------
+static __device__ __forceinline__ int batch_groups(const BatchDesc& d, int k) {
+  return (d.jgroups > 1 && k >= 4 * d.jgroups) ? d.jgroups : 1;
+}
+static __device__ __forceinline__ int idiv_up(int a, int b) { return (a + b - 1) / b; }
+
+template <int VEC>
+__global__ __launch_bounds__(TB) void kb_dots(const BatchDesc* __restrict__ descs, int k) {
+  const BatchDesc& d = descs[blockIdx.z];
+  const int G = batch_groups(d, k);
+  if ((int)blockIdx.x >= d.nblk || (int)blockIdx.y >= G) return;
+  dots_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.V, d.upd, d.dg, d.gx, d.part, d.npart, d.thr,
+                 idiv_up(k > 1 ? k : 1, G), d.ld);
+}
+__global__ __launch_bounds__(TB) void kb_reduce_check(const BatchDesc* __restrict__ descs, int k, double eps) {
+  __shared__ double sh[TB];
+  const BatchDesc& d = descs[blockIdx.z];
+  reduce_check_body(reinterpret_cast<Status*>(d.st), d.part, d.npart, d.thr, k, d.coef, d.nrm_part, d.n_tiles, d.rel_trace,
+                    d.abs_trace, eps, d.seq_len, d.keep_trace, sh);
+}
+template <int VEC>
+__global__ __launch_bounds__(TB) void kb_axpy(const BatchDesc* __restrict__ descs, int k, int own_width) {
+  const BatchDesc& d = descs[blockIdx.z];
+  // own_width: the axpy / final passes run unsplit with their own vector width (broyden_alloc: vec_ax != vec)
+  const int G = own_width ? 1 : batch_groups(d, k);
+  const int nb = own_width ? d.nblk_ax : d.nblk;
+  if ((int)blockIdx.x >= nb || (int)blockIdx.y >= G) return;
+  axpy_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.V, d.upd, d.dg, d.gx, d.coef, d.thr, d.part, nb,
+                 idiv_up(k > 1 ? k : 1, G), d.jpart, d.ld, G > 1);
+}
+template <int VEC>
+__global__ __launch_bounds__(TB) void kb_axpy_combine(const BatchDesc* __restrict__ descs, int k) {
+  const BatchDesc& d = descs[blockIdx.z];
+  const int G = batch_groups(d, k);
+  if ((int)blockIdx.x >= d.nblk || G <= 1) return;
+  axpy_combine_body<VEC>(d.M, k, G, reinterpret_cast<const Status*>(d.st), d.jpart, d.U, d.V, d.upd, d.dg, d.gx, d.part, d.nblk, d.ld);
+}
+template <int VEC>
+__global__ __launch_bounds__(TB) void kb_final(const BatchDesc* __restrict__ descs, int k, int own_width) {
+  __shared__ double sh[TB];
+  const BatchDesc& d = descs[blockIdx.z];
+  const int nb = own_width ? d.nblk_ax : d.nblk;
+  if ((int)blockIdx.x >= nb) return;
+  final_body<VEC>(d.M, k, reinterpret_cast<Status*>(d.st), d.U, d.upd, d.ld, d.part, nb, sh);
+}
+// *all_done = 1 when every mesh's stop test has fired
+__global__ void kb_all_done(const BatchDesc* __restrict__ descs, int n, int off_done, int32_t* __restrict__ all_done) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int a = 1;
+    for (int m = 0; m < n; ++m) a &= descs[m].st[off_done] != 0;
+    *all_done = a;
+  }
+}
+
+int psignn_f_tile_fused_batch(const BatchDesc* d_descs, int n_mesh, int n_slots, int max_rows, int32_t* d_ctr, const float* W,
+                              int off_done, int off_cur, int off_nxt, hipStream_t st);
+
+extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const float* W, int nl, const float* const* h0,
+                                          const float* const* prb, double eps, int poll_every, float* const* d_results,
+                                          psignn_solve_info_t* infos, double* const* h_rel, double* const* h_abs, void* stream) {
+  ARG_CHECK(n > 0 && sv && W && h0 && prb, "bad arguments");
+  ARG_CHECK(nl == 1, "the batched solver runs single-layer blocks");
+  hipStream_t st = (hipStream_t)stream;
+  if (poll_every <= 0) poll_every = 8;
+  // one vector width / split layout / threshold for the whole shard (meshes of one shard are of one size class)
+  const psignn_broyden* s0 = sv[0];
+  int max_g = 0, max_ga = 0, max_G = 1, max_rows = 0, n_slots = 0;
+  for (int m = 0; m < n; ++m) {
+    const psignn_broyden* s = sv[m];
+    ARG_CHECK(s && s->plan && s->plan->tiled && !s->plan->mixed, "batched solve: tiled dirichlet plans only");
+    ARG_CHECK(s->vec == s0->vec && s->vec_ax == s0->vec_ax && s->thr == s0->thr,
+              "batched solve: meshes of different size classes (vector width / threshold differ)");
+    ARG_CHECK(h0[m] && prb[m], "NULL argument");
+    max_g = std::max(max_g, s->nblk);
+    max_ga = std::max(max_ga, s->nblk_ax);
+    max_G = std::max(max_G, s->jgroups);
+    max_rows = std::max(max_rows, s->plan->max_rows);
+    n_slots += (int)s->plan->n_tiles;
+  }
+  const bool own_width = s0->vec_ax != s0->vec;
+  // ---- per mesh: status, plan-order inputs, g0 = f(x0) - x0 (exactly the single-mesh prologue)
+  std::vector<BatchDesc> hd(n);
+  int rc, base = 0;
+  for (int m = 0; m < n; ++m) {
+    psignn_broyden* s = sv[m];
+    const psignn_plan* p = s->plan;
+    s->plan_order = 1;
+    k_init_status<<<4, TB, 0, st>>>(s->st, s->rel_trace, s->abs_trace, s->thr, s->stop_abs);
+    if ((rc = psignn_plan_permute(p, h0[m], D, s->h0p, 1, st))) return rc;
+    if ((rc = psignn_plan_permute(p, prb[m], 2, s->prbp, 1, st))) return rc;
+    if ((rc = psignn_f_eval_p(p, W, nl, s->h0p, nullptr, 0, s->h0p, s->prbp, nullptr, s->fx, s->fwork, st))) return rc;
+    VPLAIN(s->vec, k_begin, ((unsigned)s->nblk, TB, 0, st), s->M, s->h0p, s->fx, s->xbuf, s->gx, s->upd);
+    BatchDesc& d = hd[m];
+    d.M = s->M; d.ld = s->ld; d.nblk = s->nblk; d.npart = s->npart; d.nblk_ax = s->nblk_ax; d.jgroups = s->jgroups;
+    d.thr = s->thr; d.seq_len = s->seq_len; d.keep_trace = s->keep_trace; d.n_tiles = (int)p->n_tiles; d.tile_base = base;
+    d.st = reinterpret_cast<int32_t*>(s->st);
+    d.U = s->U; d.V = s->V; d.xbuf = s->xbuf; d.gx = s->gx; d.dg = s->dg; d.upd = s->upd; d.part = s->part; d.coef = s->coef;
+    d.nrm_part = s->nrm_part; d.jpart = s->jpart; d.rel_trace = s->rel_trace; d.abs_trace = s->abs_trace;
+    d.ctx = p->d_ctx; d.h0p = s->h0p; d.prbp = s->prbp;
+    base += (int)p->n_tiles;
+  }
+  BatchDesc* d_descs = nullptr;
+  int32_t *d_ctr = nullptr, *d_done = nullptr, *h_done = nullptr;
+  auto cleanup = [&]() {
+    if (d_descs) (void)hipFree(d_descs);
+    if (d_ctr) (void)hipFree(d_ctr);
+    if (d_done) (void)hipFree(d_done);
+    if (h_done) (void)hipHostFree(h_done);
+  };
+#define BT(expr)                                                                          \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      psignn_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      cleanup();                                                                          \
+      return PSIGNN_EHIP;                                                                 \
+    }                                                                                     \
+  } while (0)
+  BT(hipMalloc((void**)&d_descs, sizeof(BatchDesc) * n));
+  BT(hipMalloc((void**)&d_ctr, 9 * 32 * 4));
+  BT(hipMalloc((void**)&d_done, 4));
+  BT(hipHostMalloc((void**)&h_done, 4));
+  BT(hipMemcpyAsync(d_descs, hd.data(), sizeof(BatchDesc) * n, hipMemcpyHostToDevice, st));
+  BT(hipMemsetAsync(d_ctr, 0, 9 * 32 * 4, st));
+  const int off_done = offsetof(Status, done) / 4;
+  const int thr = s0->thr;
+  for (int it = 0; it < thr; ++it) {
+    rc = psignn_f_tile_fused_batch(d_descs, n, n_slots, max_rows, d_ctr, W, off_done, sel_off_cur(), sel_off_nxt(), st);
+    if (rc) { cleanup(); return rc; }
+    const int k = it;
+    const int kd = k >= thr ? 0 : k;
+    if (kd > 0)
+      VLAUNCH("k_dots", st, s0->vec, kb_dots, (dim3((unsigned)max_g, (unsigned)max_G, (unsigned)n), TB, 0, st), d_descs, kd);
+    LAUNCH("k_reduce_check", st, (kb_reduce_check<<<dim3((unsigned)std::max(kd, 1), 4, (unsigned)n), TB, 0, st>>>(d_descs, kd, eps)));
+    if (own_width) {
+      VLAUNCH("k_axpy", st, s0->vec_ax, kb_axpy, (dim3((unsigned)max_ga, 1, (unsigned)n), TB, 0, st), d_descs, k, 1);
+      VLAUNCH("k_final", st, s0->vec_ax, kb_final, (dim3((unsigned)max_ga, 1, (unsigned)n), TB, 0, st), d_descs, k, 1);
+    } else {
+      VLAUNCH("k_axpy", st, s0->vec, kb_axpy, (dim3((unsigned)max_g, (unsigned)max_G, (unsigned)n), TB, 0, st), d_descs, k, 0);
+      if (max_G > 1 && k >= 4 * 2)   // some mesh may split from k = 4 * jgroups on (jgroups >= 2)
+        VLAUNCH("k_axpy_combine", st, s0->vec, kb_axpy_combine, (dim3((unsigned)max_g, 1, (unsigned)n), TB, 0, st), d_descs, k);
+      VLAUNCH("k_final", st, s0->vec, kb_final, (dim3((unsigned)max_g, 1, (unsigned)n), TB, 0, st), d_descs, k, 0);
+    }
+    if ((it + 1) % poll_every == 0 || it + 1 == thr) {
+      kb_all_done<<<1, 64, 0, st>>>(d_descs, n, off_done, d_done);
+      BT(hipMemcpyAsync(h_done, d_done, 4, hipMemcpyDeviceToHost, st));
+      BT(hipStreamSynchronize(st));
+      if (*h_done) break;
+    }
+  }
+  rc = PSIGNN_OK;
+  for (int m = 0; m < n && rc == PSIGNN_OK; ++m)
+    rc = finish(sv[m], d_results ? d_results[m] : nullptr, infos ? &infos[m] : nullptr, h_rel ? h_rel[m] : nullptr,
+                h_abs ? h_abs[m] : nullptr, st);
+  cleanup();
+#undef BT
+  return rc;
 }
 
 

@@ -30,11 +30,19 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
 
 // acc[p] += WT[k][2p..2p+1] * x[k],  p < 5, k < K
+// A 10 x 10 block is 100 wave-uniform weights -- with the wave's other live SGPRs more than the 102 there are, and the
+// compiler, which loads a whole block ahead of its first use, then parks the excess in VGPR lanes (v_writelane /
+// v_readlane: 36 VALU slots per stage-1 round in round 1's build).  A compiler barrier every MV2_CH inputs keeps at most
+// MV2_CH x 10 weights in flight.
+#ifndef MV2_CH
+#define MV2_CH 5
+#endif
 template <int K>
 __device__ __forceinline__ void mv2(const float* __restrict__ WT, const float* x, v2f* acc) {
   const v2f* w = reinterpret_cast<const v2f*>(WT);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
+    if (MV2_CH > 0 && k > 0 && k % MV2_CH == 0) PHASE();
     const v2f xs = splat(x[k]);
 #pragma unroll
     for (int p = 0; p < 5; ++p) acc[p] = __builtin_elementwise_fma(w[k * 5 + p], xs, acc[p]);
@@ -141,7 +149,7 @@ template <int RS>
 __device__ __forceinline__ void edge_pass_both_clamp(const uint4* __restrict__ slots, int nslots, const float* __restrict__ lds,
                                                      const float* __restrict__ AT_to, const float* __restrict__ AT_fr,
                                                      const v2f* Pi_to, const v2f* Pi_fr, v2f* S_to, v2f* S_fr,
-                                                     float& deg_in, float& deg_out) {
+                                                     float& deg_in, float& deg_out, const uint4* first = nullptr) {
   v2f wt[15], wf[15], pt[5], pf[5];
 #pragma unroll
   for (int i = 0; i < 15; ++i) {
@@ -156,7 +164,7 @@ __device__ __forceinline__ void edge_pass_both_clamp(const uint4* __restrict__ s
   }
   deg_in = deg_out = 0.f;
   if (nslots <= 0) return;
-  uint4 c0 = slots[0];
+  uint4 c0 = first ? *first : slots[0];   // `first`: slot row 0, loaded by the caller ahead of time
 #if CLAMP_PD == 2
   uint4 c1 = slots[(int64_t)min(1, nslots - 1) * 64];
 #endif

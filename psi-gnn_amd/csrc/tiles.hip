@@ -6,9 +6,12 @@
 // With nodes renumbered so that <= 256 consecutive ids form a compact patch of the mesh, a workgroup
 // stages the rows of its patch + halo in LDS once and every gather becomes a ds_read.
 //
-//   1. bin nodes into square cells of ~tile_target nodes (pos, bounding box, one refinement of the cell
-//      size from the occupied-cell count); counting sort by cell, node id ascending inside a cell
-//   2. cells -> tiles (cells above TILE_MAX nodes are split evenly); tiles -> 64-lane slices
+//   1. order the nodes along a Hilbert curve: fine square cells (~4 nodes each, a 2^k x 2^k grid over the bounding box),
+//      cell key = Hilbert index, counting sort by key, node id ascending inside a cell
+//   2. tiles = consecutive chunks of exactly tile_target (256) nodes of that order -- every workgroup of the tile kernels
+//      has all its lanes busy (cells sized for "at most 256" left 12 % of the lanes idle: 226 nodes per tile on the
+//      1M-node mesh) and a chunk of a Hilbert curve is a compact blob at any local mesh density; node ids are then
+//      sorted ascending inside each tile; tiles -> 64-lane slices
 //   3. per tile: halo = sorted distinct out-of-tile neighbours (both directions)
 //   4. per slice: pair-merged ELL slot-rows x 64 lanes: one 16-byte slot per neighbour {LDS row, IN/OUT, attr}
 //      (see 'pair-merged ELL' below), in the canonical neighbour order of the CSR/CSC plan
@@ -18,6 +21,7 @@
 #include <math.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 
 #define SORT_CAP 4096
 #define CAND_CAP 4096
@@ -51,12 +55,27 @@ __global__ void k_bbox(int64_t N, const float* __restrict__ pos, uint32_t* __res
   }
 }
 
+// Hilbert index of cell (cx, cy) on a 2^k x 2^k grid (the classic xy -> d walk, k <= 12).  nx = ny = 2^k.
 __device__ __forceinline__ int cell_of(float x, float y, float xmin, float ymin, float inv_cs, int nx, int ny) {
   int cx = (int)floorf((x - xmin) * inv_cs);
   int cy = (int)floorf((y - ymin) * inv_cs);
   cx = min(max(cx, 0), nx - 1);
   cy = min(max(cy, 0), ny - 1);
-  return cy * nx + cx;
+  int d = 0;
+  for (int s = nx >> 1; s > 0; s >>= 1) {
+    const int rx = (cx & s) ? 1 : 0, ry = (cy & s) ? 1 : 0;
+    d += s * s * ((3 * rx) ^ ry);
+    if (!ry) {  // rotate the quadrant
+      if (rx) {
+        cx = nx - 1 - cx;
+        cy = nx - 1 - cy;
+      }
+      const int t = cx;
+      cx = cy;
+      cy = t;
+    }
+  }
+  return d;
 }
 
 __global__ void k_cell_count(int64_t N, const float* __restrict__ pos, float xmin, float ymin, float inv_cs, int nx,
@@ -302,11 +321,11 @@ int psignn_exclusive_scan(const int32_t* in, int64_t n, int32_t* out, int32_t* b
 
 void psignn_tiles_free(psignn_plan* p) {
   void* ptrs[] = {p->perm, p->inv, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt,
-                  p->slice_off, p->slice_deg, p->ell, p->flags_p, p->tile_order};
+                  p->slice_off, p->slice_deg, p->ell, p->flags_p, p->tile_order, p->d_ctx, p->d_tile_ctr};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   p->perm = p->inv = p->tile_ptr = p->tile_slice = p->halo = p->halo_cnt = p->slice_off = nullptr;
-  p->slice_deg = nullptr; p->ell = nullptr; p->flags_p = nullptr; p->tile_order = nullptr;
+  p->slice_deg = nullptr; p->ell = nullptr; p->flags_p = nullptr; p->tile_order = nullptr; p->d_ctx = nullptr; p->d_tile_ctr = nullptr;
   p->tiled = 0;
 }
 
@@ -362,27 +381,21 @@ int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipS
     float xmin = o2f(h_box[0]), ymin = o2f(h_box[1]), xmax = o2f(h_box[2]), ymax = o2f(h_box[3]);
     if (!(isfinite(xmin) && isfinite(ymin) && isfinite(xmax) && isfinite(ymax))) goto done;  // NaN/inf positions: stay untiled
     double w = fmax((double)xmax - xmin, 1e-30), hgt = fmax((double)ymax - ymin, 1e-30);
-    // Cell size: the FULLEST cell should hold just under `goal` nodes, so that tiles fill the 256-lane
-    // workgroup (idle lanes are paid for in every f evaluation).  Start from the box area, then rescale by
-    // the measured maximum (domains do not fill their bounding box, meshes are not uniform).
-    const int goal = tile_target;
-    double cs = sqrt(0.75 * goal * w * hgt / (double)N);
-    int nx = 1, ny = 1;
-    for (int attempt = 0; attempt < 4; ++attempt) {
-      nx = (int)fmin(fmax(ceil(w / cs), 1.0), 32768.0);
-      ny = (int)fmin(fmax(ceil(hgt / cs), 1.0), 32768.0);
-      ncell = (int64_t)nx * ny;
-      if (cnt) { (void)hipFree(cnt); cnt = nullptr; }
-      HT(hipMalloc((void**)&cnt, (ncell + 1) * 4));
-      HT(hipMemsetAsync(cnt, 0, (ncell + 1) * 4, st));
-      k_cell_count<<<gn, TB, 0, st>>>(N, d_pos, xmin, ymin, (float)(1.0 / cs), nx, ny, cnt);
-      k_count_max<<<(unsigned)cdiv(ncell, TB), TB, 0, st>>>(ncell, cnt, cnt + ncell);
-      int32_t mx = 0;
-      HT(hipMemcpyAsync(&mx, cnt + ncell, 4, hipMemcpyDeviceToHost, st));
-      HT(hipStreamSynchronize(st));
-      if (attempt == 3 || (mx <= goal && mx >= 0.9 * goal) || mx <= 0) break;
-      cs *= sqrt(0.96 * goal / (double)mx);
-    }
+    // Fine cells of ~4 nodes on a 2^k x 2^k grid over the bounding square (side L = max(w, h)); the part of the grid
+    // inside the bounding box has G^2 w h / L^2 cells.  Ordering only: any k gives a correct plan.
+    const double L = fmax(w, hgt);
+    const double cells_wanted = fmax((double)N / 4.0, 1.0);
+    int k = (int)ceil(0.5 * log2(fmax(cells_wanted * L * L / (w * hgt), 1.0)));
+    const int kcap = (int)ceil(0.5 * log2(16.0 * (double)N));   // at most ~16 cells per node, however thin the domain
+    k = std::min(k, std::min(kcap, 12));
+    k = k < 0 ? 0 : k;
+    const int G = 1 << k;
+    const double cs = L / G * (1.0 + 1e-6);
+    const int nx = G, ny = G;
+    ncell = (int64_t)G * G;
+    HT(hipMalloc((void**)&cnt, (ncell + 1) * 4));
+    HT(hipMemsetAsync(cnt, 0, (ncell + 1) * 4, st));
+    k_cell_count<<<gn, TB, 0, st>>>(N, d_pos, xmin, ymin, (float)(1.0 / cs), nx, ny, cnt);
     p->cell_size = (float)cs; p->xmin = xmin; p->ymin = ymin; p->nx = nx; p->ny = ny;
     HT(hipMalloc((void**)&cptr, (ncell + 1) * 4));
     HT(hipMalloc((void**)&cur, ncell * 4));
@@ -390,28 +403,19 @@ int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipS
     HT(hipMemsetAsync(cur, 0, ncell * 4, st));
     if ((rc = psignn_exclusive_scan(cnt, ncell, cptr, bsum, st)) != 0) goto done;
     k_cell_fill<<<gn, TB, 0, st>>>(N, d_pos, xmin, ymin, (float)(1.0 / cs), nx, ny, cptr, cur, p->perm);
-    k_cell_sort<<<(unsigned)ncell, TB, 0, st>>>(cptr, p->perm, misc);
-    h_cptr.resize(ncell + 1);
-    HT(hipMemcpyAsync(h_cptr.data(), cptr, (ncell + 1) * 4, hipMemcpyDeviceToHost, st));
+    // node ids ascending inside a cell: the order (hence which nodes a chunk boundary cuts off) is deterministic
+    for (int64_t c0 = 0; c0 < ncell; c0 += 1 << 20)
+      k_cell_sort<<<(unsigned)std::min<int64_t>(ncell - c0, 1 << 20), TB, 0, st>>>(cptr + c0, p->perm, misc);
     HT(hipMemcpyAsync(h_misc, misc, 8, hipMemcpyDeviceToHost, st));
     HT(hipStreamSynchronize(st));
-    if (h_misc[0]) goto done;  // a cell above SORT_CAP nodes: stay untiled
+    if (h_misc[0]) goto done;  // a cell above SORT_CAP nodes (coincident points): stay untiled
   } else {
     // no coordinates: keep the given numbering, tiles = consecutive chunks
     k_iota<<<gn, TB, 0, st>>>(N, p->perm);
-    ncell = cdiv(N, tile_target);
-    h_cptr.resize(ncell + 1);
-    for (int64_t c = 0; c <= ncell; ++c) h_cptr[c] = (int32_t)((c * (int64_t)tile_target < N) ? c * tile_target : N);
   }
-  // ---- 2. tiles and slices (host: a few thousand entries)
-  h_tile_ptr.push_back(0);
-  for (int64_t c = 0; c < ncell; ++c) {
-    int32_t n = h_cptr[c + 1] - h_cptr[c];
-    if (n <= 0) continue;
-    int nt = (n + TILE_MAX - 1) / TILE_MAX;
-    int chunk = (n + nt - 1) / nt;
-    for (int j = 0; j < nt; ++j) h_tile_ptr.push_back(h_cptr[c] + (int32_t)fmin((double)n, (double)(j + 1) * chunk));
-  }
+  // ---- 2. tiles = consecutive chunks of tile_target nodes of that order; slices (host: a few thousand entries)
+  for (int64_t b = 0; b < N; b += tile_target) h_tile_ptr.push_back((int32_t)b);
+  h_tile_ptr.push_back((int32_t)N);
   p->n_tiles = (int64_t)h_tile_ptr.size() - 1;
   h_tile_slice.resize(p->n_tiles + 1);
   h_tile_slice[0] = 0;
@@ -431,6 +435,8 @@ int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipS
   HT(hipMemcpyAsync(p->tile_ptr, h_tile_ptr.data(), (p->n_tiles + 1) * 4, hipMemcpyHostToDevice, st));
   HT(hipMemcpyAsync(p->tile_slice, h_tile_slice.data(), (p->n_tiles + 1) * 4, hipMemcpyHostToDevice, st));
   HT(hipMemcpyAsync(slice_tile, h_slice_tile.data(), p->n_slices * 4, hipMemcpyHostToDevice, st));
+  if (d_pos)  // node ids ascending inside a tile (a tile's lanes then follow the caller's numbering, like its LDS rows)
+    k_cell_sort<<<(unsigned)p->n_tiles, TB, 0, st>>>(p->tile_ptr, p->perm, misc);
   k_inverse_perm<<<gn, TB, 0, st>>>(N, p->perm, p->inv, p->flags, p->flags_p);
   // ---- 3. halos
   k_halo<<<(unsigned)p->n_tiles, TB, 0, st>>>(p->tile_ptr, p->perm, p->inv, p->csr_ptr, p->csr_nbr, p->csc_ptr,
@@ -480,6 +486,13 @@ int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipS
       if (h_has[t]) order.push_back((int32_t)t);
     HT(hipMalloc((void**)&p->tile_order, p->n_tiles * 4));
     HT(hipMemcpy(p->tile_order, order.data(), p->n_tiles * 4, hipMemcpyHostToDevice));
+  }
+  {
+    TileCtx h{p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell, p->flags_p};
+    HT(hipMalloc((void**)&p->d_ctx, sizeof(TileCtx)));
+    HT(hipMemcpy(p->d_ctx, &h, sizeof(TileCtx), hipMemcpyHostToDevice));
+    HT(hipMalloc((void**)&p->d_tile_ctr, 9 * 32 * 4));
+    HT(hipMemset(p->d_tile_ctr, 0, 9 * 32 * 4));
   }
   p->tiled = 1;
 done:

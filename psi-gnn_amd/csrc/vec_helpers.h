@@ -1,0 +1,121 @@
+// Vector-kernel helpers shared by the solver kernels (solver.hip, fpiter.hip, krylov.hip): thread -> element mapping,
+// coalesced float4 loads / stores, fixed-shape reductions (bitwise reproducible results).  gfx950.
+#pragma once
+#include "common.h"
+
+// The vector kernels are templated on VEC = elements per thread (16 for long vectors, 4 when N*d is small so that
+// the grid still covers the 256 CUs; chosen at solver creation).
+#define TB 256           // threads per block
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Two per-lane values -> ONE pair per block (wave shuffles, then the 4 wave sums through LDS, fixed order).
+__device__ __forceinline__ void block_pair_store(float a, float b, float* __restrict__ part, int n) {
+  __shared__ float red[2][TB / 64];
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a;
+    red[1][threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    part[n + blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+
+// Thread -> element mapping of every vector kernel: a wave owns 64*VEC contiguous floats and reads them as VEC/4
+// fully coalesced float4 rows (lane l takes floats [256*i + 4*l, +4) of the wave's span), so one load instruction
+// covers 8 whole 128-byte lines instead of a quarter of 32 lines.  elem0 is the thread's lowest element.
+template <int VEC>
+__device__ __forceinline__ int64_t elem0() {
+  return ((int64_t)blockIdx.x * TB + (threadIdx.x & ~63)) * VEC + (threadIdx.x & 63) * 4;
+}
+template <int VEC>
+__device__ __forceinline__ void ldv(const float* __restrict__ p, int64_t e0, int64_t M, float* r) {
+#pragma unroll
+  for (int i = 0; i < VEC / 4; ++i) {
+    const int64_t o = e0 + i * 256;
+    if (o + 4 <= M) {
+      float4 t = *reinterpret_cast<const float4*>(p + o);
+      r[4 * i] = t.x; r[4 * i + 1] = t.y; r[4 * i + 2] = t.z; r[4 * i + 3] = t.w;
+    } else {  // tail
+#pragma unroll
+      for (int c = 0; c < 4; ++c) r[4 * i + c] = (o + c < M) ? p[o + c] : 0.f;
+    }
+  }
+}
+// Loads of the U / V sweeps.  Non-temporal loads were measured and REJECTED: although every byte is read once
+// per pass, k_dots / k_axpy at N = 1M, k = 0..49 took 557 / 550 us per launch with nt against 365 / 382 us with
+// default-policy loads (round 1, MI355X).  -DPSIGNN_NT_SWEEPS=1 rebuilds the nt variant for A/B timing.
+#ifndef PSIGNN_NT_SWEEPS
+#define PSIGNN_NT_SWEEPS 0
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int VEC>
+__device__ __forceinline__ void ldv_stream(const float* __restrict__ p, int64_t e0, int64_t M, float* r) {
+#if PSIGNN_NT_SWEEPS
+  if (e0 + (VEC / 4 - 1) * 256 + 4 <= M) {
+#pragma unroll
+    for (int i = 0; i < VEC / 4; ++i) {
+      f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p + e0 + i * 256));
+      r[4 * i] = t.x; r[4 * i + 1] = t.y; r[4 * i + 2] = t.z; r[4 * i + 3] = t.w;
+    }
+    return;
+  }
+#endif
+  ldv<VEC>(p, e0, M, r);
+}
+
+template <int VEC>
+__device__ __forceinline__ void stv(float* __restrict__ p, int64_t e0, int64_t M, const float* r) {
+#pragma unroll
+  for (int i = 0; i < VEC / 4; ++i) {
+    const int64_t o = e0 + i * 256;
+    if (o + 4 <= M) {
+      *reinterpret_cast<float4*>(p + o) = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (o + c < M) p[o + c] = r[4 * i + c];
+    }
+  }
+}
+
+__device__ inline double block_sum_partials(const float* __restrict__ p, int n, double* sh) {
+  // fixed summation shape (lane-strided, 4 independent accumulators, then a tree): reproducible, and the
+  // loads of one lane do not wait on each other (a dependent scalar loop here cost 20-30 us per call)
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * TB < n; i += 4 * TB) {
+    float a = p[i], b = p[i + TB], c = p[i + 2 * TB], d = p[i + 3 * TB];
+    s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
+  }
+  for (; i < n; i += TB) s0 += (double)p[i];
+  double s = (s0 + s1) + (s2 + s3);
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = TB / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+// launch a VEC-templated kernel with the solver's vector width
+#define VPLAIN(vec, kern, cfg, ...)                                     \
+  do {                                                                  \
+    if ((vec) == 16) kern<16><<<VCFG cfg>>>(__VA_ARGS__);               \
+    else kern<4><<<VCFG cfg>>>(__VA_ARGS__);                            \
+  } while (0)
+#define VCFG(...) __VA_ARGS__
+#define VLAUNCH(name, st, vec, kern, cfg, ...) LAUNCH(name, st, VPLAIN(vec, kern, cfg, __VA_ARGS__))
+

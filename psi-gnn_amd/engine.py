@@ -962,3 +962,112 @@ class DeviceBroyden:
         out = self._collect(info, rel, abs_, result.shape, result.device)
         out["result"] = result
         return out
+
+
+def broyden_solve_batch(solvers, fmaps, eps, poll_every=8):
+    """One lockstep device solve of several independent meshes (``psignn_broyden_solve_batch``): ``solvers[i]`` is a
+    ``DeviceBroyden`` of ``fmaps[i].plan``.  Returns the list of per-mesh result dicts of ``DeviceBroyden.solve`` -- each
+    bit-identical to solving that mesh alone."""
+    n = len(solvers)
+    if n == 0:
+        return []
+    if len(fmaps) != n:
+        raise nat.NativeError("one FixedPointMap per solver")
+    w0 = fmaps[0].weights
+    for s, f in zip(solvers, fmaps):
+        if f.weights is not w0 and f.weights.flat.data_ptr() != w0.flat.data_ptr():
+            raise nat.NativeError("batched solve: all meshes must share one packed weight buffer")
+        if s.plan is not f.plan:
+            raise nat.NativeError("batched solve: solver and map were built from different plans")
+    dev = solvers[0].device
+    thr = solvers[0].threshold
+    results = [torch.empty_like(f.h0) for f in fmaps]
+    arr = lambda ptrs: (C.c_void_p * n)(*ptrs)
+    infos = (nat.SolveInfo * n)()
+    rel = [(C.c_double * s.threshold)() for s in solvers]
+    abs_ = [(C.c_double * s.threshold)() for s in solvers]
+    dpp = lambda rows: (C.POINTER(C.c_double) * n)(*[C.cast(r, C.POINTER(C.c_double)) for r in rows])
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().psignn_broyden_solve_batch(
+            n, arr([s.handle.value for s in solvers]), nat.ptr(w0.flat), w0.n_layers, arr([nat.ptr(f.h0) for f in fmaps]),
+            arr([nat.ptr(f.prb) for f in fmaps]), float(eps), int(poll_every), arr([nat.ptr(r) for r in results]), infos,
+            dpp(rel), dpp(abs_), nat.stream_ptr(dev)), "psignn_broyden_solve_batch")
+    outs = []
+    for i, s in enumerate(solvers):
+        o = s._collect(infos[i], rel[i], abs_[i], results[i].shape, dev)
+        o["result"] = results[i]
+        outs.append(o)
+    return outs
+
+
+# ---------------------------------------------------------------------------------------------
+# Picard / Anderson on the device (csrc/fpiter.hip)
+# ---------------------------------------------------------------------------------------------
+class DeviceFixedPointIter:
+    """Vector work, norms, stop tests and the small bordered solve of ``forward_iteration`` / ``anderson``
+    (utilities/solver.py:301-341, :215-293) on the device.  The caller evaluates f between the calls; nothing is read back
+    per iteration unless asked (``poll``)."""
+
+    def __init__(self, n_elems, device, m=2, threshold=50, keep_trace=False):
+        h = C.c_void_p()
+        self.device, self.M, self.m = device, int(n_elems), int(m)
+        self.threshold, self.keep_trace = int(threshold), bool(keep_trace)
+        with torch.cuda.device(device):
+            nat.check(nat.lib().psignn_fpiter_create(C.byref(h), self.M, self.m, self.threshold, int(self.keep_trace)),
+                      "psignn_fpiter_create")
+        self.handle = h
+        self._fin = weakref.finalize(self, nat.lib().psignn_fpiter_destroy, h)
+
+    def close(self):
+        self._fin()
+
+    def _sp(self):
+        return nat.stream_ptr(self.device)
+
+    def poll(self):
+        d = C.c_int(0)
+        nat.check(nat.lib().psignn_fpiter_poll(self.handle, C.byref(d), self._sp()), "psignn_fpiter_poll")
+        return bool(d.value)
+
+    # Picard
+    def picard_begin(self, x0):
+        nat.check(nat.lib().psignn_picard_begin(self.handle, nat.ptr(x0), self._sp()), "psignn_picard_begin")
+
+    def picard_current(self, like):
+        x = torch.empty_like(like)
+        nat.check(nat.lib().psignn_picard_current_x(self.handle, nat.ptr(x), self._sp()), "psignn_picard_current_x")
+        return x
+
+    def picard_update(self, fx, eps):
+        nat.check(nat.lib().psignn_picard_update(self.handle, nat.ptr(fx), float(eps), None, self._sp()), "psignn_picard_update")
+
+    # Anderson
+    def anderson_begin(self, x0, f0, f1, lam, beta, stop_abs):
+        nat.check(nat.lib().psignn_anderson_begin(self.handle, nat.ptr(x0), nat.ptr(f0), nat.ptr(f1), float(lam), float(beta),
+                                                  int(stop_abs), self._sp()), "psignn_anderson_begin")
+
+    def anderson_next(self, like):
+        x = torch.empty_like(like)
+        nat.check(nat.lib().psignn_anderson_next_x(self.handle, nat.ptr(x), self._sp()), "psignn_anderson_next_x")
+        return x
+
+    def anderson_update(self, fx, eps):
+        nat.check(nat.lib().psignn_anderson_update(self.handle, nat.ptr(fx), float(eps), None, self._sp()),
+                  "psignn_anderson_update")
+
+    def finish(self, like):
+        result = torch.empty_like(like)
+        info = nat.SolveInfo()
+        n = self.threshold + 2
+        rel, abs_, low = (C.c_double * n)(), (C.c_double * n)(), (C.c_int32 * n)()
+        nat.check(nat.lib().psignn_fpiter_finish(self.handle, nat.ptr(result), C.byref(info), rel, abs_, low, self._sp()),
+                  "psignn_fpiter_finish")
+        k = int(info.n_iter)
+        return {"result": result, "n_iter": k, "nstep": int(info.nstep), "lowest": float(info.lowest),
+                "lowest_abs": float(info.lowest_abs), "stop_reason": int(info.stop_reason),
+                "rel_trace": list(rel[:k]), "abs_trace": list(abs_[:k]), "low_idx": list(low[:k])}
+
+    def iterate(self, i, like):
+        dst = torch.empty_like(like)
+        nat.check(nat.lib().psignn_fpiter_get_iterate(self.handle, int(i), nat.ptr(dst), self._sp()), "psignn_fpiter_get_iterate")
+        return dst

@@ -16,7 +16,7 @@ from __future__ import annotations
 import torch
 
 from .. import _native as nat
-from ..engine import D, TRACE_BUDGET_BYTES, DeviceBroyden, FixedPointMap
+from ..engine import D, TRACE_BUDGET_BYTES, DeviceBroyden, DeviceFixedPointIter, FixedPointMap
 
 
 class _LazyTrace:
@@ -89,82 +89,114 @@ def broyden(f, x0, threshold, eps=1e-3, stop_mode="rel", ls=False, name="unknown
             "eps": eps, "threshold": threshold, "n_iter": out["n_iter"], "stop_reason": out["stop_reason"]}
 
 
-def forward_iteration(f, z0, eps=1.e-5, threshold=50):
-    """Picard iteration (reference: utilities/solver.py:301-341): returns the last iterate."""
+class _LazyIterates:
+    """``xest_trace`` of a device Picard / Anderson run: iterates are copied out of the solver's trace buffer on demand.
+    ``index[j]`` = which stored iterate entry j of the reference's list is (Anderson appends the LOWEST iterate so far at
+    every step, solver.py:275)."""
+
+    def __init__(self, it, index, first, shape, back):
+        self._it, self._index, self._first, self._shape, self._back = it, index, first, shape, back
+
+    def __len__(self):
+        return len(self._index) + 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        if i == 0:
+            return self._first
+        if not self._it.keep_trace:
+            raise RuntimeError("iterates were not kept (trace would exceed the memory budget); pass keep_trace=True")
+        return self._back(self._it.iterate(self._index[i - 1], self._first.reshape(-1))).reshape(self._shape)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+def _plan_mode(f):
+    """Tiled plans: iterate in plan order on f.fp (no permutation passes per evaluation; norms, inner products and linear
+    combinations do not depend on the node numbering); results go back to the caller's numbering."""
+    if isinstance(f, FixedPointMap) and f.plan.tiled:
+        return f.fp, f.to_plan, f.from_plan
+    ident = lambda t: t
+    return f, ident, ident
+
+
+def forward_iteration(f, z0, eps=1.e-5, threshold=50, keep_trace=None, poll_every=8):
+    """Picard iteration z <- f(z) (reference: utilities/solver.py:301-341): after every evaluation abs = |z_prev - z|,
+    rel = abs / |z|; runs while rel > eps and fewer than ``threshold`` loop passes were made; returns the LAST iterate,
+    ``lowest`` = the last relative residual (a 0-dim tensor, like the reference's), ``nstep`` = loop passes.
+
+    The norms, traces and the stop test live on the device (csrc/fpiter.hip); the host evaluates f and reads the done flag
+    every ``poll_every`` evaluations, so up to ``poll_every - 1`` evaluations are issued past the stop and ignored."""
     nat.require_cuda(z0, "z0")
-    z_est = [z0]
-    z_prev, z = z0, f(z0)
-    trace = {"abs": [], "rel": []}
-    ite = 0
-    a = torch.linalg.norm(z_prev - z)
-    r = a / torch.linalg.norm(z)
-    trace["abs"].append(a.detach())
-    trace["rel"].append(r.detach())
-    z_est.append(z)
-    while trace["rel"][-1] > eps and ite < threshold:
-        z_prev = z
-        z = f(z_prev)
-        ite += 1
-        a = torch.linalg.norm(z_prev - z)
-        r = a / torch.linalg.norm(z)
-        trace["abs"].append(a.detach())
-        trace["rel"].append(r.detach())
-        z_est.append(z)
-    return {"result": z, "lowest": trace["rel"][-1], "abs_trace": trace["abs"], "rel_trace": trace["rel"],
-            "xest_trace": z_est, "nstep": ite, "eps": eps, "threshold": threshold}
+    F, to_p, from_p = _plan_mode(f)
+    shape = z0.shape
+    x0 = to_p(z0.to(torch.float32).contiguous())
+    M = x0.numel()
+    if keep_trace is None:
+        keep_trace = (threshold + 3) * M * 4 <= TRACE_BUDGET_BYTES
+    it = DeviceFixedPointIter(M, x0.device, m=1, threshold=threshold, keep_trace=keep_trace)
+    with torch.cuda.device(x0.device):
+        it.picard_begin(x0)
+        for i in range(threshold + 1):
+            x = it.picard_current(x0)
+            it.picard_update(F(x).to(torch.float32).contiguous(), eps)
+            if (i + 1) % poll_every == 0 and it.poll():
+                break
+        out = it.finish(x0)
+    dev = z0.device
+    rel = list(torch.tensor(out["rel_trace"], dtype=torch.float32, device=dev).unbind())
+    ab = list(torch.tensor(out["abs_trace"], dtype=torch.float32, device=dev).unbind())
+    n = out["n_iter"]
+    trace = _LazyIterates(it, list(range(1, n + 1)), z0, shape, from_p)
+    return {"result": from_p(out["result"]).reshape(shape), "lowest": rel[-1], "abs_trace": ab, "rel_trace": rel,
+            "xest_trace": trace, "nstep": out["nstep"], "eps": eps, "threshold": threshold}
 
 
-def anderson(f, x0, m=2, lam=1e-4, threshold=50, eps=1e-3, stop_mode="rel", beta=1.0, **kwargs):
-    """Anderson acceleration (reference: utilities/solver.py:215-293; m=2, lam=1e-4, beta=1;
-    ``rel = |f(x)-x| / (1e-5 + |f(x)|)``)."""
+def anderson(f, x0, m=2, lam=1e-4, threshold=50, eps=1e-3, stop_mode="rel", beta=1.0, keep_trace=None, poll_every=8,
+             **kwargs):
+    """Anderson acceleration (reference: utilities/solver.py:215-293; m = 2, lam = 1e-4, beta = 1 at its call sites;
+    ``rel = |f(x) - x| / (1e-5 + |f(x)|)``): loop index k = 2 .. threshold - 1, the lowest iterate in ``stop_mode`` is the
+    result, traces are padded with the lowest values after an early stop.
+
+    Gram matrix of the residual history, the (m+1) x (m+1) bordered solve, the mixing step, norms and stop test run on the
+    device (csrc/fpiter.hip); the host evaluates f and polls the done flag every ``poll_every`` steps."""
+    if stop_mode not in ("rel", "abs"):
+        raise ValueError(f"stop_mode {stop_mode!r}")
     nat.require_cuda(x0, "x0")
+    F, to_p, from_p = _plan_mode(f)
     shape = x0.shape
-    n = x0.numel()
-    alt = "rel" if stop_mode == "abs" else "abs"
-    kw = dict(dtype=x0.dtype, device=x0.device)
-    X = torch.zeros(m, n, **kw)
-    Fm = torch.zeros(m, n, **kw)
-    X[0] = x0.reshape(-1)
-    Fm[0] = f(x0).reshape(-1)
-    X[1] = Fm[0]
-    Fm[1] = f(Fm[0].reshape(shape)).reshape(-1)
-    H = torch.zeros(m + 1, m + 1, **kw)
-    H[0, 1:] = H[1:, 0] = 1
-    y = torch.zeros(m + 1, 1, **kw)
-    y[0] = 1
-    trace = {"abs": [], "rel": []}
-    lowest = {"abs": 1e8, "rel": 1e8}
-    lowest_step = {"abs": 0, "rel": 0}
-    xest_trace = [x0]
-    lowest_x = None
-    for k in range(2, threshold):
-        nn = min(k, m)
-        G = Fm[:nn] - X[:nn]
-        H[1:nn + 1, 1:nn + 1] = G @ G.t() + lam * torch.eye(nn, **kw)
-        alpha = torch.linalg.solve(H[:nn + 1, :nn + 1], y[:nn + 1])[1:nn + 1, 0]
-        X[k % m] = beta * (alpha[None] @ Fm[:nn])[0] + (1 - beta) * (alpha[None] @ X[:nn])[0]
-        Fm[k % m] = f(X[k % m].reshape(shape)).reshape(-1)
-        gx = Fm[k % m] - X[k % m]
-        abs_diff = gx.norm().item()
-        rel_diff = abs_diff / (1e-5 + Fm[k % m].norm().item())
-        diff = {"abs": abs_diff, "rel": rel_diff}
-        trace["abs"].append(abs_diff)
-        trace["rel"].append(rel_diff)
-        for mode in ("rel", "abs"):
-            if diff[mode] < lowest[mode]:
-                if mode == stop_mode:
-                    lowest_x = X[k % m].reshape(shape).clone()
-                lowest[mode] = diff[mode]
-                lowest_step[mode] = k
-        xest_trace.append(lowest_x)
-        if trace[stop_mode][-1] < eps:
-            for _ in range(threshold - 1 - k):
-                trace[stop_mode].append(lowest[stop_mode])
-                trace[alt].append(lowest[alt])
-            break
-    return {"result": lowest_x, "lowest": lowest[stop_mode], "nstep": lowest_step[stop_mode], "prot_break": False,
-            "abs_trace": trace["abs"], "rel_trace": trace["rel"], "xest_trace": xest_trace,
-            "eps": eps, "threshold": threshold}
+    xp = to_p(x0.to(torch.float32).contiguous())
+    M = xp.numel()
+    if keep_trace is None:
+        keep_trace = (threshold + 3) * M * 4 <= TRACE_BUDGET_BYTES
+    it = DeviceFixedPointIter(M, xp.device, m=m, threshold=threshold, keep_trace=keep_trace)
+    c = lambda t: t.to(torch.float32).contiguous()
+    with torch.cuda.device(xp.device):
+        f0 = c(F(xp))
+        f1 = c(F(f0))
+        it.anderson_begin(xp, f0, f1, lam, beta, stop_mode == "abs")
+        for k in range(2, threshold):
+            x = it.anderson_next(xp)
+            it.anderson_update(c(F(x)), eps)
+            if (k - 1) % poll_every == 0 and it.poll():
+                break
+        out = it.finish(xp)
+    n = out["n_iter"]
+    low, low_alt = (out["lowest_abs"], out["lowest"]) if stop_mode == "abs" else (out["lowest"], out["lowest_abs"])
+    rel, ab = out["rel_trace"], out["abs_trace"]
+    if out["stop_reason"] == 1:   # early stop: pad as solver.py:279-282 (threshold - 1 - k entries, k = last loop index)
+        pad = threshold - 1 - (n + 1)
+        rel = rel + [out["lowest"]] * pad
+        ab = ab + [out["lowest_abs"]] * pad
+    trace = _LazyIterates(it, out["low_idx"], x0, shape, from_p)
+    return {"result": from_p(out["result"]).reshape(shape), "lowest": low, "nstep": out["nstep"], "prot_break": False,
+            "abs_trace": ab, "rel_trace": rel, "xest_trace": trace, "eps": eps, "threshold": threshold}
 
 
 def newton(f, z0, eps=1.e-5, threshold=50):

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: A/B of run-time (environment) variants of the f tile kernel: plain f at 1M nodes (3 runs) and the fused
+# step inside the default bench.  AB_ENVS="PSIGNN_WG_PER_CU=0 PSIGNN_WG_PER_CU=5" (one VAR=value per variant).
+cd "$GRAFT_REPO_ROOT"
+for v in ${AB_ENVS:-"PSIGNN_WG_PER_CU=0" "PSIGNN_WG_PER_CU=5"}; do
+  f=""
+  for i in 1 2 3; do f="$f $(env $v timeout -k 10 120 python3 scripts/prof_f.py 1000000 50 0 dirichlet 2>/dev/null | grep -o 'f avg [0-9.]* us' | grep -o '[0-9.]*')"; done
+  b=$(env $v timeout -k 10 200 python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+k=[x for x in d['kernels'] if 'fused' in x['kernel']][0]
+print('it/s', round(d['iters_per_sec'],1), 'fused_us', round(k['avg_us'],1), 'tiles', d['config']['tiles'], 'max_rows', d['config']['max_tile_rows'])")
+  echo "$v | plain f us:$f | $b"
+done
