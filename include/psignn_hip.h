@@ -360,6 +360,29 @@ int psignn_fpiter_finish(psignn_fpiter_t* s, float* d_result, psignn_solve_info_
 int psignn_fpiter_get_iterate(const psignn_fpiter_t* s, int i, float* d_dst, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * GMRES on the device for the Newton-Krylov solver (BASELINE configs[4]: "Newton-Krylov JVP path").
+ * replaces: nothing executable -- scipy.optimize.newton_krylov is imported at utilities/solver.py:6 and never called; with
+ *           fp32 finite-difference products scipy's solver does not converge on this problem, the
+ *           analytic JVP kernel (psignn_f_jvp_p) is the operator here.
+ * The caller owns the basis d_basis: (m_max + 1) rows of `ld` floats (ld >= n_elems, a multiple of 4).  Per Arnoldi step j
+ * it writes the raw operator product of basis row j into row j + 1 and calls psignn_gmres_step, which orthogonalises it
+ * (classical Gram-Schmidt twice), updates the Hessenberg least-squares problem by Givens rotations and raises the device
+ * stop flag once |residual| <= eta |b|.  Krylov operator: A v = product - shift * v (shift = 1 for A = J_f - I).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct psignn_gmres psignn_gmres_t;
+int psignn_gmres_create(psignn_gmres_t** out, int64_t n_elems, int64_t ld, int m_max, float* d_basis);
+void psignn_gmres_destroy(psignn_gmres_t* s);
+/* g = fx - x -> d_g (may be NULL), -g -> d_neg_g (may be NULL); h_norms[0] = |g|, h_norms[1] = |fx|.  Synchronous. */
+int psignn_residual_norms(psignn_gmres_t* s, const float* d_x, const float* d_fx, float* d_g, float* d_neg_g, double* h_norms,
+                          void* stream);
+int psignn_gmres_begin(psignn_gmres_t* s, const float* d_b, void* stream);               /* basis row 0 = b / |b| */
+int psignn_gmres_step(psignn_gmres_t* s, int j, double shift, double eta, int* h_done /* may be NULL */, void* stream);
+/* d_dst = d_base + scale * z, z = the least-squares solution over the first k steps (k <= 0: all completed; d_base may be
+ * NULL).  h_info (may be NULL): [steps completed, |b|, |residual|].  d_dst may alias d_base. */
+int psignn_gmres_solution(psignn_gmres_t* s, int k, const float* d_base, double scale, float* d_dst, double* h_info, void* stream);
+int psignn_gmres_history(psignn_gmres_t* s, double* h_res /* m_max + 1 */, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline line;
  * replaces: the reference's only instrumentation, time.time() around the model call,
  * tests/special_geo/spec_geo_2.py:313-317).  Off by default.

@@ -111,6 +111,13 @@ SIGNATURES = {
     "psignn_fpiter_finish": (_INT, [_P, _P, C.POINTER(SolveInfo), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int32), _P]),
     "psignn_fpiter_get_iterate": (_INT, [_P, _INT, _P, _P]),
+    "psignn_gmres_create": (_INT, [C.POINTER(_P), _I64, _I64, _INT, _P]),
+    "psignn_gmres_destroy": (None, [_P]),
+    "psignn_residual_norms": (_INT, [_P, _P, _P, _P, _P, C.POINTER(C.c_double), _P]),
+    "psignn_gmres_begin": (_INT, [_P, _P, _P]),
+    "psignn_gmres_step": (_INT, [_P, _INT, C.c_double, C.c_double, C.POINTER(_INT), _P]),
+    "psignn_gmres_solution": (_INT, [_P, _INT, _P, C.c_double, _P, C.POINTER(C.c_double), _P]),
+    "psignn_gmres_history": (_INT, [_P, C.POINTER(C.c_double), _P]),
     "psignn_prof_enable": (None, [_INT]),
     "psignn_prof_tile_stamps": (None, [_P]),
     "psignn_prof_collect": (_INT, []),

@@ -13,7 +13,7 @@
 // the host (WLayout fold block).  All node tensors are in PLAN order; the solver keeps its state there.
 #include "tile_helpers.h"
 #ifndef TILE_WPE
-#define TILE_WPE 5    // > 0: __attribute__((amdgpu_waves_per_eu(TILE_WPE, TILE_WPE))) on k_f_tile: the register allocator is held to 96 VGPRs (5 waves per SIMD)
+#define TILE_WPE 0    // > 0: __attribute__((amdgpu_waves_per_eu(TILE_WPE, TILE_WPE))) on k_f_tile: the register allocator is held to 96 VGPRs (5 waves per SIMD)
 #endif
 #if TILE_WPE
 #define TILE_WPE_ATTR __attribute__((amdgpu_waves_per_eu(TILE_WPE, TILE_WPE)))
@@ -225,7 +225,9 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
 #define HALO_SPLIT 1   // 1: halo rows of stage 1 shared out as half rows over all four waves (see below); 0: round 1's loop
 #endif
 #ifndef SLOT_PREFETCH
-#define SLOT_PREFETCH 1   // 1: the wave's slot rows are requested before stage 1 (row 0 kept, the rest pulled towards L2)
+#define SLOT_PREFETCH 0   // 1: the wave's slot rows are requested before stage 1 (row 0 kept, the rest pulled towards L2).
+                          // Measured (1M nodes, plain f): 64.7 - 65.2 us with, 57.5 - 58.2 us without -- the extra pass over the
+                          // slot records costs more than the walk's misses; kept for A/B runs
 #endif
 #if HALO_SPLIT
 #if SLOT_PREFETCH

@@ -159,11 +159,12 @@ def _solve(A, rhs, compute_sol):
 
 
 def make_from_triangulation(pos, tri, dirichlet_mask, seed=0, radius=1.0, mixed=False,
-                            normals=None, compute_sol=True, dtype=torch.float32) -> MeshData:
-    """Assemble one Poisson problem on an arbitrary P1 triangulation and emit the reader schema."""
+                            normals=None, compute_sol=True, dtype=torch.float32, coeffs=None) -> MeshData:
+    """Assemble one Poisson problem on an arbitrary P1 triangulation and emit the reader schema.
+    ``coeffs`` = (param_f[3], param_g[6]) overrides the seeded draw (to rebuild a problem the reference recorded)."""
     N = pos.shape[0]
     K, M = p1_assemble(pos, tri)
-    pf, pg = _problem_coeffs(seed)
+    pf, pg = _problem_coeffs(seed) if coeffs is None else (np.asarray(coeffs[0], float), np.asarray(coeffs[1], float))
     xs, ys = pos[:, 0] / radius, pos[:, 1] / radius
     fv = _f_expr(pf, xs, ys)
     gv = _g_expr(pg, xs, ys)

@@ -335,13 +335,17 @@ class FixedPointMap:
                                              nat.stream_ptr(Hc.device)), "psignn_f_jvp")
         return out
 
-    def jvp_p(self, Hp, Vp):
-        """J_f(Hp) Vp with everything in plan order (tiled single-layer dirichlet plans)."""
+    def jvp_p(self, Hp, Vp, out=None):
+        """J_f(Hp) Vp with everything in plan order (tiled single-layer dirichlet plans).  ``out``: a contiguous (N, d)
+        float32 tensor to write into (e.g. a row of a Krylov basis)."""
         if self._p is None:
             self.fp(Hp)
         _, prbp, _ = self._p
         Hc, Vc = _f32c(Hp), _f32c(Vp)
-        out = torch.empty_like(Hc)
+        if out is None:
+            out = torch.empty_like(Hc)
+        elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != Hc.numel():
+            raise nat.NativeError("jvp_p: out must be a contiguous float32 tensor of the state's size")
         with torch.cuda.device(Hc.device):
             nat.check(nat.lib().psignn_f_jvp_p(self.plan.handle, nat.ptr(self.weights.flat), self.weights.n_layers,
                                                nat.ptr(Hc), nat.ptr(prbp), nat.ptr(Vc), nat.ptr(out),
@@ -1071,3 +1075,57 @@ class DeviceFixedPointIter:
         dst = torch.empty_like(like)
         nat.check(nat.lib().psignn_fpiter_get_iterate(self.handle, int(i), nat.ptr(dst), self._sp()), "psignn_fpiter_get_iterate")
         return dst
+
+
+# ---------------------------------------------------------------------------------------------
+# GMRES on the device (csrc/krylov.hip)
+# ---------------------------------------------------------------------------------------------
+class DeviceGmres:
+    """Krylov workspace of ``newton_krylov``: the basis is a torch tensor (rows are handed to the JVP kernel as views),
+    everything else -- Gram-Schmidt sweeps, Hessenberg / Givens least squares, stop flag -- lives in the library."""
+
+    def __init__(self, n_elems, device, m_max):
+        self.M, self.m, self.device = int(n_elems), int(m_max), device
+        self.ld = (self.M + 63) // 64 * 64
+        self.V = torch.empty((self.m + 1, self.ld), dtype=torch.float32, device=device)
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            nat.check(nat.lib().psignn_gmres_create(C.byref(h), self.M, self.ld, self.m, nat.ptr(self.V)), "psignn_gmres_create")
+        self.handle = h
+        self._fin = weakref.finalize(self, nat.lib().psignn_gmres_destroy, h)
+
+    def close(self):
+        self._fin()
+
+    def row(self, j, shape):
+        return self.V[j, :self.M].view(shape)
+
+    def _sp(self):
+        return nat.stream_ptr(self.device)
+
+    def residual_norms(self, x, fx, g=None, neg_g=None):
+        """(|fx - x|, |fx|) as the fp32 norms the reference reads back with .item(); optionally stores g and -g."""
+        out = (C.c_double * 2)()
+        nat.check(nat.lib().psignn_residual_norms(self.handle, nat.ptr(x), nat.ptr(fx), nat.ptr(g), nat.ptr(neg_g), out,
+                                                  self._sp()), "psignn_residual_norms")
+        return float(out[0]), float(out[1])
+
+    def begin(self, b):
+        nat.check(nat.lib().psignn_gmres_begin(self.handle, nat.ptr(b), self._sp()), "psignn_gmres_begin")
+
+    def step(self, j, shift, eta, poll=False):
+        d = C.c_int(0)
+        nat.check(nat.lib().psignn_gmres_step(self.handle, int(j), float(shift), float(eta), C.byref(d) if poll else None,
+                                              self._sp()), "psignn_gmres_step")
+        return bool(d.value)
+
+    def solution(self, base, scale, dst, k=0, info=False):
+        inf = (C.c_double * 3)()
+        nat.check(nat.lib().psignn_gmres_solution(self.handle, int(k), nat.ptr(base), float(scale), nat.ptr(dst),
+                                                  inf if info else None, self._sp()), "psignn_gmres_solution")
+        return (int(inf[0]), float(inf[1]), float(inf[2])) if info else None
+
+    def history(self):
+        h = (C.c_double * (self.m + 1))()
+        nat.check(nat.lib().psignn_gmres_history(self.handle, h, self._sp()), "psignn_gmres_history")
+        return list(h)

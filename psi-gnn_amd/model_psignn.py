@@ -285,21 +285,24 @@ class DeepEquilibrium(nn.Module):
         ident = lambda t: t
         return (lambda w: fmap.vjp(H_star, w)), ident, ident
 
-    def jac_loss_estimate(self, H_star, H_init, batch, vecs=1, generator=None):
-        """Hutchinson estimate of tr(J^T J) / (N d) (model.py:416-435) with the VJP kernel."""
+    def jac_loss_estimate(self, H_star, H_init, batch, vecs=1, generator=None, probes=None):
+        """Hutchinson estimate of tr(J^T J) / (N d) (model.py:416-435) with the VJP kernel.  ``probes``: the Gaussian
+        vectors to use instead of drawing ``vecs`` of them (so that a test can fix them)."""
         fmap = self.f.bind(H_init, batch)
         vjp, to_p, _ = self._vjp_in_plan_order(fmap, H_star)
         acc = 0.0
-        for _ in range(vecs):
-            v = torch.randn(H_star.shape, device=H_star.device, generator=generator)
+        n = vecs if probes is None else len(probes)
+        for i in range(n):
+            v = torch.randn(H_star.shape, device=H_star.device, generator=generator) if probes is None else probes[i]
             acc = acc + vjp(to_p(v)).norm() ** 2
-        return acc / vecs / H_star.numel()
+        return acc / n / H_star.numel()
 
-    def power_method(self, H_star, H_init, batch, n_iters=150, generator=None):
-        """Spectral-radius estimate of J by power iteration on v^T J (model.py:437-452)."""
+    def power_method(self, H_star, H_init, batch, n_iters=150, generator=None, v0=None):
+        """Spectral-radius estimate of J by power iteration on v^T J (model.py:437-452).  ``v0``: start vector instead
+        of a Gaussian draw."""
         fmap = self.f.bind(H_init, batch)
         vjp, to_p, from_p = self._vjp_in_plan_order(fmap, H_star)
-        ev = to_p(torch.randn(H_star.shape, device=H_star.device, generator=generator))
+        ev = to_p(torch.randn(H_star.shape, device=H_star.device, generator=generator) if v0 is None else v0)
         val = torch.zeros((), device=H_star.device)
         for _ in range(n_iters):
             vj = vjp(ev)

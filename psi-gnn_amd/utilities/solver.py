@@ -216,72 +216,122 @@ def newton(f, z0, eps=1.e-5, threshold=50):
             "xest_trace": r["xest_trace"], "nstep": r["nstep"], "eps": eps, "threshold": threshold}
 
 
-def newton_krylov(f, x0, threshold=30, eps=1e-5, inner_m=30, inner_tol=1e-2, **kwargs):
-    """Jacobian-free Newton-Krylov on g(x) = f(x) - x with the ANALYTIC Jacobian-vector product.
+def newton_krylov(f, x0, threshold=30, eps=1e-5, inner_m=200, inner_tol=1e-2, max_backtracks=10, poll_every=10,
+                  warm_start=0, picard_fallback=20, broyden_burst=0, burst_below=0.1, **kwargs):
+    """Globalised inexact Newton-Krylov on g(x) = f(x) - x with the ANALYTIC Jacobian-vector product (BASELINE configs[4]).
 
-    The reference imports ``scipy.optimize.newton_krylov`` (utilities/solver.py:6) but never calls it, so
-    there is no reference implementation; the dict keys follow ``broyden``.  Outer Newton step:
-    solve (J_f(x) - I) dx = -g(x) approximately with ``inner_m`` GMRES steps (inexact Newton; ``inner_tol`` is
-    accepted for signature compatibility, the inner loop runs a fixed number of steps so that it needs no
-    host synchronisation), x <- x + dx.  ``rel = |g|/(|f(x)| + 1e-9)`` as in broyden; ``nstep`` counts outer
-    iterations, ``n_feval`` f + JVP evaluations (the unit comparable to one Broyden iteration).
-    With fp32 finite-difference JVPs scipy's solver does not converge on this problem; the
-    analytic JVP kernel (psignn_f_jvp) is what makes the method usable in fp32.
-    """
+    The reference imports ``scipy.optimize.newton_krylov`` (utilities/solver.py:6) but never calls it, so there is no
+    reference implementation; the dict keys follow ``broyden``.  Outer step: solve (J_f(x) - I) dx = -g(x) with GMRES until
+    the linear residual is below ``inner_tol`` (or ``inner_m`` Krylov vectors: no restarts -- restarted GMRES throws away the
+    smooth modes the problem's long-range coupling lives in, and 288 GB of HBM hold hundreds of basis vectors of a 1M-node
+    state), then a backtracking line search on |g| (s = 1, 1/2, ... ; sufficient decrease 1e-4; f is piecewise smooth --
+    ReLU kinks -- and full Newton steps overshoot far from the fixed point).  Everything runs in plan order on the device:
+    f and the JVP are the tiled HIP kernels, Arnoldi (classical Gram-Schmidt twice), the Hessenberg / Givens least-squares
+    problem and the update are csrc/krylov.hip; the host reads two norms per trial point and a stop flag every
+    ``poll_every`` Krylov steps.  ``warm_start`` > 0: that many on-device Broyden iterations first (far from the fixed point
+    the kinks make Newton directions poor: on the 2 107-node fixture a cold start spends most of its evaluations on damped
+    steps, a start from Broyden's iterate converges quadratically).  When no step length along the Newton direction
+    decreases |g|, up to ``picard_fallback`` plain iterations x <- f(x) are taken while they decrease it, and Newton resumes.
+    ``broyden_burst`` > 0: whenever the accepted step length falls below ``burst_below`` (the iterate sits in a patch of
+    kinks where the linear model is only valid very locally) that many Broyden iterations are run from the current iterate
+    with the device solver's machinery, and their lowest iterate is taken if it is lower -- quasi-Newton steps cross such
+    patches, Newton steps finish the job once the iterate is in the basin of quadratic convergence.
+
+    ``rel = |g| / (|f(x)| + 1e-9)`` as in broyden; ``nstep`` = outer step of the lowest iterate, ``n_feval`` = f + JVP
+    evaluations (the unit comparable to one Broyden iteration), ``n_krylov`` = Krylov steps per outer iteration."""
     if not isinstance(f, FixedPointMap):
         raise nat.NativeError("newton_krylov needs the analytic JVP of a FixedPointMap")
     nat.require_cuda(x0, "x0")
-    # tiled single-layer dirichlet plans: the whole iteration in plan order on the tiled f / JVP kernels (norms and
-    # inner products do not depend on the node numbering); results are returned in the caller's numbering
-    plan_mode = f.plan.tiled and not f.weights.mixed and f.weights.n_layers == 1
-    F, J = (f.fp, f.jvp_p) if plan_mode else (f, f.jvp)
-    back = f.from_plan if plan_mode else (lambda t: t)
-    x = f.to_plan(x0) if plan_mode else x0.clone()
-    fx = F(x)
-    g = fx - x
+    if not (f.plan.tiled and not f.weights.mixed and f.weights.n_layers == 1):
+        raise nat.NativeError("newton_krylov runs on tiled single-layer dirichlet plans (the tiled JVP kernel)")
+    from ..engine import DeviceGmres
+    shape = x0.shape
+    n_feval = 0
+    if warm_start > 0:
+        ob = broyden(f, x0, threshold=warm_start, eps=eps, keep_trace=False)
+        x = f.to_plan(ob["result"])
+        n_feval += ob["n_iter"] + 1
+    else:
+        x = f.to_plan(x0.to(torch.float32).contiguous())
+    M = x.numel()
+    gm = DeviceGmres(M, x.device, inner_m)
+    neg_g = torch.empty_like(x)
+    xt = torch.empty_like(x)
     trace = {"abs": [], "rel": []}
-    n_feval = 1
-    lowest, lowest_x, lowest_step = 1e8, x, 0
+    n_krylov, steps = [], []
     xest_trace = [x]
-    nstep = 0
-    for nstep in range(1, threshold + 1):
-        # GMRES(inner_m) on A dx = b, A v = J_f v - v, b = -g.  The Arnoldi process runs a fixed number of steps
-        # with everything (Hessenberg matrix included) on the device: no host sync inside the inner loop; the
-        # small least-squares problem is solved once per outer step.
-        b = -g.reshape(-1)
-        beta = torch.linalg.norm(b)
-        m = inner_m
-        V = torch.zeros(m + 1, b.numel(), device=b.device, dtype=b.dtype)
-        Hm = torch.zeros(m + 1, m, device=b.device, dtype=b.dtype)
-        V[0] = b / beta
-        for k in range(m):
-            w = (J(x, V[k].reshape(x.shape)) - V[k].reshape(x.shape)).reshape(-1)
-            n_feval += 1
-            h = V[:k + 1] @ w                      # classical Gram-Schmidt, twice
-            w = w - h @ V[:k + 1]
-            h2 = V[:k + 1] @ w
-            w = w - h2 @ V[:k + 1]
-            Hm[:k + 1, k] = h + h2
-            hn = torch.linalg.norm(w)
-            Hm[k + 1, k] = hn
-            V[k + 1] = w / hn.clamp_min(1e-30)
-        e1 = torch.zeros(m + 1, 1, device=b.device, dtype=torch.float64)
-        e1[0, 0] = beta.double()
-        y = torch.linalg.lstsq(Hm.double().cpu(), e1.cpu()).solution[:, 0].to(b.device, b.dtype)
-        dx = (y @ V[:m]).reshape(x.shape)
-        x = x + dx
-        fx = F(x)
+    with torch.cuda.device(x.device):
+        fx = f.fp(x)
         n_feval += 1
-        g = fx - x
-        abs_diff = torch.linalg.norm(g).item()
-        rel_diff = abs_diff / (torch.linalg.norm(fx).item() + 1e-9)
-        trace["abs"].append(abs_diff)
-        trace["rel"].append(rel_diff)
-        xest_trace.append(x)
-        if rel_diff < lowest:
-            lowest, lowest_x, lowest_step = rel_diff, x, nstep
-        if rel_diff < eps:
-            break
-    return {"result": back(lowest_x), "lowest": lowest, "nstep": lowest_step, "prot_break": False,
-            "abs_trace": trace["abs"], "rel_trace": trace["rel"], "xest_trace": [back(t) for t in xest_trace], "eps": eps,
-            "threshold": threshold, "n_feval": n_feval, "n_outer": nstep}
+        gn, fn = gm.residual_norms(x, fx, neg_g=neg_g)
+        rel = gn / (fn + 1e-9)
+        lowest, lowest_x, lowest_step = rel, x, 0
+        nstep = 0
+        for nstep in range(1, threshold + 1):
+            if rel < eps:
+                nstep -= 1
+                break
+            gm.begin(neg_g)
+            k = 0
+            for j in range(inner_m):
+                f.jvp_p(x, gm.row(j, x.shape), out=gm.row(j + 1, x.shape))
+                n_feval += 1
+                k = j + 1
+                if gm.step(j, 1.0, inner_tol, poll=(k % poll_every == 0 or k == inner_m)):
+                    break
+            # x_trial = x + s dx ; accept the first s with |g(x_trial)| <= (1 - 1e-4 s) |g(x)|
+            s, accepted = 1.0, False
+            for _ in range(max_backtracks + 1):
+                kk, _, _ = gm.solution(x, s, xt, info=True)
+                fxt = f.fp(xt)
+                n_feval += 1
+                gt, ft = gm.residual_norms(xt, fxt, neg_g=neg_g)   # -g(x_trial): the next right-hand side if accepted
+                if gt <= (1.0 - 1e-4 * s) * gn:
+                    accepted = True
+                    break
+                s *= 0.5
+            n_krylov.append(kk)
+            steps.append(s if accepted else 0.0)
+            if not accepted:
+                # no decrease along the Newton direction: plain iterations x <- f(x) while they decrease |g|
+                moved = False
+                for _ in range(picard_fallback):
+                    xt.copy_(f.fp(x))
+                    fxt = f.fp(xt)
+                    n_feval += 2
+                    gt, ft = gm.residual_norms(xt, fxt, neg_g=None)
+                    if not gt < gn:
+                        break
+                    x, xt = xt, torch.empty_like(x)
+                    gn, fn = gt, ft
+                    moved = True
+                if not moved:   # stalled at this precision
+                    break
+                gm.residual_norms(x, f.fp(x), neg_g=neg_g)
+                n_feval += 1
+                steps[-1] = -1.0   # marks a fallback round
+            else:
+                x, xt = xt, torch.empty_like(x)
+                gn, fn = gt, ft
+            if broyden_burst > 0 and steps[-1] < burst_below:
+                ob = broyden(lambda H: f.fp(H), x, threshold=broyden_burst, eps=eps, keep_trace=False)
+                n_feval += ob["n_iter"] + 1
+                xb = ob["result"].to(torch.float32).contiguous()
+                gb, fb = gm.residual_norms(xb, f.fp(xb), neg_g=None)
+                n_feval += 1
+                if gb < gn:
+                    x, gn, fn = xb, gb, fb
+                    gm.residual_norms(x, f.fp(x), neg_g=neg_g)
+                    n_feval += 1
+            rel = gn / (fn + 1e-9)
+            trace["abs"].append(gn)
+            trace["rel"].append(rel)
+            xest_trace.append(x)
+            if rel < lowest:
+                lowest, lowest_x, lowest_step = rel, x, nstep
+    gm.close()
+    back = f.from_plan
+    return {"result": back(lowest_x).reshape(shape), "lowest": lowest, "nstep": lowest_step, "prot_break": False,
+            "abs_trace": trace["abs"], "rel_trace": trace["rel"], "xest_trace": [back(t).reshape(shape) for t in xest_trace],
+            "eps": eps, "threshold": threshold, "n_feval": n_feval, "n_outer": len(trace["rel"]), "n_krylov": n_krylov,
+            "step_lengths": steps}

@@ -1,4 +1,5 @@
-"""Per-phase time budget of the f tile kernel from in-kernel shader-clock stamps (psignn_prof_tile_stamps).
+"""Per-phase time budget of the f tile kernel from in-kernel clock stamps (psignn_prof_tile_stamps; the library must be
+built with the stamps compiled in:  make -C psi-gnn_amd/csrc clean && make -C psi-gnn_amd/csrc EXTRA=-DTILE_STAMPS=1).
 
     python3 scripts/tile_phases.py [nodes=1000000]
 """
@@ -27,8 +28,9 @@ t = buf.cpu().numpy().reshape(plan.n_tiles, 4, 8).astype(np.float64)
 us = e0.elapsed_time(e1) * 1e3
 span = t[..., :6][t[..., :6] > 0]
 total_ticks = span.max() - span.min()
-tick_ns = us * 1e3 / total_ticks
-print(f"N={plan.N} tiles={plan.n_tiles} kernel {us:.1f} us (with stamps), first..last stamp {total_ticks:.0f} ticks -> {tick_ns:.3f} ns per tick")
+tick_ns = 10.0   # wall_clock64(): constant 100 MHz
+print(f"N={plan.N} tiles={plan.n_tiles}: first .. last stamp {total_ticks * tick_ns * 1e-3:.1f} us (kernel built with -DTILE_STAMPS=1; "
+      f"event time around the launch incl. launch overhead {us:.1f} us)")
 names = ["stage 1 (loads + projections)", "barrier wait", "neighbour sums (slot walk)", "node update", "store"]
 ok = (t[..., 5] > 0)
 for i, nme in enumerate(names):

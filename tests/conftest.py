@@ -53,3 +53,15 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def load_circlelarge():
+    """The reference's own 5 329-node disc (tests/special_geo/mesh_files/circlelarge, decoded by
+    oracle/make_golden_circlelarge.py) with the problem its notebooks solved: (MeshData, recorded rows dict)."""
+    import json
+    z = np.load(os.path.join(GOLDEN, "mesh_circlelarge.npz"))
+    hm = pkg("data.hexmesh")
+    mesh = hm.make_from_triangulation(z["pos"], z["tri"].astype(np.int64), z["dirichlet"], radius=float(z["radius"]),
+                                      coeffs=(z["param_f"], z["param_g"]))
+    band = json.load(open(os.path.join(GOLDEN, "circlelarge_band.json")))
+    return mesh, band

@@ -202,3 +202,76 @@ def test_batched_solver_ragged_shard_and_fallbacks(dev):
     mm = [data.make_hex_problem(9 + s, seed=s, mixed=True) for s in range(3)]
     a, b = batch.solve_shard(mnet, mm, dev), batch.solve_shard_batched(mnet, mm, dev)
     assert all(torch.equal(x[1], y[1]) for x, y in zip(a, b))
+
+
+def test_hip_path_reproduces_the_reference_recorded_rows_on_circlelarge(dev):
+    """The HIP path against the known answer the reference holds for its own 5 329-node disc (see
+    tests/test_oracle_golden.py::test_oracle_reproduces_the_reference_recorded_rows_on_circlelarge): DSS through the tile
+    kernels to the four printed digits, the PSI-GNN fixed point of the on-device Broyden solve within 1 % (MSEDirichlet to
+    four digits), and one f evaluation against the oracle on this gmsh mesh."""
+    from conftest import load_circlelarge
+    mesh, band = load_circlelarge()
+    rec = band["recorded_2"]
+    md = mesh.to(dev)
+    d = (mesh.tags[:, 0] == 1).to(dev)
+    sd = load_weights("dirichlet")
+    # The recorded row is the reference's run to ITS stop (976 steps).  Residual and MSEDirichlet settle early (the
+    # reference's 976-step run, the oracle's 482-step run and a 236-step HIP run at fw_tol 1e-6 agree on them to 3 - 4
+    # digits); the error against the LU solution lives in smooth modes that converge last -- at fw_tol 1e-6 the plateau rule
+    # of the solver (solver.py:179-180) may stop a run early with the same Residual and a 35 % higher MSE.  The solve is
+    # therefore driven to 1e-7 here.
+    net = pkg("model_psignn").ModelPSIGNN(dict(latent_dim=10, n_layers=1, fw_tol=1e-7, fw_thres=1500))
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    u, loss = net(md)
+    _, sol = net._solve(md)
+    got = {"residual": float(loss["residual_loss"]), "mse": float(loss["mse_loss"]),
+           "rel": float((u - md.sol).norm() / md.sol.norm()), "mse_dirichlet": float(loss["mse_dirichlet_loss"])}
+    print("PSI-GNN on circlelarge:", got, "nsteps", loss["nsteps"], "lowest", sol["lowest"], "stop", sol["stop_reason"],
+          "| recorded", rec["psignn"], "| oracle", band["oracle"])
+    assert sol["lowest"] < 1e-6
+    for k in ("residual", "mse_dirichlet"):
+        assert abs(got[k] - rec["psignn"][k]) <= 0.01 * rec["psignn"][k], (k, got[k], rec["psignn"][k])
+    assert abs(got["mse_dirichlet"] - rec["psignn"]["mse_dirichlet"]) <= 6e-4 * rec["psignn"]["mse_dirichlet"]
+    for k in ("mse", "rel"):   # the reference printed 1.432 / 7.391e-2, the oracle converges to 1.4268 / 7.377e-2
+        assert abs(got[k] - rec["psignn"][k]) <= 0.03 * rec["psignn"][k], (k, got[k], rec["psignn"][k])
+    with torch.no_grad():
+        h0 = orc.encoder(sd, mesh.x)
+        want = orc.function_forward(sd, h0.clone(), h0, mesh)
+    assert rel_l2(net.deqdss.f(h0.to(dev), h0.to(dev), md), want) < 2e-6
+    # DSS: deterministic known answer
+    w = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "weights_dss.npz"))
+    dss = pkg("dss")
+    dnet = dss.DeepStatisticalSolver(dict(latent_dim=10, k=int(w["k"]), alpha=float(w["alpha"]), gamma=0.9, path_logs=None))
+    dnet.load_state_dict({k: torch.from_numpy(w[k]) for k in w.files if k not in ("k", "alpha")})
+    dnet = dnet.to(dev).eval()
+    db = dss.to_dss_batch(md)
+    us = dnet.inference(db)
+    us = us[0] if isinstance(us, (tuple, list)) else us
+    dbc = orc.dss_batch(mesh)
+    gd = {"residual": float(orc.dss_residual_loss(us.cpu(), dbc.edge_index, dbc.a_ij, dbc.b_prime)),
+          "mse": float(((us - md.sol) ** 2).mean()), "rel": float((us - md.sol).norm() / md.sol.norm()),
+          "mse_dirichlet": float(((us[d] - md.x[d]) ** 2).mean())}
+    print("DSS on circlelarge:", gd, "| recorded", rec["dss"])
+    for k, v in gd.items():
+        assert abs(v - rec["dss"][k]) <= 6e-4 * rec["dss"][k], (k, v, rec["dss"][k])
+
+
+def test_newton_krylov_at_100k_nodes(dev):
+    """BASELINE configs[4]'s solver at configs[1]'s size (99 919 nodes).  On meshes this far outside the training range
+    (<= 600 nodes) the trained model's fixed-point problem is ill-conditioned: Broyden's lowest residual, ~1.7e-4, is reached
+    around iteration 30 of 1 500 and never improved, and GMRES with 200 - 400 basis vectors brings the Newton system's
+    residual down by less than 20x.  What is asserted: the device Newton-Krylov iteration started from
+    Broyden's iterate does not lose ground -- its lowest residual is <= Broyden's -- is monotone, finite, and reports its
+    cost in f / JVP evaluations."""
+    data, solver = pkg("data"), pkg("utilities.solver")
+    sd = load_weights("dirichlet")
+    mesh = data.make_hex_problem(182, seed=0, compute_sol=False)
+    md, h0, plan, fm = _fmap(mesh, sd, dev)
+    ob = solver.broyden(fm, fm.h0, threshold=60, eps=1e-6, keep_trace=False)
+    out = solver.newton_krylov(fm, fm.h0, threshold=3, eps=1e-6, inner_m=200, inner_tol=5e-2, warm_start=60)
+    print(f"100k nodes: Broyden(60) lowest {ob['lowest']:.3e} at step {ob['nstep']}; Newton-Krylov from it: lowest {out['lowest']:.3e}, "
+          f"{out['n_outer']} outer steps, {out['n_feval']} f/JVP evaluations, Krylov steps {out['n_krylov']}, step lengths {out['step_lengths']}")
+    assert np.isfinite(out["lowest"]) and out["lowest"] <= ob["lowest"] * (1 + 1e-6)
+    assert all(b <= a for a, b in zip(out["abs_trace"], out["abs_trace"][1:]))
+    assert out["n_feval"] >= 60 and out["result"].shape == fm.h0.shape and bool(torch.isfinite(out["result"]).all())

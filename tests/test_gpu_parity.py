@@ -619,6 +619,65 @@ def test_newton_krylov_with_analytic_jvp(dev):
     assert set(solver.broyden(fmap, fmap.h0, threshold=5, eps=1e-3)) >= {"result", "lowest", "nstep", "rel_trace"}
 
 
+def test_device_gmres_solves_a_known_linear_system(dev):
+    """csrc/krylov.hip on its own: A = P - shift I with a dense P applied by torch, 700 unknowns (two blocks of the vector
+    kernels, ragged tail), against torch.linalg.solve in float64; residual history monotone; early stop at eta."""
+    eng = pkg("engine")
+    gen = torch.Generator().manual_seed(5)
+    n = 70
+    Pm = torch.randn(n * 10, n * 10, generator=gen) / (4.0 * (n * 10) ** 0.5)          # spectral radius ~ 0.5
+    b = torch.randn(n, 10, generator=gen)
+    A64 = Pm.double() - torch.eye(n * 10, dtype=torch.float64)
+    z_true = torch.linalg.solve(A64, b.reshape(-1).double())
+    Pd, bd = Pm.to(dev), b.to(dev)
+    gm = eng.DeviceGmres(n * 10, dev, 60)
+    gm.begin(bd)
+    done, k = False, 0
+    for j in range(60):
+        v = gm.row(j, (n, 10))
+        gm.row(j + 1, (n, 10)).copy_((Pd @ v.reshape(-1)).reshape(n, 10))
+        k = j + 1
+        if gm.step(j, 1.0, 1e-6, poll=True):
+            done = True
+            break
+    assert done and k < 60
+    z = torch.empty_like(bd)
+    kk, beta, resid = gm.solution(None, 1.0, z, info=True)
+    assert kk == k and abs(beta - float(b.norm())) < 1e-4 * beta and resid <= 1e-6 * beta
+    assert rel_l2(z, z_true.reshape(n, 10)) < 1e-4
+    hist = gm.history()[:k + 1]
+    assert all(hist[i + 1] <= hist[i] * (1 + 1e-6) for i in range(k))
+    true_res = float((A64 @ z.cpu().reshape(-1).double() - b.reshape(-1).double()).norm())
+    assert abs(true_res - resid) < 1e-4 * beta            # the Givens residual is the true residual
+    # x + s z in one pass, truncated solution over the first 5 columns only
+    x0 = torch.ones_like(bd)
+    out = torch.empty_like(bd)
+    gm.solution(x0, 0.5, out)
+    assert rel_l2(out, 1.0 + 0.5 * z.cpu()) < 1e-6
+    z5 = torch.empty_like(bd)
+    k5, _, _ = gm.solution(None, 1.0, z5, k=5, info=True)
+    assert float((A64 @ z5.cpu().reshape(-1).double() - b.reshape(-1).double()).norm()) > true_res
+    gm.close()
+
+
+def test_newton_krylov_converges_to_the_fp64_fixed_point(dev):
+    """BASELINE configs[4] solver on the 2 107-node fixture: inexact Newton + device GMRES (no restarts) + line search
+    reaches the fp64 fixed point within 1e-5 (north_star) where scipy's finite-difference variant does not converge."""
+    g, mesh, md, sd, fmap = bind("hex26_dirichlet_s0", dev)
+    solver = pkg("utilities.solver")
+    out = solver.newton_krylov(fmap, fmap.h0, threshold=60, eps=2e-7, inner_m=150, inner_tol=1e-2, warm_start=100,
+                               broyden_burst=60)
+    print("hex26 NK: lowest", out["lowest"], "outer", out["n_outer"], "n_feval", out["n_feval"], "krylov", out["n_krylov"],
+          "steps", out["step_lengths"])
+    assert out["lowest"] < 1e-6
+    assert rel_l2(out["result"], g["fp64_result"]) < 1e-5
+    assert out["n_feval"] < 4000
+    # monotone by construction of the line search
+    assert all(b <= a for a, b in zip(out["abs_trace"], out["abs_trace"][1:]))
+    fx = fmap(out["result"])
+    assert abs(float((fx - out["result"]).norm() / (fx.norm() + 1e-9)) - out["lowest"]) < 1e-3 * out["lowest"] + 1e-9
+
+
 def test_forward_iteration_anderson_newton(dev):
     """The other solvers of utilities/solver.py against the oracle run on the same f."""
     g, mesh, md, sd, fmap = bind("hex13_dirichlet_s0", dev)
@@ -751,6 +810,22 @@ def test_implicit_backward_solve(dev):
     assert 0.8 < float(rho) < 1.1   # logged spectral radius of the trained model ~0.99
     jl = net.deqdss.jac_loss_estimate(h_star.to(dev), h0.to(dev), md, vecs=2, generator=torch.Generator(device=dev).manual_seed(2))
     assert torch.isfinite(jl) and float(jl) > 0
+    # the same two diagnostics with the SAME probe vectors through the oracle's VJP (jac_loss_estimate model.py:416-435,
+    # power_method :437-452 restated on orc.function_vjp)
+    gen = torch.Generator().manual_seed(21)
+    probes = [torch.randn(h_star.shape, generator=gen) for _ in range(3)]
+    want_jl = sum(float(orc.function_vjp(sd, h_star, h0, mesh, v).norm()) ** 2 for v in probes) / 3 / h_star.numel()
+    got_jl = net.deqdss.jac_loss_estimate(h_star.to(dev), h0.to(dev), md, probes=[v.to(dev) for v in probes])
+    assert abs(float(got_jl) - want_jl) < 1e-5 * want_jl, (float(got_jl), want_jl)
+    v0 = torch.randn(h_star.shape, generator=gen)
+    evc, val = v0.clone(), None
+    for _ in range(40):
+        vj = orc.function_vjp(sd, h_star, h0, mesh, evc)
+        val = (vj * evc).sum() / (evc * evc).sum()
+        evc = vj / vj.norm()
+    ev2, rho2 = net.deqdss.power_method(h_star.to(dev), h0.to(dev), md, n_iters=40, v0=v0.to(dev))
+    assert abs(float(rho2) - abs(float(val))) < 2e-4 * abs(float(val)), (float(rho2), float(val))
+    assert min(rel_l2(ev2, evc), rel_l2(ev2, -evc)) < 5e-3
 
 
 def test_eval_harness_reference_protocol(dev):
