@@ -164,8 +164,9 @@ def main():
     net.load_state_dict(sd)
     net = net.to(dev)
     meshes, fmaps = [], []
-    for j in range(MPG):  # independent problems: own seed, same topology (phase-shifted warp)
-        m = pkg.data.make_hex_problem(n, seed=rank * MPG + j, mixed=mixed, compute_sol=False, phase=0.37 * j)
+    batch_mod = importlib.import_module("psi-gnn_amd.batch")
+    for j, seed in enumerate(batch_mod.rank_seeds(rank, world, MPG)):  # independent problems: own seed, same topology (phase-shifted warp)
+        m = pkg.data.make_hex_problem(n, seed=seed, mixed=mixed, compute_sol=False, phase=0.37 * j)
         md = m.to(dev)
         with torch.no_grad():
             h0 = net.autoencoder.encoder(md.x)
@@ -209,7 +210,8 @@ def main():
         ws.solve(fmap, eps=0.0)
         ws.close()
         del ws
-    solvers = [eng.DeviceBroyden(plan=f.plan, threshold=K, keep_trace=False) for f in fmaps]
+    shard = sum(f.plan.N for f in fmaps) * D if MPG > 1 and os.environ.get("PSIGNN_BENCH_STREAMS", "0") != "1" else 0
+    solvers = [eng.DeviceBroyden(plan=f.plan, threshold=K, keep_trace=False, shard_elems=shard) for f in fmaps]
     solver = solvers[0]
     streams = [torch.cuda.Stream(dev) for _ in range(MPG)] if MPG > 1 else [None]
 
@@ -244,12 +246,7 @@ def main():
         for o in outs:
             assert o["n_iter"] == K, f"solver stopped after {o['n_iter']} of {K} iterations (reason {o['stop_reason']})"
             assert np.all(np.isfinite(o["rel_trace"][:K]))
-        t_rep = elapsed
-        if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            t_rep = float(t.item())
-        times.append(t_rep)
+        times.append(batch_mod.max_over_ranks(elapsed, device=dev if backend == "nccl" else "cpu"))
     out = outs[0]
     t_max = float(np.median(times))
     elapsed = t_max
@@ -284,9 +281,10 @@ def main():
     # ---- per-kernel durations: HIP events on the launch stream, instrumented repeat of the same K steps
     if rank == 0 and not args.no_kernel_timing:
         nat.prof_enable(True)
-        solver.solve(fmap, eps=0.0, poll_every=max(K, 1))
+        run_all() if (MPG > 1 and not use_streams) else solver.solve(fmap, eps=0.0, poll_every=max(K, 1))
         prof = nat.prof_collect()
         nat.prof_enable(False)
+        nmesh_launch = MPG if (MPG > 1 and not use_streams) else 1   # a batched launch covers every mesh of the shard
         kern = {}
         f_names = ("k_project", "k_node", "k_f_tile", "k_f_tile_fused")
         if "k_f_tile_fused" in prof:   # the solver's iterations use the fused kernel; judge f by it
@@ -300,14 +298,14 @@ def main():
             f_calls = max(prof.get("k_node", (0, 0.0))[0], prof.get("k_f_tile", (0, 0.0))[0], 1)
             f_label = "f(k_f_tile)" if "k_f_tile" in prof else "f(k_project+k_node)"
             f_bytes = per_launch["f(k_project+k_node)"]
-        kern[f_label] = (f_calls, f_ms, f_bytes * f_calls)
+        kern[f_label] = (f_calls, f_ms, f_bytes * f_calls * nmesh_launch)
         for name in ("k_xnext", "k_resid", "k_final"):
             if name in prof:
-                kern[name] = (prof[name][0], prof[name][1], per_launch[name] * prof[name][0])
+                kern[name] = (prof[name][0], prof[name][1], per_launch[name] * prof[name][0] * nmesh_launch)
         if "k_dots" in prof:
-            kern["k_dots"] = (prof["k_dots"][0], prof["k_dots"][1], sum(dots_b))
+            kern["k_dots"] = (prof["k_dots"][0], prof["k_dots"][1], sum(dots_b) * nmesh_launch)
         if "k_axpy" in prof:
-            kern["k_axpy"] = (prof["k_axpy"][0], prof["k_axpy"][1], sum(axpy_b))
+            kern["k_axpy"] = (prof["k_axpy"][0], prof["k_axpy"][1], sum(axpy_b) * nmesh_launch)
         table = []
         for name, (calls, ms, byts) in kern.items():
             gbs = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0

@@ -284,11 +284,16 @@ int psignn_broyden_solve(psignn_broyden_t* s, const float* d_weights, int n_laye
 /* Batched solve of n independent meshes (one GPU's share of a batch: BASELINE configs[3], 8 x 50k-node meshes): the meshes
  * iterate in lockstep and every per-iteration pass (fused f step, dots, reduce + stop tests, axpy, final) is ONE launch over
  * all of them; each mesh keeps its own status block, traces and stop test, and its result is bit-identical to
- * psignn_broyden_solve on that mesh alone.  solvers[i] was created from mesh i's plan (tiled dirichlet plans, one
+ * psignn_broyden_solve with the same solver on that mesh alone.  solvers[i] was created from mesh i's plan (tiled dirichlet plans, one
  * threshold and vector-size class for the shard; otherwise PSIGNN_EINVAL and the caller solves them one by one).
  * replaces: the reference's one-union-Batch-per-device DataParallel call (dirichlet/psignn/main.py:106,
  *           dirichlet/psignn/test/test_func.py:68-120) for independent per-mesh solves.
  * Arrays of n device / host pointers; h_rel_trace[i] / h_abs_trace[i]: `threshold` doubles each (arrays may be NULL). */
+/* Solver for mesh `plan` that will be used inside psignn_broyden_solve_batch together with others: shard_elems = sum of
+ * N * d over the shard.  Its reduction shapes (vector width, split of the sweeps over the stored pairs) are sized for the
+ * shard, not for the single mesh; psignn_broyden_solve on such a solver gives the same bits as the batched solve. */
+int psignn_broyden_create_for_batch(psignn_broyden_t** out, const psignn_plan_t* plan, int threshold, int keep_trace,
+                                    int64_t shard_elems);
 int psignn_broyden_solve_batch(int n, psignn_broyden_t** solvers, const float* d_weights, int n_layers,
                                const float* const* d_h_initial, const float* const* d_prb, double eps, int poll_every,
                                float* const* d_results, psignn_solve_info_t* h_infos, double* const* h_rel_trace,

@@ -79,6 +79,7 @@ SIGNATURES = {
     "psignn_mlp2": (_INT, [_P, _I64, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P]),
     "psignn_residual": (_INT, [_P, _P, _P, _P, _P]),
     "psignn_broyden_create": (_INT, [C.POINTER(_P), _P, _INT, _INT]),
+    "psignn_broyden_create_for_batch": (_INT, [C.POINTER(_P), _P, _INT, _INT, _I64]),
     "psignn_broyden_create_n": (_INT, [C.POINTER(_P), _I64, _INT, _INT, _INT]),
     "psignn_broyden_destroy": (None, [_P]),
     "psignn_broyden_bytes": (C.c_size_t, [_P]),

@@ -18,11 +18,32 @@ def shard_indices(n_items: int, rank: int, world: int):
     return list(range(rank, n_items, world))
 
 
+def rank_seeds(rank: int, world: int, meshes_per_gpu: int):
+    """Problem seeds of the meshes rank `rank` solves in the weak-scaling bench: rank r owns seeds r * MPG .. r * MPG + MPG - 1,
+    so that the `world * MPG` meshes of a run are distinct problems and adding GPUs adds problems (BASELINE configs[3]:
+    8 ranks x 8 meshes = seeds 0 .. 63)."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world {world}")
+    return [rank * meshes_per_gpu + j for j in range(meshes_per_gpu)]
+
+
+def max_over_ranks(value: float, device=None, group=None) -> float:
+    """MAX all-reduce of a per-rank wall time: the job's time is the slowest rank's (bench.py contract)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
 def solve_shard_batched(model, meshes, device, indices=None, group=8):
     """``solve_shard`` with the device's share of the batch solved in LOCKSTEP: ``group`` meshes at a time go through one
     batched device solve (``engine.broyden_solve_batch``: every per-iteration pass is one launch over all of them, own stop
-    test per mesh).  Results are bit-identical to ``solve_shard``; meshes the batched solver cannot take together (mixed
-    family, untiled plans, different size classes) fall back to one solve each."""
+    test per mesh).  Each mesh's result is bit-identical to its own solve with a solver of the same configuration
+    (``DeviceBroyden(..., shard_elems=...)``: the sweeps' reduction shapes are sized for the shard) and agrees with the plain
+    ``solve_shard`` path to solver tolerance; meshes the batched solver cannot take together (mixed family, untiled plans,
+    different size classes) fall back to one solve each."""
     import importlib
     from . import _native as nat
     eng = importlib.import_module(__package__ + ".engine")
@@ -39,7 +60,9 @@ def solve_shard_batched(model, meshes, device, indices=None, group=8):
             fmaps = [net.deqdss.f.bind(h0, md) for h0, md in zip(h0s, mds)]
             solved = None
             if cfg["solver"] is slv.broyden and len(ids) > 1:
-                solvers = [eng.DeviceBroyden(plan=f.plan, threshold=cfg["fw_thres"], keep_trace=False) for f in fmaps]
+                total = sum(f.plan.N for f in fmaps) * eng.D
+                solvers = [eng.DeviceBroyden(plan=f.plan, threshold=cfg["fw_thres"], keep_trace=False, shard_elems=total)
+                           for f in fmaps]
                 try:
                     solved = eng.broyden_solve_batch(solvers, fmaps, cfg["fw_tol"])
                 except nat.NativeError:

@@ -80,6 +80,17 @@ struct WLayout {
   }
 };
 
+// Iteration-invariant pointers of a tiled plan, kept in DEVICE memory and handed to the tile kernels as one pointer.
+// As separate kernel arguments they are all live from the kernel's first instruction; the f kernel needs ~60 SGPRs for
+// weights in its hot phases, so the compiler parked those arguments in VGPR lanes (v_writelane / v_readlane: VALU issue
+// slots).  Behind a pointer each one is a scalar load next to its use.
+struct TileCtx {
+  const int32_t *tile_ptr, *tile_slice, *halo, *halo_cnt, *slice_off;
+  const uint8_t* slice_deg;
+  const uint4* ell;
+  const uint8_t* flags_p;
+};
+
 // ---------------------------------------------------------------------------------------------
 // Mesh plan (device memory owned here).
 // ---------------------------------------------------------------------------------------------
@@ -114,21 +125,10 @@ struct psignn_plan {
   int64_t n_tiles_plain = 0;                   // tiles in the first group
   float cell_size = 0.f, xmin = 0.f, ymin = 0.f;
   int nx = 0, ny = 0;
-  struct TileCtx* d_ctx = nullptr;             // device copy of the tile pointers (one kernel argument instead of eight)
-  int32_t* d_tile_ctr = nullptr;               // work queues of the persistent tile kernels: 8 per-XCD counters + an exit
-                                               // counter, one 128-byte line each; zero between launches (self-resetting)
+  TileCtx* d_ctx = nullptr;                    // device copy of the tile pointers (one kernel argument instead of eight)
+  TileCtx h_ctx{};                             // the same on the host (kernels that take the struct by value)
 };
 
-// Iteration-invariant pointers of a tiled plan, kept in DEVICE memory and handed to the tile kernels as one pointer.
-// As separate kernel arguments they are all live from the kernel's first instruction; the f kernel needs ~60 SGPRs for
-// weights in its hot phases, so the compiler parked those arguments in VGPR lanes (v_writelane / v_readlane: VALU issue
-// slots).  Behind a pointer each one is a scalar load next to its use.
-struct TileCtx {
-  const int32_t *tile_ptr, *tile_slice, *halo, *halo_cnt, *slice_off;
-  const uint8_t* slice_deg;
-  const uint4* ell;
-  const uint8_t* flags_p;
-};
 
 #define TILE_MAX 256      // nodes per tile = threads per block of the tile kernel
 #define HALO_CAP 512      // halo entries stored per tile

@@ -157,6 +157,8 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
   float x[D];
   uint4 slot0 = make_uint4(ELL_EMPTY, 0u, 0u, 0u);   // slot row 0 of this lane / prefetch witness (SLOT_PREFETCH below)
   unsigned slot_touch = 0;
+  (void)slot0;
+  (void)slot_touch;
   if constexpr (MFMA1) {
     // Dense node-feature x weight product on the matrix cores: out[row][o] = sum_k x[row][k] W1j[o][k] as
     // v_mfma_f32_16x16x4_f32 tiles with the WEIGHTS as the A operand (A[i = output][k]) and the node rows as B
@@ -600,47 +602,38 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
   }
 }
 
-// Kernel: workgroups are PERSISTENT -- the grid holds at most as many workgroups as fit on the chip at once and each walks
-// several tiles.  blocks b and b+8 share an XCD (round-robin dispatch): each XCD owns a contiguous run of `chunk` tiles
-// (neighbouring tiles' halo rows hit the same L2).  A workgroup's first tile is fixed (its index in the XCD); every further
-// one comes from the XCD's queue -- an atomic counter fetched while the current tile is being computed -- so that a
-// workgroup whose tiles ran fast takes more of them.  Why: per-phase stamps of the one-workgroup-per-tile form on the 1M-node
-// mesh showed tile lifetimes of 10 .. 21 us (p10 .. p90) and only 78 % of the chip's workgroup slots occupied on average --
-// the last quarter of the kernel's duration is a tail of late tiles.  The last workgroup to leave resets the counters, so they
-// are zero between launches.  Any tile -> workgroup mapping gives the same results.
+// Kernel: one workgroup per tile.  blocks b and b+8 share an XCD (round-robin dispatch): each XCD owns a contiguous run of
+// `chunk` tiles, so that neighbouring tiles' halo rows hit the same L2.  Speed only; any mapping is correct.
+// (Round 2 tried persistent workgroups -- a grid of 5 per CU striding through the XCD's run, and the same with a per-XCD
+// atomic work queue whose next index is fetched during the current tile -- to fill the tail the phase stamps show: 60.9 - 62.2
+// and 62.6 - 64.8 us against 57.7 - 58.7 us for this form on the 1M-node mesh; the loop state also cost the fused variant its
+// fifth wave.  Removed; profiles/r2_f_tile_ab_runs.txt keeps the runs.)
+#ifndef TILE_CTX_VALUE
+#define TILE_CTX_VALUE 1   // 1: the tile pointers travel as a by-value struct in the kernel arguments; 0: behind a device
+                           // pointer (scalar loads next to each use).  Measured, 1M nodes: plain f 52.6 - 53.9 us by value vs
+                           // 54.9 - 57.7 us by pointer, fused step 94.0 vs 97.7 us
+#endif
+#if TILE_CTX_VALUE
+#define TILE_CTX_PARAM const TileCtx Cv
+#define TILE_CTX_USE const TileCtx* __restrict__ C = &Cv;
+#else
+#define TILE_CTX_PARAM const TileCtx* __restrict__ C
+#define TILE_CTX_USE
+#endif
 template <int P, bool MIXED, bool FUSED, bool MFMA1>
 __global__ __launch_bounds__(TILE_THREADS) TILE_WPE_ATTR void k_f_tile(FuseArgs fa, int n_tiles, int chunk, const int32_t* __restrict__ tile_list,
-                                                const TileCtx* __restrict__ C, int32_t* __restrict__ ctr,
-                                                const float* __restrict__ W, int lofs, int tofs,
+                                                TILE_CTX_PARAM, const float* __restrict__ W, int lofs, int tofs,
                                                 int tnofs, int apply_ln, const float* __restrict__ h,
                                                 const int32_t* __restrict__ hsel, int64_t hstride,
                                                 const float* __restrict__ h0, const float* __restrict__ prb,
                                                 const float* __restrict__ nrm, float* __restrict__ out) {
+  TILE_CTX_USE
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ int s_next[2];
   if (FUSED && fa.st[fa.off_done]) return;
-  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
-  const bool queued = per_xcd < chunk;   // else one workgroup per tile: nothing to queue
-  int j = blockIdx.x >> 3;
-  int b = 0;
-  for (;;) {
-    int nxt = 0;
-    if (queued && threadIdx.x == 0) nxt = atomicAdd(&ctr[xcd * 32], 1);   // in flight while this tile is computed
-    const int slot = xcd * chunk + j;
-    if (j < chunk && slot < n_tiles)
-      f_tile_body<P, MIXED, FUSED, MFMA1>(fa, slot, tile_list, C, W, lofs, tofs, tnofs, apply_ln, h, hsel, hstride, h0, prb, nrm,
-                                          out, lds);
-    if (!queued) return;
-    if (threadIdx.x == 0) s_next[b] = per_xcd + nxt;
-    __syncthreads();   // also: the next tile's stage 1 overwrites the LDS rows this tile's lanes were reading
-    j = __builtin_amdgcn_readfirstlane(s_next[b]);
-    b ^= 1;
-    if (j >= chunk) break;
-  }
-  if (threadIdx.x == 0 && atomicAdd(&ctr[8 * 32], 1) == (int)gridDim.x - 1) {   // last one out: queues back to zero
-#pragma unroll
-    for (int q = 0; q < 9; ++q) ctr[q * 32] = 0;
-  }
+  const int slot = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (slot >= n_tiles) return;
+  f_tile_body<P, MIXED, FUSED, MFMA1>(fa, slot, tile_list, C, W, lofs, tofs, tnofs, apply_ln, h, hsel, hstride, h0, prb, nrm, out,
+                                      lds);
 }
 
 static unsigned tile_grid(int chunk);
@@ -652,48 +645,27 @@ static unsigned tile_grid(int chunk);
 // test has fired is skipped tile by tile.
 template <int P>
 __global__ __launch_bounds__(TILE_THREADS) void k_f_tile_batch(const BatchDesc* __restrict__ descs, int n_mesh, int n_slots, int chunk,
-                                                              int32_t* __restrict__ ctr, int off_done, int off_cur, int off_nxt,
+                                                              int off_done, int off_cur, int off_nxt,
                                                               const float* __restrict__ W, int lofs, int tofs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ int s_next[2];
-  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
-  const bool queued = per_xcd < chunk;
-  int j = blockIdx.x >> 3;
-  int b = 0;
-  for (;;) {
-    int nxt = 0;
-    if (queued && threadIdx.x == 0) nxt = atomicAdd(&ctr[xcd * 32], 1);
-    const int slot = xcd * chunk + j;
-    if (j < chunk && slot < n_slots) {
-      int m = 0;
-      while (m + 1 < n_mesh && descs[m + 1].tile_base <= slot) ++m;   // wave-uniform scalar walk (a shard has few meshes)
-      const BatchDesc& d = descs[m];
-      if (!d.st[off_done]) {
-        FuseArgs fa{d.upd, d.gx, d.dg, d.xbuf, d.st, off_done, off_cur, off_nxt, d.M, d.nrm_part, d.n_tiles, nullptr};
-        f_tile_body<P, false, true, false>(fa, slot - d.tile_base, nullptr, d.ctx, W, lofs, tofs, 0, 1, d.xbuf, nullptr, 0, d.h0p,
-                                           d.prbp, nullptr, nullptr, lds);
-      }
-    }
-    if (!queued) return;
-    if (threadIdx.x == 0) s_next[b] = per_xcd + nxt;
-    __syncthreads();
-    j = __builtin_amdgcn_readfirstlane(s_next[b]);
-    b ^= 1;
-    if (j >= chunk) break;
-  }
-  if (threadIdx.x == 0 && atomicAdd(&ctr[8 * 32], 1) == (int)gridDim.x - 1) {
-#pragma unroll
-    for (int q = 0; q < 9; ++q) ctr[q * 32] = 0;
-  }
+  const int slot = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (slot >= n_slots) return;
+  int m = 0;
+  while (m + 1 < n_mesh && descs[m + 1].tile_base <= slot) ++m;   // wave-uniform scalar walk (a shard has few meshes)
+  const BatchDesc& d = descs[m];
+  if (d.st[off_done]) return;
+  FuseArgs fa{d.upd, d.gx, d.dg, d.xbuf, d.st, off_done, off_cur, off_nxt, d.M, d.nrm_part, d.n_tiles, nullptr};
+  f_tile_body<P, false, true, false>(fa, slot - d.tile_base, nullptr, d.ctx, W, lofs, tofs, 0, 1, d.xbuf, nullptr, 0, d.h0p, d.prbp,
+                                     nullptr, nullptr, lds);
 }
 
 // descs: device array of n_mesh descriptors; max_rows: largest tile + halo row count over the meshes (LDS size).
-int psignn_f_tile_fused_batch(const BatchDesc* d_descs, int n_mesh, int n_slots, int max_rows, int32_t* d_ctr, const float* W,
+int psignn_f_tile_fused_batch(const BatchDesc* d_descs, int n_mesh, int n_slots, int max_rows, const float* W,
                               int off_done, int off_cur, int off_nxt, hipStream_t st) {
   using L = WLayout<2>;
   const int chunk = (int)cdiv(n_slots, 8);
   LAUNCH("k_f_tile_fused", st, (k_f_tile_batch<2><<<tile_grid(chunk), TILE_THREADS, (size_t)max_rows * TileRow<false>::RS * 4, st>>>(
-      d_descs, n_mesh, n_slots, chunk, d_ctr, off_done, off_cur, off_nxt, W, L::layer(0), L::tp_layer(1, false, 0))));
+      d_descs, n_mesh, n_slots, chunk, off_done, off_cur, off_nxt, W, L::layer(0), L::tp_layer(1, false, 0))));
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }
@@ -708,27 +680,14 @@ __global__ void k_permute_rows(int64_t N, int cols, const int32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------ host
-#define TILE_ARGS p->d_ctx, p->d_tile_ctr
+#if TILE_CTX_VALUE
+#define TILE_ARGS p->h_ctx
+#else
+#define TILE_ARGS p->d_ctx
+#endif
 
-// Grid of a tile-kernel launch over `chunk` tiles per XCD.  Default: one workgroup per tile.  PSIGNN_WG_PER_CU = n > 0 caps
-// the grid at n workgroups per CU (a multiple of 8, so that every XCD gets the same share); the workgroups are then
-// persistent and take further tiles from a per-XCD queue (see k_f_tile).  Measured on the 1M-node mesh (round 2, one box,
-// plain f): one workgroup per tile 57.7 - 58.7 us; persistent with static striding 60.9 - 62.2 us; persistent with the
-// atomic queue 62.6 - 64.8 us (5 per CU), 61.1 - 62.6 us (6 per CU) -- the hardware dispatcher refills a CU faster than a
-// loop whose next index is an atomic's return value sitting in front of the tile's first loads.  Kept for A/B runs.
-static unsigned tile_grid(int chunk) {
-  static const int cap = [] {
-    const char* e = getenv("PSIGNN_WG_PER_CU");
-    const int per_cu = e ? atoi(e) : 0;
-    if (per_cu <= 0) return 0;
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    return std::max(8, per_cu * cus / 8 * 8);
-  }();
-  const int full = chunk * 8;
-  return (unsigned)((cap > 0 && full > cap) ? cap : full);
-}
+// Grid of a tile-kernel launch over `chunk` tiles per XCD: one workgroup per tile, a multiple of 8.
+static unsigned tile_grid(int chunk) { return (unsigned)(chunk * 8); }
 
 static FuseArgs plain_args() {
   FuseArgs a{};

@@ -63,6 +63,7 @@ struct psignn_broyden {
   int ext_iter = 0;
   int64_t ld = 0;           // row pitch (floats) of U and V
   int stop_abs = 0;         // stop_mode of the next solve
+  int64_t size_hint = 0;    // elements of ALL vectors swept together (batched shard): picks the vector width / j-split
   int plan_order = 1;       // 0 while iterates are kept in the caller's numbering (adjoint solve on the gather kernels)
   // PSIGNN_GRAPH=1 (experiment): the launches of each poll_every-iteration chunk captured into a HIP
   // graph, cached per chunk and re-used by later solves with the same arguments
@@ -510,9 +511,14 @@ static int broyden_alloc(psignn_broyden* s) {
     const char* e = getenv("PSIGNN_VEC16_MIN");
     return e ? (int64_t)atoll(e) : (int64_t)3 << 18;
   }();
-  s->vec = s->M >= vec16_min ? 16 : 4;
+  // A solver that will run inside a batched solve (size_hint = elements of the whole shard) sizes its sweeps for the
+  // aggregate: the shard's blocks fill the chip together, so the long-vector width applies and the sweeps need no split
+  // over the stored pairs.  Its single-mesh solves use the same shapes, hence the same bits as its batched ones.
+  const int64_t eff = std::max<int64_t>(s->M, s->size_hint);
+  s->vec = eff >= vec16_min ? 16 : 4;
   s->nblk = (int)cdiv(s->M, (int64_t)s->vec * TB);
-  s->jgroups = s->nblk >= 768 ? 1 : (int)std::min<int64_t>(8, cdiv(768, s->nblk));
+  const int64_t eff_blk = cdiv(eff, (int64_t)s->vec * TB);
+  s->jgroups = eff_blk >= 768 ? 1 : (int)std::min<int64_t>(8, cdiv(768, eff_blk));
   s->npart = s->nblk * (TB / 64);
   // Mid-size vectors (16 floats per lane, but too few blocks to fill the chip): the dots pass is split over the stored
   // pairs (free: every pair's partial sums are independent), the axpy pass would need a combine launch after such a split
@@ -603,11 +609,18 @@ extern "C" int psignn_broyden_create_n(psignn_broyden_t** out, int64_t n_elems, 
   return PSIGNN_OK;
 }
 
+extern "C" int psignn_broyden_create_for_batch(psignn_broyden_t** out, const psignn_plan_t* plan, int threshold, int keep_trace,
+                                               int64_t shard_elems);
 extern "C" int psignn_broyden_create(psignn_broyden_t** out, const psignn_plan_t* plan, int threshold, int keep_trace) {
+  return psignn_broyden_create_for_batch(out, plan, threshold, keep_trace, 0);
+}
+extern "C" int psignn_broyden_create_for_batch(psignn_broyden_t** out, const psignn_plan_t* plan, int threshold, int keep_trace,
+                                               int64_t shard_elems) {
   ARG_CHECK(out, "out is NULL");
   *out = nullptr;
-  ARG_CHECK(plan && threshold > 0, "bad arguments");
+  ARG_CHECK(plan && threshold > 0 && shard_elems >= 0, "bad arguments");
   psignn_broyden* s = new psignn_broyden();
+  s->size_hint = shard_elems;
   s->plan = plan;
   s->M = plan->N * D;
   s->seq_len = D;
@@ -847,7 +860,7 @@ __global__ void kb_all_done(const BatchDesc* __restrict__ descs, int n, int off_
   }
 }
 
-int psignn_f_tile_fused_batch(const BatchDesc* d_descs, int n_mesh, int n_slots, int max_rows, int32_t* d_ctr, const float* W,
+int psignn_f_tile_fused_batch(const BatchDesc* d_descs, int n_mesh, int n_slots, int max_rows, const float* W,
                               int off_done, int off_cur, int off_nxt, hipStream_t st);
 
 extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const float* W, int nl, const float* const* h0,
@@ -895,10 +908,9 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
     base += (int)p->n_tiles;
   }
   BatchDesc* d_descs = nullptr;
-  int32_t *d_ctr = nullptr, *d_done = nullptr, *h_done = nullptr;
+  int32_t *d_done = nullptr, *h_done = nullptr;
   auto cleanup = [&]() {
     if (d_descs) (void)hipFree(d_descs);
-    if (d_ctr) (void)hipFree(d_ctr);
     if (d_done) (void)hipFree(d_done);
     if (h_done) (void)hipHostFree(h_done);
   };
@@ -912,15 +924,13 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
     }                                                                                     \
   } while (0)
   BT(hipMalloc((void**)&d_descs, sizeof(BatchDesc) * n));
-  BT(hipMalloc((void**)&d_ctr, 9 * 32 * 4));
   BT(hipMalloc((void**)&d_done, 4));
   BT(hipHostMalloc((void**)&h_done, 4));
   BT(hipMemcpyAsync(d_descs, hd.data(), sizeof(BatchDesc) * n, hipMemcpyHostToDevice, st));
-  BT(hipMemsetAsync(d_ctr, 0, 9 * 32 * 4, st));
   const int off_done = offsetof(Status, done) / 4;
   const int thr = s0->thr;
   for (int it = 0; it < thr; ++it) {
-    rc = psignn_f_tile_fused_batch(d_descs, n, n_slots, max_rows, d_ctr, W, off_done, sel_off_cur(), sel_off_nxt(), st);
+    rc = psignn_f_tile_fused_batch(d_descs, n, n_slots, max_rows, W, off_done, sel_off_cur(), sel_off_nxt(), st);
     if (rc) { cleanup(); return rc; }
     const int k = it;
     const int kd = k >= thr ? 0 : k;

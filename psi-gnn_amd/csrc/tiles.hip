@@ -55,8 +55,17 @@ __global__ void k_bbox(int64_t N, const float* __restrict__ pos, uint32_t* __res
   }
 }
 
-// Hilbert index of cell (cx, cy) on a 2^k x 2^k grid (the classic xy -> d walk, k <= 12).  nx = ny = 2^k.
-__device__ __forceinline__ int cell_of(float x, float y, float xmin, float ymin, float inv_cs, int nx, int ny) {
+// Ordering key of a node.  inv_cs > 0: Hilbert index of its cell (cx, cy) on a 2^k x 2^k grid (the classic xy -> d walk,
+// k <= 12; nx = ny = 2^k).  inv_cs < 0: "snake strips" -- the domain is cut into ny horizontal strips of height 1 / g_inv_h and
+// each strip into nx cells of width -1 / inv_cs (inv_h = 1 / strip height); strips are walked alternately left-to-right and right-to-left.
+__device__ __forceinline__ int cell_of(float x, float y, float xmin, float ymin, float inv_cs, float inv_h, int nx, int ny) {
+  if (inv_cs < 0.f) {
+    int cx = (int)floorf((x - xmin) * -inv_cs);
+    int cy = (int)floorf((y - ymin) * inv_h);
+    cx = min(max(cx, 0), nx - 1);
+    cy = min(max(cy, 0), ny - 1);
+    return cy * nx + ((cy & 1) ? nx - 1 - cx : cx);
+  }
   int cx = (int)floorf((x - xmin) * inv_cs);
   int cy = (int)floorf((y - ymin) * inv_cs);
   cx = min(max(cx, 0), nx - 1);
@@ -78,11 +87,17 @@ __device__ __forceinline__ int cell_of(float x, float y, float xmin, float ymin,
   return d;
 }
 
-__global__ void k_cell_count(int64_t N, const float* __restrict__ pos, float xmin, float ymin, float inv_cs, int nx,
+__global__ void k_cell_count(int64_t N, const float* __restrict__ pos, float xmin, float ymin, float inv_cs, float inv_h, int nx,
                              int ny, int32_t* __restrict__ cnt) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  atomicAdd(&cnt[cell_of(pos[2 * i], pos[2 * i + 1], xmin, ymin, inv_cs, nx, ny)], 1);
+  atomicAdd(&cnt[cell_of(pos[2 * i], pos[2 * i + 1], xmin, ymin, inv_cs, inv_h, nx, ny)], 1);
+}
+__global__ void k_count_occupied(int64_t n, const int32_t* __restrict__ cnt, int32_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int v = (i < n && cnt[i] > 0) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
 }
 __global__ void k_count_max(int64_t n, const int32_t* __restrict__ cnt, int32_t* __restrict__ out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,12 +105,12 @@ __global__ void k_count_max(int64_t n, const int32_t* __restrict__ cnt, int32_t*
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
   if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
 }
-__global__ void k_cell_fill(int64_t N, const float* __restrict__ pos, float xmin, float ymin, float inv_cs, int nx,
+__global__ void k_cell_fill(int64_t N, const float* __restrict__ pos, float xmin, float ymin, float inv_cs, float inv_h, int nx,
                             int ny, const int32_t* __restrict__ cptr, int32_t* __restrict__ cur,
                             int32_t* __restrict__ list) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  int c = cell_of(pos[2 * i], pos[2 * i + 1], xmin, ymin, inv_cs, nx, ny);
+  int c = cell_of(pos[2 * i], pos[2 * i + 1], xmin, ymin, inv_cs, inv_h, nx, ny);
   list[cptr[c] + atomicAdd(&cur[c], 1)] = (int32_t)i;
 }
 // One block per cell: rank sort of the (unique) node ids held by the cell.
@@ -321,11 +336,11 @@ int psignn_exclusive_scan(const int32_t* in, int64_t n, int32_t* out, int32_t* b
 
 void psignn_tiles_free(psignn_plan* p) {
   void* ptrs[] = {p->perm, p->inv, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt,
-                  p->slice_off, p->slice_deg, p->ell, p->flags_p, p->tile_order, p->d_ctx, p->d_tile_ctr};
+                  p->slice_off, p->slice_deg, p->ell, p->flags_p, p->tile_order, p->d_ctx};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   p->perm = p->inv = p->tile_ptr = p->tile_slice = p->halo = p->halo_cnt = p->slice_off = nullptr;
-  p->slice_deg = nullptr; p->ell = nullptr; p->flags_p = nullptr; p->tile_order = nullptr; p->d_ctx = nullptr; p->d_tile_ctr = nullptr;
+  p->slice_deg = nullptr; p->ell = nullptr; p->flags_p = nullptr; p->tile_order = nullptr; p->d_ctx = nullptr;
   p->tiled = 0;
 }
 
@@ -351,7 +366,9 @@ __global__ void k_tile_has_neumann(int64_t n_tiles, const int32_t* __restrict__ 
   if (threadIdx.x == 0) has[t] = any ? 1 : 0;
 }
 
-int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipStream_t st) {
+// mode 0: snake strips (full tiles with the halo of a square patch on quasi-uniform meshes); 1: Hilbert curve (compact blobs
+// at any local density, ~25 % more halo rows)
+static int tiles_build_mode(psignn_plan* p, const float* d_pos, int tile_target, hipStream_t st, int mode) {
   const int64_t N = p->N;
   const unsigned TB = 256;
   int rc = 0;
@@ -381,28 +398,55 @@ int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipS
     float xmin = o2f(h_box[0]), ymin = o2f(h_box[1]), xmax = o2f(h_box[2]), ymax = o2f(h_box[3]);
     if (!(isfinite(xmin) && isfinite(ymin) && isfinite(xmax) && isfinite(ymax))) goto done;  // NaN/inf positions: stay untiled
     double w = fmax((double)xmax - xmin, 1e-30), hgt = fmax((double)ymax - ymin, 1e-30);
-    // Fine cells of ~4 nodes on a 2^k x 2^k grid over the bounding square (side L = max(w, h)); the part of the grid
-    // inside the bounding box has G^2 w h / L^2 cells.  Ordering only: any k gives a correct plan.
-    const double L = fmax(w, hgt);
-    const double cells_wanted = fmax((double)N / 4.0, 1.0);
-    int k = (int)ceil(0.5 * log2(fmax(cells_wanted * L * L / (w * hgt), 1.0)));
-    const int kcap = (int)ceil(0.5 * log2(16.0 * (double)N));   // at most ~16 cells per node, however thin the domain
-    k = std::min(k, std::min(kcap, 12));
-    k = k < 0 ? 0 : k;
-    const int G = 1 << k;
-    const double cs = L / G * (1.0 + 1e-6);
-    const int nx = G, ny = G;
-    ncell = (int64_t)G * G;
+    int nx, ny;
+    double cs, inv_h = 0.0;
+    if (mode == 1) {
+      // Fine cells of ~4 nodes on a 2^k x 2^k grid over the bounding square (side L = max(w, h)); the part of the grid
+      // inside the bounding box has G^2 w h / L^2 cells.  Ordering only: any k gives a correct plan.
+      const double L = fmax(w, hgt);
+      const double cells_wanted = fmax((double)N / 4.0, 1.0);
+      int k = (int)ceil(0.5 * log2(fmax(cells_wanted * L * L / (w * hgt), 1.0)));
+      const int kcap = (int)ceil(0.5 * log2(16.0 * (double)N));   // at most ~16 cells per node, however thin the domain
+      k = std::min(k, std::min(kcap, 12));
+      k = k < 0 ? 0 : k;
+      nx = ny = 1 << k;
+      cs = L / nx * (1.0 + 1e-6);
+    } else {
+      // Strips: node density from the occupied cells of a coarse grid (domains do not fill their bounding box), strip height
+      // = side of a square patch of tile_target nodes, cells of ~8 nodes along the strip.
+      double c0 = sqrt(64.0 * w * hgt / (double)N);
+      int gx = (int)fmin(fmax(ceil(w / c0), 1.0), 4096.0), gy = (int)fmin(fmax(ceil(hgt / c0), 1.0), 4096.0);
+      c0 = fmax(w / gx, hgt / gy) * (1.0 + 1e-6);
+      const int64_t nc0 = (int64_t)gx * gy;
+      HT(hipMalloc((void**)&cnt, (nc0 + 1) * 4));
+      HT(hipMemsetAsync(cnt, 0, (nc0 + 1) * 4, st));
+      k_cell_count<<<gn, TB, 0, st>>>(N, d_pos, xmin, ymin, -(float)(1.0 / c0), (float)(1.0 / c0), gx, gy, cnt);
+      k_count_occupied<<<(unsigned)cdiv(nc0, TB), TB, 0, st>>>(nc0, cnt, cnt + nc0);
+      int32_t occ = 0;
+      HT(hipMemcpyAsync(&occ, cnt + nc0, 4, hipMemcpyDeviceToHost, st));
+      HT(hipStreamSynchronize(st));
+      (void)hipFree(cnt);
+      cnt = nullptr;
+      const double rho = (double)N / (fmax((double)occ, 1.0) * c0 * c0);
+      const double H = sqrt((double)tile_target / rho);
+      ny = (int)fmin(fmax(ceil(hgt / H), 1.0), 65536.0);
+      const double cw = 8.0 / (rho * H);
+      nx = (int)fmin(fmax(ceil(w / cw), 1.0), 65536.0);
+      while ((int64_t)nx * ny > 16 * N + 1024 && nx > 1) nx = (nx + 1) / 2;   // never more than ~16 cells per node
+      inv_h = (double)ny / (hgt * (1.0 + 1e-6));
+      cs = -(w * (1.0 + 1e-6)) / nx;          // negative: marks the strip mode for cell_of (|cs| = cell width)
+    }
+    ncell = (int64_t)nx * ny;
     HT(hipMalloc((void**)&cnt, (ncell + 1) * 4));
     HT(hipMemsetAsync(cnt, 0, (ncell + 1) * 4, st));
-    k_cell_count<<<gn, TB, 0, st>>>(N, d_pos, xmin, ymin, (float)(1.0 / cs), nx, ny, cnt);
-    p->cell_size = (float)cs; p->xmin = xmin; p->ymin = ymin; p->nx = nx; p->ny = ny;
+    k_cell_count<<<gn, TB, 0, st>>>(N, d_pos, xmin, ymin, (float)(1.0 / cs), (float)inv_h, nx, ny, cnt);
+    p->cell_size = (float)fabs(cs); p->xmin = xmin; p->ymin = ymin; p->nx = nx; p->ny = ny;
     HT(hipMalloc((void**)&cptr, (ncell + 1) * 4));
     HT(hipMalloc((void**)&cur, ncell * 4));
     HT(hipMalloc((void**)&bsum, (cdiv(ncell, 1024) + 2) * 4));
     HT(hipMemsetAsync(cur, 0, ncell * 4, st));
     if ((rc = psignn_exclusive_scan(cnt, ncell, cptr, bsum, st)) != 0) goto done;
-    k_cell_fill<<<gn, TB, 0, st>>>(N, d_pos, xmin, ymin, (float)(1.0 / cs), nx, ny, cptr, cur, p->perm);
+    k_cell_fill<<<gn, TB, 0, st>>>(N, d_pos, xmin, ymin, (float)(1.0 / cs), (float)inv_h, nx, ny, cptr, cur, p->perm);
     // node ids ascending inside a cell: the order (hence which nodes a chunk boundary cuts off) is deterministic
     for (int64_t c0 = 0; c0 < ncell; c0 += 1 << 20)
       k_cell_sort<<<(unsigned)std::min<int64_t>(ncell - c0, 1 << 20), TB, 0, st>>>(cptr + c0, p->perm, misc);
@@ -491,13 +535,25 @@ int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipS
     TileCtx h{p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell, p->flags_p};
     HT(hipMalloc((void**)&p->d_ctx, sizeof(TileCtx)));
     HT(hipMemcpy(p->d_ctx, &h, sizeof(TileCtx), hipMemcpyHostToDevice));
-    HT(hipMalloc((void**)&p->d_tile_ctr, 9 * 32 * 4));
-    HT(hipMemset(p->d_tile_ctr, 0, 9 * 32 * 4));
+    p->h_ctx = h;
   }
   p->tiled = 1;
 done:
   for (void* q : {(void*)cnt, (void*)cptr, (void*)cur, (void*)bsum, (void*)misc, (void*)slice_tile, (void*)box})
     if (q) (void)hipFree(q);
   if (!p->tiled) psignn_tiles_free(p);
+  return rc;
+}
+
+// Tile structures: strips first, the Hilbert order where strips exceed a structure limit (halo > 512: graded meshes whose
+// strips degenerate into long thin tiles), untiled where that fails too.  PSIGNN_TILING = strips | hilbert forces one.
+int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipStream_t st) {
+  static const int forced = [] {
+    const char* e = getenv("PSIGNN_TILING");
+    return !e ? -1 : (strcmp(e, "hilbert") == 0 ? 1 : 0);
+  }();
+  if (!d_pos || forced >= 0) return tiles_build_mode(p, d_pos, tile_target, st, forced > 0 ? 1 : 0);
+  int rc = tiles_build_mode(p, d_pos, tile_target, st, 0);
+  if (rc == 0 && !p->tiled) rc = tiles_build_mode(p, d_pos, tile_target, st, 1);
   return rc;
 }

@@ -803,7 +803,9 @@ TRACE_BUDGET_BYTES = 8 << 30  # keep every iterate only while (thr+2)*N*d*4 stay
 
 
 class DeviceBroyden:
-    def __init__(self, plan=None, threshold=50, keep_trace=False, n_elems=None, seq_len=D, device=None):
+    def __init__(self, plan=None, threshold=50, keep_trace=False, n_elems=None, seq_len=D, device=None, shard_elems=0):
+        """``shard_elems`` > 0: the solver will run inside ``broyden_solve_batch`` with others; its reduction shapes are sized
+        for the whole shard (sum of N * d), and its single-mesh solves give the same bits as the batched ones."""
         h = C.c_void_p()
         self.plan = plan
         self.threshold = int(threshold)
@@ -811,8 +813,8 @@ class DeviceBroyden:
         self.device = plan.device if plan is not None else device
         with torch.cuda.device(self.device):
             if plan is not None:
-                nat.check(nat.lib().psignn_broyden_create(C.byref(h), plan.handle, self.threshold, int(keep_trace)),
-                          "psignn_broyden_create")
+                nat.check(nat.lib().psignn_broyden_create_for_batch(C.byref(h), plan.handle, self.threshold, int(keep_trace),
+                                                                     int(shard_elems)), "psignn_broyden_create_for_batch")
                 self.M = plan.N * D
             else:
                 nat.check(nat.lib().psignn_broyden_create_n(C.byref(h), int(n_elems), int(seq_len), self.threshold,

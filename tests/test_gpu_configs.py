@@ -114,13 +114,29 @@ def test_config3_shard_of_eight_50k_meshes(dev):
         assert torch.equal(a[1], b[1]) and a[2]["nsteps"] == b[2]["nsteps"]
         assert float(a[2]["residual_loss"]) == float(b[2]["residual_loss"])
     assert len({r[2]["nsteps"] for r in seq}) > 1 or len({float(r[2]["residual_loss"]) for r in seq}) == 8  # distinct problems
-    # the batched device solver: one launch per pass over all eight meshes, own stop test per mesh -- same bits again
+    # the batched device solver: one launch per pass over all eight meshes, own stop test per mesh.  Its solvers size their
+    # reductions for the shard (DeviceBroyden(shard_elems=...)): bit-identical to single solves with THOSE solvers, and equal to
+    # the plain path up to the solver tolerance
+    eng = pkg("engine")
+    mds = [m.to(dev) for m in meshes]
+    with torch.no_grad():
+        fmaps = [net.deqdss.f.bind(net.autoencoder.encoder(md.x), md) for md in mds]
+    total = sum(f.plan.N for f in fmaps) * 10
+    solvers = [eng.DeviceBroyden(plan=f.plan, threshold=60, keep_trace=False, shard_elems=total) for f in fmaps]
+    single = [sv.solve(f, 1e-4) for sv, f in zip(solvers, fmaps)]
+    outs = eng.broyden_solve_batch(solvers, fmaps, 1e-4)
+    for a, b in zip(single, outs):
+        assert a["n_iter"] == b["n_iter"] and a["nstep"] == b["nstep"] and a["rel_trace"] == b["rel_trace"]
+        assert torch.equal(a["result"], b["result"])
+    for sv in solvers:
+        sv.close()
     bat = batch.solve_shard_batched(net, meshes, dev)
     assert [r[0] for r in bat] == list(range(8))
-    for a, b in zip(seq, bat):
-        assert a[2]["nsteps"] == b[2]["nsteps"], (a[2]["nsteps"], b[2]["nsteps"])
-        assert torch.equal(a[1], b[1])
-        assert float(a[2]["residual_loss"]) == float(b[2]["residual_loss"])
+    for a, b, o in zip(seq, bat, outs):
+        assert b[2]["nsteps"] == o["nstep"]
+        # plain path (per-mesh reduction shapes) vs batched path (shard shapes): two fp32 runs of an iteration that has not
+        # converged at 60 steps on a 50k-node mesh (its residual bottoms out near step 30) -- same quality, not the same bits
+        assert abs(float(a[2]["residual_loss"]) - float(b[2]["residual_loss"])) < 0.2 * float(a[2]["residual_loss"])
     # mesh 5 against the oracle: f, and the first Broyden iterations of the full solve
     m = meshes[5]
     md, h0, plan, fm = _fmap(m, sd, dev)
@@ -174,12 +190,9 @@ def test_batched_solver_ragged_shard_and_fallbacks(dev):
     mds = [m.to(dev) for m in meshes]
     with torch.no_grad():
         fmaps = [net.deqdss.f.bind(net.autoencoder.encoder(md.x), md) for md in mds]
-    single = []
-    for f in fmaps:
-        sv = eng.DeviceBroyden(plan=f.plan, threshold=300, keep_trace=False)
-        single.append(sv.solve(f, 1e-5))
-        sv.close()
-    solvers = [eng.DeviceBroyden(plan=f.plan, threshold=300, keep_trace=False) for f in fmaps]
+    total = sum(f.plan.N for f in fmaps) * 10
+    solvers = [eng.DeviceBroyden(plan=f.plan, threshold=300, keep_trace=False, shard_elems=total) for f in fmaps]
+    single = [sv.solve(f, 1e-5) for sv, f in zip(solvers, fmaps)]      # the same solver objects, one mesh at a time
     outs = eng.broyden_solve_batch(solvers, fmaps, 1e-5)
     assert len({o["n_iter"] for o in single}) > 2          # the meshes really stop at different iterations
     for a, b in zip(single, outs):
@@ -193,8 +206,8 @@ def test_batched_solver_ragged_shard_and_fallbacks(dev):
         sv.close()
     seq = batch.solve_shard(net, meshes, dev)
     bat = batch.solve_shard_batched(net, meshes, dev, group=4)
-    for a, b in zip(seq, bat):
-        assert torch.equal(a[1], b[1]) and a[2]["nsteps"] == b[2]["nsteps"]
+    for a, b in zip(seq, bat):      # plain path (per-mesh reduction shapes) vs batched (shard shapes): solver tolerance
+        assert rel_l2(b[1], a[1]) < 5e-3
     # mixed family: not batched -> falls back, same results as the plain path
     mnet = pkg("mixed").ModelPSIGNN(dict(latent_dim=10, n_layers=1, fw_tol=1e-4, fw_thres=200))
     mnet.load_state_dict(load_weights("mixed"))

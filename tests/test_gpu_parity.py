@@ -409,7 +409,8 @@ def test_full_size_properties(dev):
     solver = pkg("utilities.solver")
     out = solver.broyden(fm, fm.h0, threshold=40, eps=1e-5, keep_trace=False)
     assert out["n_iter"] == 40 and np.all(np.isfinite(out["rel_trace"]))
-    assert out["rel_trace"][39] < out["rel_trace"][0]
+    # (at this size the residual bottoms out around iteration 30 and wanders afterwards: the lowest value is what counts)
+    assert min(out["rel_trace"][:40]) < 0.2 * out["rel_trace"][0] and out["lowest"] == min(out["rel_trace"][:40])
 
 
 def test_full_size_adjoint_and_gradient_properties(dev):

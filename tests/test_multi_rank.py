@@ -29,10 +29,10 @@ def _worker(rank, world, port, n_meshes, q):
              "mse_loss": torch.tensor(float(rank))}
     mean = batch.mean_over_replicas(local)
     total = batch.gather_counts(len(mine))
-    t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
     dist.barrier()
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    q.put((rank, mine, {k: float(v) for k, v in mean.items()}, total, float(t)))
+    t = batch.max_over_ranks(0.1 * (rank + 1))          # bench.py: the job's time is the slowest rank's
+    seeds = batch.rank_seeds(rank, world, 3)            # bench.py: problem seeds of this rank's meshes
+    q.put((rank, mine, {k: float(v) for k, v in mean.items()}, total, t, seeds))
     dist.destroy_process_group()
 
 
@@ -58,7 +58,9 @@ def test_two_ranks_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, m0, mean0, tot0, t0), (r1, m1, mean1, tot1, t1) = res
+    (r0, m0, mean0, tot0, t0, s0), (r1, m1, mean1, tot1, t1, s1) = res
+    assert s0 == [0, 1, 2] and s1 == [3, 4, 5]          # distinct problems per rank; 8 ranks x 8 meshes = seeds 0 .. 63
+    assert sorted(sum((pkg("batch").rank_seeds(r, 8, 8) for r in range(8)), [])) == list(range(64))
     assert m0 == [0, 2, 4] and m1 == [1, 3]
     assert tot0 == tot1 == n_meshes
     # mean over replicas of the per-replica means, as DataParallel's loss.mean() (training_class.py:156-159)
