@@ -89,6 +89,10 @@ struct TileCtx {
   const uint8_t* slice_deg;
   const uint4* ell;
   const uint8_t* flags_p;
+  // tiles are consecutive chunks of `tile_nodes` nodes (a multiple of 64; the last tile may be short): a tile's node range and
+  // its first slice follow from its index -- no dependent scalar load in front of the kernel's first vector loads
+  int32_t tile_nodes;
+  int32_t n_nodes;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -142,9 +142,11 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
   const int tile = tile_list ? tile_list[slot] : slot;   // mixed plans: a sub-list of the tiles (see launch_mixed)
   STAMP(0);
   const int tid = threadIdx.x;
-  const int32_t* __restrict__ tile_ptr = C->tile_ptr;
-  const int32_t t0 = tile_ptr[tile];
-  const int n_t = tile_ptr[tile + 1] - t0;
+  // tile -> node range: arithmetic when the plan's tiles are uniform chunks (always, since round 2; the table stays for
+  // tile sizes that are not a multiple of 64)
+  const int tn = C->tile_nodes;
+  const int32_t t0 = tn ? tile * tn : C->tile_ptr[tile];
+  const int n_t = tn ? min(tn, C->n_nodes - t0) : C->tile_ptr[tile + 1] - t0;
   const int n_h = C->halo_cnt[tile];
   const int32_t* hl = C->halo + (int64_t)tile * HALO_CAP;
   if (hsel) h += (int64_t)(*hsel) * hstride;
@@ -239,7 +241,7 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
   // registers for the walk, the others are only pulled towards L2 / L1 (their first words are folded into a value that is
   // looked at once after stage 1 and never acted on), so that the walk's loads are cache hits.
   if ((tid & ~63) < n_t) {
-    const int pslice = C->tile_slice[tile] + (tid >> 6);
+    const int pslice = (tn ? tile * (tn >> 6) : C->tile_slice[tile]) + (tid >> 6);
     const uint4* pslots = C->ell + (int64_t)C->slice_off[pslice] * 64 + (tid & 63);
     const int pn = C->slice_deg[pslice];
     if (pn > 0) {   // (the fused Broyden step has no four registers to spare across stage 1: it only touches row 0 as well)
@@ -415,7 +417,7 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
   }
   if (!dirichlet && active) {
   const int lane = tid & 63;
-  const int slice = C->tile_slice[tile] + (tid >> 6);
+  const int slice = (tn ? tile * (tn >> 6) : C->tile_slice[tile]) + (tid >> 6);
   const uint4* slots = C->ell + (int64_t)C->slice_off[slice] * 64 + lane;
   const int nslots = C->slice_deg[slice];
 

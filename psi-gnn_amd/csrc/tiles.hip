@@ -532,7 +532,8 @@ static int tiles_build_mode(psignn_plan* p, const float* d_pos, int tile_target,
     HT(hipMemcpy(p->tile_order, order.data(), p->n_tiles * 4, hipMemcpyHostToDevice));
   }
   {
-    TileCtx h{p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell, p->flags_p};
+    TileCtx h{p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell, p->flags_p,
+              (tile_target % 64 == 0) ? tile_target : 0, (int32_t)N};
     HT(hipMalloc((void**)&p->d_ctx, sizeof(TileCtx)));
     HT(hipMemcpy(p->d_ctx, &h, sizeof(TileCtx), hipMemcpyHostToDevice));
     p->h_ctx = h;
