@@ -229,17 +229,16 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
 #define HALO_SPLIT 1   // 1: halo rows of stage 1 shared out as half rows over all four waves (see below); 0: round 1's loop
 #endif
 #ifndef SLOT_PREFETCH
-#define SLOT_PREFETCH 0   // 1: the wave's slot rows are requested before stage 1 (row 0 kept, the rest pulled towards L2).
+#define SLOT_PREFETCH 2   // 2: flag byte and slot row 0 requested before the stage-1 barrier (default); 0: after it; 1: the wave's slot rows are requested before stage 1 (row 0 kept, the rest pulled towards L2).
                           // Measured (1M nodes, plain f): 64.7 - 65.2 us with, 57.5 - 58.2 us without -- the extra pass over the
                           // slot records costs more than the walk's misses; kept for A/B runs
 #endif
 #if HALO_SPLIT
-#if SLOT_PREFETCH
-  // The slot walk of stage 2 streams 16-byte records that nobody has touched before: an HBM miss (~0.4 us under load) per
-  // slot row, with one row's arithmetic (~0.15 us of issue time) to hide it -- stamps put the walk at 7.7 us per wave where
-  // its instructions account for 4.  Every wave therefore requests its slot rows NOW, ahead of the h rows: row 0 stays in
-  // registers for the walk, the others are only pulled towards L2 / L1 (their first words are folded into a value that is
-  // looked at once after stage 1 and never acted on), so that the walk's loads are cache hits.
+#if SLOT_PREFETCH == 1
+  // (experiment, off) every wave requests ALL its slot rows ahead of the h rows: row 0 stays in registers for the walk, the
+  // others are only pulled towards L2 / L1 (their first words are folded into a value that is looked at once and never acted
+  // on).  Measured: 64.7 - 65.2 us vs 57.5 - 58.2 us without -- the second pass over the slot records costs more than the
+  // walk's misses.
   if ((tid & ~63) < n_t) {
     const int pslice = (tn ? tile * (tn >> 6) : C->tile_slice[tile]) + (tid >> 6);
     const uint4* pslots = C->ell + (int64_t)C->slice_off[pslice] * 64 + (tid & 63);
@@ -257,9 +256,20 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
   const int32_t hidx_w = (tid >> 6 & 1) * 64 + (tid & 63);   // this lane's halo slot inside a 128-row batch
   int32_t hnode = 0;
   if (hidx_w < n_h) hnode = hl[hidx_w];                        // halo index of the first batch, ahead of its use
+  float xr[D], xh[D];
+  if (tid < n_t) load10(h + (int64_t)(t0 + tid) * D, xr);
+  // the first batch's halo row is requested before the own row is projected (the phase barriers below would otherwise keep
+  // its load behind that arithmetic): one more memory round trip off stage 1's critical path
+  if (hidx_w < n_h) {
+    load10(h + (int64_t)hnode * D, xh);
+    if (FUSED) {
+      float uh[D];
+      load10(fa.upd + (int64_t)hnode * D, uh);
+#pragma unroll
+      for (int o = 0; o < D; ++o) xh[o] += uh[o];
+    }
+  }
   if (tid < n_t) {
-    float xr[D];
-    load10(h + (int64_t)(t0 + tid) * D, xr);
     if (FUSED) {  // x_next = x_cur + update (line_search with on=False: step 1, solver.py:85-94)
       float ur[D];
       load10(fa.upd + (int64_t)(t0 + tid) * D, ur);
@@ -307,12 +317,17 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
       if (hb > 0 && idx < n_h) hnode = hl[idx];
       if (idx < n_h) {
         float xr[D];
-        load10(h + (int64_t)hnode * D, xr);
-        if (FUSED) {
-          float ur[D];
-          load10(fa.upd + (int64_t)hnode * D, ur);
+        if (hb == 0) {
 #pragma unroll
-          for (int o = 0; o < D; ++o) xr[o] += ur[o];
+          for (int o = 0; o < D; ++o) xr[o] = xh[o];
+        } else {
+          load10(h + (int64_t)hnode * D, xr);
+          if (FUSED) {
+            float ur[D];
+            load10(fa.upd + (int64_t)hnode * D, ur);
+#pragma unroll
+            for (int o = 0; o < D; ++o) xr[o] += ur[o];
+          }
         }
         v2f ta[5];
 #pragma unroll
@@ -397,15 +412,23 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
   }
 #endif
   }
+  // stage 2's first loads -- the node's flag byte and slot row 0 -- are requested BEFORE the barrier: both sit on the
+  // critical path right behind it (flag -> Dirichlet branch -> slot pointer -> first record), an HBM round trip each
+  const bool active = tid < n_t;
+  const int64_t n = (int64_t)t0 + (active ? tid : 0);
+  const uint8_t fl = C->flags_p[n];
+#if HALO_SPLIT && SLOT_PREFETCH == 2
+  if (!MFMA1 && active) {
+    const int pslice = (tn ? tile * (tn >> 6) : C->tile_slice[tile]) + (tid >> 6);
+    if (C->slice_deg[pslice] > 0) slot0 = C->ell[(int64_t)C->slice_off[pslice] * 64 + (tid & 63)];
+  }
+#endif
   STAMP(1);
   __syncthreads();
   STAMP(2);
   if (!FUSED && tid >= n_t) return;
 
   // ---- stage 2: one tile node per lane
-  const bool active = tid < n_t;
-  const int64_t n = (int64_t)t0 + (active ? tid : 0);
-  const uint8_t fl = C->flags_p[n];
   float y[D];
   const bool dirichlet = fl & FLAG_DIRICHLET;
   if (dirichlet) {  // Dirichlet rows <- h_initial rows (model.py:298)
@@ -449,7 +472,7 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
 #if EDGE_CLAMP
 #if HALO_SPLIT && SLOT_PREFETCH
     edge_pass_both_clamp<RS>(slots, nslots, lds, T + L::T_A_TO, T + L::T_A_FR, Pi, Pi2, S_to, S_fr, deg_in, deg_out,
-                             (MFMA1 || FUSED) ? nullptr : &slot0);
+                             (MFMA1 || (FUSED && SLOT_PREFETCH == 1)) ? nullptr : &slot0);
 #else
     edge_pass_both_clamp<RS>(slots, nslots, lds, T + L::T_A_TO, T + L::T_A_FR, Pi, Pi2, S_to, S_fr, deg_in, deg_out);
 #endif
