@@ -229,7 +229,8 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
 #define HALO_SPLIT 1   // 1: halo rows of stage 1 shared out as half rows over all four waves (see below); 0: round 1's loop
 #endif
 #ifndef SLOT_PREFETCH
-#define SLOT_PREFETCH 2   // 2: flag byte and slot row 0 requested before the stage-1 barrier (default); 0: after it; 1: the wave's slot rows are requested before stage 1 (row 0 kept, the rest pulled towards L2).
+#define SLOT_PREFETCH 0   // 0 (default): stage 2 requests its slot rows itself; 2: flag byte and slot row 0 requested before the
+                          // stage-1 barrier (measured: plain f 53.6 vs 53.2 us, fused step 95.0 vs 90.1 us -- no gain); 1: the wave's slot rows are requested before stage 1 (row 0 kept, the rest pulled towards L2).
                           // Measured (1M nodes, plain f): 64.7 - 65.2 us with, 57.5 - 58.2 us without -- the extra pass over the
                           // slot records costs more than the walk's misses; kept for A/B runs
 #endif
@@ -419,7 +420,7 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
   const uint8_t fl = C->flags_p[n];
 #if HALO_SPLIT && SLOT_PREFETCH == 2
   if (!MFMA1 && active) {
-    const int pslice = (tn ? tile * (tn >> 6) : C->tile_slice[tile]) + (tid >> 6);
+    const int pslice = (tn ? tile * (tn >> 6) : C->tile_slice[tile]) + __builtin_amdgcn_readfirstlane(tid >> 6);
     if (C->slice_deg[pslice] > 0) slot0 = C->ell[(int64_t)C->slice_off[pslice] * 64 + (tid & 63)];
   }
 #endif
@@ -440,7 +441,8 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
   }
   if (!dirichlet && active) {
   const int lane = tid & 63;
-  const int slice = (tn ? tile * (tn >> 6) : C->tile_slice[tile]) + (tid >> 6);
+  // the wave index is wave-uniform: saying so keeps the slice's slot count and the whole slot-loop control in scalar registers
+  const int slice = (tn ? tile * (tn >> 6) : C->tile_slice[tile]) + __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint4* slots = C->ell + (int64_t)C->slice_off[slice] * 64 + lane;
   const int nslots = C->slice_deg[slice];
 
