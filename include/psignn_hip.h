@@ -143,9 +143,10 @@ int psignn_f_vjp(const psignn_plan_t* plan, const float* d_weights, int n_layers
                  const float* d_prb, const float* d_normals, const float* d_w, float* d_out, float* d_work,
                  void* stream);
 
-/* JVP with h, prb, v and out in plan order (tiled single-layer dirichlet plans; the tiled LDS-staged kernel). */
+/* JVP with h, prb, normals, v and out in plan order (the tiled LDS-staged kernel: single-layer dirichlet plans, and
+ * mixed plans of any depth, whose iterated layer is the last one).  d_normals: (N,2) in plan order for mixed plans, else NULL. */
 int psignn_f_jvp_p(const psignn_plan_t* plan, const float* d_weights, int n_layers, const float* d_h, const float* d_prb,
-                   const float* d_v, float* d_out, void* stream);
+                   const float* d_normals, const float* d_v, float* d_out, void* stream);
 
 /* Same with h, prb, w and out in plan order (tiled kernels where the plan has tiles; the form the adjoint solve uses). */
 int psignn_f_vjp_p(const psignn_plan_t* plan, const float* d_weights, int n_layers, const float* d_h,

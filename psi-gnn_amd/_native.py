@@ -52,7 +52,7 @@ SIGNATURES = {
     "psignn_f_forward": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P]),
     "psignn_phi": (_INT, [_P, _P, _INT, _INT, _INT, _P, _P, _P, _P]),
     "psignn_f_jvp": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P]),
-    "psignn_f_jvp_p": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P]),
+    "psignn_f_jvp_p": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P]),
     "psignn_f_vjp": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P]),
     "psignn_f_vjp_p": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P]),
     "psignn_param_grad_size": (_I64, [_INT, _INT]),

@@ -13,6 +13,8 @@
 #include "common.h"
 
 #include "fgnn_common.h"
+#include <string.h>
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------
 // Kernel 1: neighbour-side projections.  NPH = number of Phi modules (2 dirichlet, 3 mixed).
@@ -430,15 +432,15 @@ extern "C" int psignn_phi(const psignn_plan_t* p, const float* W, int nl, int la
   return PSIGNN_OK;
 }
 
-int psignn_f_tile_jvp(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* v,
+int psignn_f_tile_jvp(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* nrm, const float* v,
                       float* out, hipStream_t st);
 
 // plan-order JVP (tiled single-layer dirichlet plans): the form a Krylov solver that keeps its vectors in plan order uses
 extern "C" int psignn_f_jvp_p(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* prb,
-                              const float* v, float* out, void* stream) {
+                              const float* nrm, const float* v, float* out, void* stream) {
   ARG_CHECK(p && W && h && prb && v && out, "NULL argument");
   ARG_CHECK(out != v && out != h, "out must not alias its inputs");
-  return psignn_f_tile_jvp(p, W, nl, h, prb, v, out, (hipStream_t)stream);
+  return psignn_f_tile_jvp(p, W, nl, h, prb, nrm, v, out, (hipStream_t)stream);
 }
 
 extern "C" int psignn_f_jvp(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* prb,
@@ -448,16 +450,20 @@ extern "C" int psignn_f_jvp(const psignn_plan_t* p, const float* W, int nl, cons
   ARG_CHECK(v != nullptr && out != v, "v is NULL or aliases out");
   ARG_CHECK(p->mixed || nl == 1, "JVP of a multi-layer dirichlet block is not implemented");
   hipStream_t st = (hipStream_t)stream;
-  if (p->tiled && !p->mixed && nl == 1) {  // caller numbering -> plan order -> tiled kernel -> caller numbering
+  static const bool mixed_tiled = [] { const char* e = getenv("PSIGNN_MIXED_JVP"); return !(e && strcmp(e, "gather") == 0); }();
+  if (p->tiled && (p->mixed ? mixed_tiled : nl == 1)) {  // caller numbering -> plan order -> tiled kernel -> caller numbering
     const int64_t N = p->N;
+    const int P = p->mixed ? 3 : 2;
     float* hp = work;
     float* vp = hp + N * D;
     float* op = vp + N * D;
-    float* pp = op + N * D;  // (N, 2)
+    float* pp = op + N * D;  // (N, P)
+    float* np = pp + N * 3;  // (N, 2) unit normals of a mixed plan
     if ((rc = psignn_plan_permute(p, h, D, hp, 1, stream))) return rc;
     if ((rc = psignn_plan_permute(p, v, D, vp, 1, stream))) return rc;
-    if ((rc = psignn_plan_permute(p, prb, 2, pp, 1, stream))) return rc;
-    if ((rc = psignn_f_tile_jvp(p, W, nl, hp, pp, vp, op, st))) return rc;
+    if ((rc = psignn_plan_permute(p, prb, P, pp, 1, stream))) return rc;
+    if (p->mixed && (rc = psignn_plan_permute(p, nrm, 2, np, 1, stream))) return rc;
+    if ((rc = psignn_f_tile_jvp(p, W, nl, hp, pp, p->mixed ? np : nullptr, vp, op, st))) return rc;
     return psignn_plan_permute(p, op, D, out, 0, stream);
   }
   if (p->mixed)

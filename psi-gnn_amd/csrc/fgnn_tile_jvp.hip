@@ -1,4 +1,5 @@
-// Tiled Jacobian-vector product of f_theta (dirichlet family, single layer), plan order (gfx950).
+// Tiled Jacobian-vector product of f_theta (both families; the layer a solver iterates: single layer, or the last layer of
+// the mixed family's loop, which reads the original h -- mixed/psignn/model.py:221-245), plan order (gfx950).
 //
 // out = J_f(h) v: what the Newton-Krylov solver of BASELINE configs[4] needs once per inner iteration (the reference only
 // imports scipy's newton_krylov, utilities/solver.py:6; its finite-difference JVPs do not converge in fp32).
@@ -7,7 +8,10 @@
 //            -> 160-byte LDS row [Pj_to | Pj_from | dPj_to | dPj_from];
 //   stage 2  per node and direction, one walk over the pair-merged slots:  z = Pi + Pj + A a,  S += relu(z),
 //            dS += 1[z > 0] (dPi + dPj);  then the tangent of the folded gate / update MLP and of LayerNorm.
-// Dirichlet rows of f are constants: their tangent is 0.
+// Dirichlet rows of f are constants: their tangent is 0.  Mixed family: a Neumann row is update_neumann([h | Phi_neumann(h)
+// | prb | normal]) (it REPLACES the row, mixed/psignn/model.py:236,241) -- its tangent comes from a third slot walk over the
+// Phi_neumann columns, which tiles WITH Neumann nodes stage as 20 more floats per LDS row (tiles without run the 160-byte
+// form in a launch of their own, like k_f_tile).
 #include "tile_helpers.h"
 #include <stdlib.h>
 #include <string.h>
@@ -70,20 +74,24 @@ __device__ __forceinline__ float edge_pass_jvp(const uint4* __restrict__ slots, 
   return deg;
 }
 
-template <int P, bool MFMA1>
-__global__ __launch_bounds__(TILE_THREADS) void k_jvp_tile(int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
+template <int P, bool MIXED, bool MFMA1>
+__global__ __launch_bounds__(TILE_THREADS) void k_jvp_tile(int n_tiles, int chunk, const int32_t* __restrict__ tile_list,
+                                                           const int32_t* __restrict__ tile_ptr,
                                                            const int32_t* __restrict__ tile_slice,
                                                            const int32_t* __restrict__ halo, const int32_t* __restrict__ halo_cnt,
                                                            const int32_t* __restrict__ slice_off,
                                                            const uint8_t* __restrict__ slice_deg, const uint4* __restrict__ ell,
                                                            const uint8_t* __restrict__ flags, const float* __restrict__ W, int lofs,
-                                                           int tofs, const float* __restrict__ h, const float* __restrict__ prb,
+                                                           int tofs, int tnofs, const float* __restrict__ h,
+                                                           const float* __restrict__ prb, const float* __restrict__ nrm,
                                                            const float* __restrict__ tv, float* __restrict__ out) {
   using L = WLayout<P>;
-  constexpr int RS = 40;
+  constexpr int RS = MIXED ? 60 : 40;   // [Pj_to | Pj_from | dPj_to | dPj_from (| Pj_neu | dPj_neu)]
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (tile >= n_tiles) return;
+  const int slot_ = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (slot_ >= n_tiles) return;
+  const int tile = tile_list ? tile_list[slot_] : slot_;
+  const float* TN = W + tnofs;
   const int tid = threadIdx.x;
   const int32_t t0 = tile_ptr[tile];
   const int n_t = tile_ptr[tile + 1] - t0;
@@ -170,13 +178,26 @@ __global__ __launch_bounds__(TILE_THREADS) void k_jvp_tile(int n_tiles, int chun
     q[7] = make_float4(da[4].x, da[4].y, db[0].x, db[0].y);
     q[8] = make_float4(db[1].x, db[1].y, db[2].x, db[2].y);
     q[9] = make_float4(db[3].x, db[3].y, db[4].x, db[4].y);
+    if (MIXED) {   // Phi_neumann columns of the state and the tangent row
+#pragma unroll
+      for (int p = 0; p < 5; ++p) ta[p] = da[p] = splat(0.f);
+      PHASE();
+      mv2<D>(TN + L::N_W1J, xr, ta);
+      mv2<D>(TN + L::N_W1J, vr, da);
+      q[10] = make_float4(ta[0].x, ta[0].y, ta[1].x, ta[1].y);
+      q[11] = make_float4(ta[2].x, ta[2].y, ta[3].x, ta[3].y);
+      q[12] = make_float4(ta[4].x, ta[4].y, da[0].x, da[0].y);
+      q[13] = make_float4(da[1].x, da[1].y, da[2].x, da[2].y);
+      q[14] = make_float4(da[3].x, da[3].y, da[4].x, da[4].y);
+    }
   }
   }
   __syncthreads();
   if (tid >= n_t) return;
   const int64_t n = (int64_t)t0 + tid;
   float dy[D];
-  if (flags[n] & FLAG_DIRICHLET) {
+  const uint8_t fl = flags[n];
+  if (fl & FLAG_DIRICHLET) {
 #pragma unroll
     for (int o = 0; o < D; ++o) dy[o] = 0.f;
     store10(out + n * D, dy);
@@ -186,6 +207,56 @@ __global__ __launch_bounds__(TILE_THREADS) void k_jvp_tile(int n_tiles, int chun
   const int slice = tile_slice[tile] + (tid >> 6);
   const uint4* slots = ell + (int64_t)slice_off[slice] * 64 + lane;
   const int nslots = slice_deg[slice];
+  float y[D], mu = 0.f;
+  if (MIXED && (fl & FLAG_NEUMANN)) {
+    // ---- Neumann row: y = N2 relu(q) + nb2, q = nb1 + deg gN + N1h x + Gn S_n + N1p [prb | normal]  (second Phi_neumann
+    // layer folded into Gn / gN like the interior path's), tangent through the same chain
+    v2f Pi[5], dPi[5], S_n[5], dS_n[5];
+    ld5(TN + L::N_B1, Pi);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) S_n[p] = dS_n[p] = dPi[p] = splat(0.f);
+    PHASE();
+    mv2<D>(TN + L::N_W1I, x, Pi);
+    mv2<D>(TN + L::N_W1I, dx, dPi);
+    const float deg_out = edge_pass_jvp<RS, 4 * D, 5 * D, SLOT_OUT>(slots, nslots, lds, TN + L::N_A, Pi, dPi, S_n, dS_n);
+    v2f q[5], dq[5], gN[5], y2[5], dy2[5];
+    ld5(TN + L::N_NB1, q);
+    ld5(TN + L::N_gN, gN);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      q[p] = __builtin_elementwise_fma(splat(deg_out), gN[p], q[p]);
+      dq[p] = dy2[p] = splat(0.f);
+    }
+    PHASE();
+    mv2<D>(TN + L::N_N1H, x, q);
+    mv2<D>(TN + L::N_N1H, dx, dq);
+    PHASE();
+    mv2<D>(TN + L::N_GN, reinterpret_cast<const float*>(S_n), q);
+    mv2<D>(TN + L::N_GN, reinterpret_cast<const float*>(dS_n), dq);
+    float pq[P + 2];
+#pragma unroll
+    for (int k = 0; k < P; ++k) pq[k] = prb[n * P + k];
+    pq[P] = nrm[n * 2];
+    pq[P + 1] = nrm[n * 2 + 1];
+    PHASE();
+    mv2<P + 2>(TN + L::N_N1P, pq, q);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      dq[p] = (v2f){q[p].x > 0.f ? dq[p].x : 0.f, q[p].y > 0.f ? dq[p].y : 0.f};
+      q[p] = __builtin_elementwise_max(q[p], splat(0.f));
+    }
+    ld5(TN + L::N_NB2, y2);
+    PHASE();
+    mv2<D>(TN + L::N_N2, reinterpret_cast<const float*>(q), y2);
+    mv2<D>(TN + L::N_N2, reinterpret_cast<const float*>(dq), dy2);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      y[2 * p] = y2[p].x; y[2 * p + 1] = y2[p].y;
+      dy[2 * p] = dy2[p].x; dy[2 * p + 1] = dy2[p].y;
+    }
+#pragma unroll
+    for (int o = 0; o < D; ++o) mu += y[o];
+  } else {
   // ---- stage 2: neighbour sums and their tangents
   v2f Pi[5], dPi[5], S_to[5], S_fr[5], dS_to[5], dS_fr[5];
   ld5(T + L::T_B1_TO, Pi);
@@ -263,12 +334,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_jvp_tile(int n_tiles, int chun
   mv2<D>(T + L::T_U2, reinterpret_cast<const float*>(dq), dupd);
   const float* u = reinterpret_cast<const float*>(upd);
   const float* du = reinterpret_cast<const float*>(dupd);
-  float y[D], mu = 0.f;
 #pragma unroll
   for (int o = 0; o < D; ++o) {
     y[o] = fmaf(al, u[o], x[o]);
     dy[o] = dx[o] + dal * u[o] + al * du[o];
     mu += y[o];
+  }
   }
   // ---- LayerNorm tangent (eps 1e-5, biased variance)
   mu *= (1.f / D);
@@ -294,10 +365,30 @@ __global__ __launch_bounds__(TILE_THREADS) void k_jvp_tile(int n_tiles, int chun
   store10(out + n * D, dy);
 }
 
-// h, prb, v, out in PLAN order.
-int psignn_f_tile_jvp(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* v,
-                      float* out, hipStream_t st) {
-  ARG_CHECK(p && p->tiled && !p->mixed && nl == 1, "tiled JVP: dirichlet single-layer plans only");
+// h, prb, nrm (mixed plans), v, out in PLAN order.
+int psignn_f_tile_jvp(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* nrm,
+                      const float* v, float* out, hipStream_t st) {
+  ARG_CHECK(p && p->tiled && (nl == 1 || p->mixed), "tiled JVP: tiled plans, single-layer blocks (mixed: any depth, last layer)");
+  ARG_CHECK(!p->mixed || nrm, "mixed plan needs unit normals");
+#define JVP_TILE_ARGS p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell, p->flags_p
+  if (p->mixed) {
+    using L = WLayout<3>;
+    const int lofs = L::layer(nl - 1), tofs = L::tp_layer(nl, true, nl - 1), tnofs = L::tp_neu(nl);
+    const int na = (int)p->n_tiles_plain, nb = (int)(p->n_tiles - p->n_tiles_plain);
+    ARG_CHECK((size_t)p->max_rows * 60 * 4 <= 160 * 1024, "tile + halo rows exceed the LDS budget of the tiled JVP");
+    if (na > 0) {   // tiles without Neumann nodes: 160-byte LDS rows, no Neumann branch
+      const int chunk = (int)cdiv(na, 8);
+      LAUNCH("k_jvp_tile", st, (k_jvp_tile<3, false, false><<<(unsigned)(chunk * 8), TILE_THREADS, (size_t)p->max_rows * 40 * 4, st>>>(
+          na, chunk, p->tile_order, JVP_TILE_ARGS, W, lofs, tofs, tnofs, h, prb, nrm, v, out)));
+    }
+    if (nb > 0) {
+      const int chunk = (int)cdiv(nb, 8);
+      LAUNCH("k_jvp_tile", st, (k_jvp_tile<3, true, false><<<(unsigned)(chunk * 8), TILE_THREADS, (size_t)p->max_rows * 60 * 4, st>>>(
+          nb, chunk, p->tile_order + na, JVP_TILE_ARGS, W, lofs, tofs, tnofs, h, prb, nrm, v, out)));
+    }
+    HIP_TRY(hipGetLastError());
+    return PSIGNN_OK;
+  }
   using L = WLayout<2>;
   const int chunk = (int)cdiv(p->n_tiles, 8);
   const size_t lds = (size_t)p->max_rows * 40 * 4;
@@ -308,13 +399,11 @@ int psignn_f_tile_jvp(const psignn_plan* p, const float* W, int nl, const float*
     return e ? (strcmp(e, "mfma") == 0) : JVP_STAGE1_DEFAULT_MFMA;
   }();
   if (use_mfma)
-    LAUNCH("k_jvp_tile", st, (k_jvp_tile<2, true><<<(unsigned)(chunk * 8), TILE_THREADS, lds, st>>>(
-        (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
-        p->flags_p, W, L::layer(0), L::tp_layer(nl, false, 0), h, prb, v, out)));
+    LAUNCH("k_jvp_tile", st, (k_jvp_tile<2, false, true><<<(unsigned)(chunk * 8), TILE_THREADS, lds, st>>>(
+        (int)p->n_tiles, chunk, nullptr, JVP_TILE_ARGS, W, L::layer(0), L::tp_layer(nl, false, 0), 0, h, prb, nrm, v, out)));
   else
-    LAUNCH("k_jvp_tile", st, (k_jvp_tile<2, false><<<(unsigned)(chunk * 8), TILE_THREADS, lds, st>>>(
-        (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell,
-        p->flags_p, W, L::layer(0), L::tp_layer(nl, false, 0), h, prb, v, out)));
+    LAUNCH("k_jvp_tile", st, (k_jvp_tile<2, false, false><<<(unsigned)(chunk * 8), TILE_THREADS, lds, st>>>(
+        (int)p->n_tiles, chunk, nullptr, JVP_TILE_ARGS, W, L::layer(0), L::tp_layer(nl, false, 0), 0, h, prb, nrm, v, out)));
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }

@@ -1,4 +1,5 @@
-// Tiled vector-Jacobian product of f_theta (dirichlet family, single layer), plan order (gfx950).
+// Tiled vector-Jacobian product of f_theta (single-layer dirichlet blocks; mixed blocks of any depth, whose iterated layer is
+// the last one and reads the original h -- mixed/psignn/model.py:221-245), plan order (gfx950).
 //
 // Same mathematics as fgnn_vjp.hip (two gather passes, no atomics; reference: autograd.grad(new_H, H, v),
 // dirichlet/psignn/model.py:210-223,416-452), on the tile structures of the mesh plan:
@@ -11,7 +12,13 @@
 //           from the neighbour's side:  OUT slot (edge u -> n): acc_t += dS_to[n] * 1[Pt[n] + Pjt[u] + At a > 0]
 //                                       IN  slot (edge n -> u): acc_f += dS_fr[n] * 1[Pf[n] + Pjf[u] + Af m(a) > 0]
 //           out[u] += W1j_to^T acc_t + W1j_fr^T acc_f.
-// All tensors in plan order.  Mixed plans use the global-gather kernels of fgnn_vjp.hip.
+// Mixed family: a Neumann row n is update_neumann([h | Phi_neumann(h) | prb | normal]) with Phi_neumann summing over the
+// node's OUT edges (mixed/psignn/model.py:225,233-236,241).  Pass A runs the tiles that hold Neumann nodes with a third
+// projection column in LDS (128-byte rows; the other tiles in a launch of their own, like k_f_tile) and writes
+// B[n] = { 0, Pn[n], 0, dS_n[n] } for such a row -- the Phi_from positions, its dS_to is zero.  Pass B keeps the rows' Neumann
+// flag beside the B rows in LDS: an IN slot (edge n -> u) whose sender n is a Neumann row uses Phi_neumann's weights and
+// accumulates into a third sum, out[u] += W1j_neu^T acc_n.  A tile without Neumann rows among tile + halo skips all of it.
+// All tensors in plan order.  The parameter-gradient records (PG) exist for the dirichlet family only.
 #include "fgnn_common.h"
 
 #define SLOT_IN 0x10000u
@@ -123,20 +130,50 @@ __device__ __forceinline__ void rec_group(float* __restrict__ g, const float* v,
   for (int i = 0; i < 4; ++i) q[i] = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
 }
 
-template <int P, bool PG>
-__global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
+// LayerNorm forward + backward at one row: y -> normalised y (in place), dy = d loss / d y for the cotangent w of LN(y)
+template <class L>
+__device__ __forceinline__ void ln_fwd_bwd(const float* __restrict__ W, float mu, float* y, const float* w, float* dy) {
+  mu *= (1.f / D);
+  float var = 0.f;
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    float c = y[o] - mu;
+    var = fmaf(c, c, var);
+  }
+  var *= (1.f / D);
+  const float rs = 1.f / sqrtf(var + 1e-5f);
+  float dyh[D], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int o = 0; o < D; ++o) {
+    y[o] = (y[o] - mu) * rs;
+    dyh[o] = w[o] * W[L::LN_G + o];
+    m1 += dyh[o];
+    m2 = fmaf(dyh[o], y[o], m2);
+  }
+  m1 *= (1.f / D);
+  m2 *= (1.f / D);
+#pragma unroll
+  for (int o = 0; o < D; ++o) dy[o] = rs * (dyh[o] - m1 - y[o] * m2);
+}
+
+template <int P, bool MIXED, bool PG>
+__global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const int32_t* __restrict__ tile_list,
+                                                   const int32_t* __restrict__ tile_ptr,
                                                    const int32_t* __restrict__ tile_slice, const int32_t* __restrict__ halo,
                                                    const int32_t* __restrict__ halo_cnt, const int32_t* __restrict__ slice_off,
                                                    const uint8_t* __restrict__ slice_deg, const uint4* __restrict__ ell,
-                                                   const uint8_t* __restrict__ flags, const float* __restrict__ W, int lofs,
-                                                   int tofs, const float* __restrict__ h, const float* __restrict__ prb,
+                                                   const uint8_t* __restrict__ flags, const float* __restrict__ W, int nl,
+                                                   int lofs, int tofs, int tnofs, const float* __restrict__ h,
+                                                   const float* __restrict__ prb, const float* __restrict__ nrm,
                                                    const float* __restrict__ wv, float* __restrict__ B,
                                                    float* __restrict__ out, float* __restrict__ rec) {
+  static_assert(!(MIXED && PG), "parameter-gradient records: dirichlet family only");
   using L = WLayout<P>;
-  constexpr int RS = 20;
+  constexpr int RS = MIXED ? 32 : 20;   // [Pj_to 10 | Pj_from 10 (| Pj_neu 10 | pad 2)]
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (tile >= n_tiles) return;
+  const int slot_ = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (slot_ >= n_tiles) return;
+  const int tile = tile_list ? tile_list[slot_] : slot_;
   const int tid = threadIdx.x;
   const int32_t t0 = tile_ptr[tile];
   const int n_t = tile_ptr[tile + 1] - t0;
@@ -166,12 +203,22 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const
     q[2] = make_float4(ta[4].x, ta[4].y, tb[0].x, tb[0].y);
     q[3] = make_float4(tb[1].x, tb[1].y, tb[2].x, tb[2].y);
     q[4] = make_float4(tb[3].x, tb[3].y, tb[4].x, tb[4].y);
+    if (MIXED) {
+#pragma unroll
+      for (int p = 0; p < 5; ++p) ta[p] = splat2(0.f);
+      PHASE();
+      mvf<D>(W + tnofs + L::N_W1J, xr, ta);
+      q[5] = make_float4(ta[0].x, ta[0].y, ta[1].x, ta[1].y);
+      q[6] = make_float4(ta[2].x, ta[2].y, ta[3].x, ta[3].y);
+      q[7] = make_float4(ta[4].x, ta[4].y, 0.f, 0.f);
+    }
   }
   __syncthreads();
   if (tid >= n_t) return;
   const int64_t n = (int64_t)t0 + tid;
   float4* Bn = reinterpret_cast<float4*>(B + n * 4 * D);
-  if (flags[n] & FLAG_DIRICHLET) {  // constant row: sends nothing
+  const uint8_t fl = flags[n];
+  if (fl & FLAG_DIRICHLET) {  // constant row: sends nothing
 #pragma unroll
     for (int i = 0; i < 10; ++i) Bn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     float zero[D];
@@ -190,6 +237,83 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const
   const int slice = tile_slice[tile] + (tid >> 6);
   const uint4* slots = ell + (int64_t)slice_off[slice] * 64 + lane;
   const int nslots = slice_deg[slice];
+  if (MIXED && (fl & FLAG_NEUMANN)) {
+    // ---- Neumann row: y = LN(N2 relu(q) + nb2), q = nb1 + deg gN + N1h x + Gn S_n + N1p [prb | normal]; the row was
+    // REPLACED, so there is no residual path
+    const float* TN = W + tnofs;
+    const float* Un = W + L::upd_neu(nl);
+    v2f Pn[5], S_n[5], c_n[5], dummy[1];
+    ldu5(TN + L::N_B1, Pn);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) S_n[p] = c_n[p] = splat2(0.f);
+    PHASE();
+    mvf<D>(TN + L::N_W1I, x, Pn);
+    const float deg_out = pass_fwd<RS, 2 * D, SLOT_OUT, false>(slots, nslots, lds, TN + L::N_A, Pn, S_n, c_n, dummy);
+    v2f q2[5], gN[5], hid2[5], y2[5];
+    ldu5(TN + L::N_NB1, q2);
+    ldu5(TN + L::N_gN, gN);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) q2[p] = __builtin_elementwise_fma(splat2(deg_out), gN[p], q2[p]);
+    PHASE();
+    mvf<D>(TN + L::N_N1H, x, q2);
+    PHASE();
+    mvf<D>(TN + L::N_GN, reinterpret_cast<const float*>(S_n), q2);
+    float pq[P + 2];
+#pragma unroll
+    for (int k = 0; k < P; ++k) pq[k] = prb[n * P + k];
+    pq[P] = nrm[n * 2];
+    pq[P + 1] = nrm[n * 2 + 1];
+    PHASE();
+    mvf<P + 2>(TN + L::N_N1P, pq, q2);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) hid2[p] = __builtin_elementwise_max(q2[p], splat2(0.f));
+    ldu5(TN + L::N_NB2, y2);
+    PHASE();
+    mvf<D>(TN + L::N_N2, reinterpret_cast<const float*>(hid2), y2);
+    float y[D], w[D], dy[D], mu = 0.f;
+#pragma unroll
+    for (int o = 0; o < D; ++o) {
+      y[o] = reinterpret_cast<const float*>(y2)[o];
+      mu += y[o];
+    }
+    load10(wv + n * D, w);
+    ln_fwd_bwd<L>(W, mu, y, w, dy);
+    v2f dq2[5], g[5], dS_n[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) dq2[p] = g[p] = dS_n[p] = splat2(0.f);
+    PHASE();
+    mvb<D>(Un + L::NEU_W2, D, 0, dy, dq2);
+    float dq[D];
+#pragma unroll
+    for (int o = 0; o < D; ++o) dq[o] = reinterpret_cast<const float*>(q2)[o] > 0.f ? reinterpret_cast<const float*>(dq2)[o] : 0.f;
+    PHASE();
+    mvb<D>(Un + L::NEU_W1, L::NEU_CAT, 0, dq, g);
+    PHASE();
+    mvb<D>(W + L::nfold(nl) + L::NF_G, D, 0, dq, dS_n);   // dS_n[k] = sum_o Gn[o][k] dq[o]
+    Bn[0] = Bn[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    Bn[2] = make_float4(0.f, 0.f, Pn[0].x, Pn[0].y);
+    Bn[3] = make_float4(Pn[1].x, Pn[1].y, Pn[2].x, Pn[2].y);
+    Bn[4] = make_float4(Pn[3].x, Pn[3].y, Pn[4].x, Pn[4].y);
+    Bn[5] = Bn[6] = make_float4(0.f, 0.f, 0.f, 0.f);
+    Bn[7] = make_float4(0.f, 0.f, dS_n[0].x, dS_n[0].y);
+    Bn[8] = make_float4(dS_n[1].x, dS_n[1].y, dS_n[2].x, dS_n[2].y);
+    Bn[9] = make_float4(dS_n[3].x, dS_n[3].y, dS_n[4].x, dS_n[4].y);
+    float gn[D], go[D];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      const v2f a = dS_n[p] * c_n[p];
+      gn[2 * p] = a.x; gn[2 * p + 1] = a.y;
+    }
+    PHASE();
+    mvb<D>(W + L::phi_neu(nl) + L::PHI_W1, L::EIN, 0, gn, g);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      go[2 * p] = g[p].x;
+      go[2 * p + 1] = g[p].y;
+    }
+    store10(out + n * D, go);
+    return;
+  }
   // ---- forward with activity counts
   v2f Pt[5], Pf[5], S_to[5], S_fr[5], c_to[5], c_fr[5];
   v2f m_to[PG ? 15 : 1], m_fr[PG ? 15 : 1];
@@ -253,32 +377,14 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const
     y[o] = fmaf(al, upd[o], x[o]);
     mu += y[o];
   }
-  mu *= (1.f / D);
-  float var = 0.f;
-#pragma unroll
-  for (int o = 0; o < D; ++o) {
-    float c = y[o] - mu;
-    var = fmaf(c, c, var);
-  }
-  var *= (1.f / D);
-  const float rs = 1.f / sqrtf(var + 1e-5f);
   // ---- backward: LayerNorm
-  float w[D], dyh[D], dy[D], m1 = 0.f, m2 = 0.f;
+  float w[D], dy[D];
   load10(wv + n * D, w);
-#pragma unroll
-  for (int o = 0; o < D; ++o) {
-    y[o] = (y[o] - mu) * rs;
-    dyh[o] = w[o] * W[L::LN_G + o];
-    m1 += dyh[o];
-    m2 = fmaf(dyh[o], y[o], m2);
-  }
-  m1 *= (1.f / D);
-  m2 *= (1.f / D);
+  ln_fwd_bwd<L>(W, mu, y, w, dy);
   float dal = 0.f, dupd[D];
   v2f g[5];
 #pragma unroll
   for (int o = 0; o < D; ++o) {
-    dy[o] = rs * (dyh[o] - m1 - y[o] * m2);
     dal = fmaf(dy[o], upd[o], dal);
     dupd[o] = al * dy[o];
   }
@@ -434,16 +540,59 @@ __device__ __forceinline__ void pass_rev(const uint4* __restrict__ slots, int ns
   }
 }
 
-template <int P, bool PG>
+// IN slots of a mixed plan: the sender n of edge (n -> u) is an interior row (Phi_from: weights AF, projection Pjf, sum af) or
+// a Neumann row (Phi_neumann: AN, Pjn, an) -- nflag[row] tells; both kinds keep Pi at row[10..] and dS at row[30..].
+template <int RS>
+__device__ __forceinline__ void pass_rev_in_mixed(const uint4* __restrict__ slots, int nslots, const float* __restrict__ lds,
+                                                  const int32_t* __restrict__ nflag, const float* __restrict__ AF,
+                                                  const float* __restrict__ AN, const v2f* Pjf, const v2f* Pjn, v2f* af,
+                                                  v2f* an) {
+  if (nslots <= 0) return;
+  uint4 c0 = slots[0];
+  uint4 c1 = slots[(int64_t)min(1, nslots - 1) * 64];
+  for (int r = 0; r < nslots; ++r) {
+    const uint4 nx = slots[(int64_t)min(r + 2, nslots - 1) * 64];
+    const unsigned w = c0.x;
+    if ((w & 0xFFFFu) != ELL_EMPTY && (w & SLOT_IN)) {
+      const int ri = (int)(w & 0xFFFFu);
+      const bool neu = nflag[ri] != 0;
+      const v2f a0 = splat2(-__uint_as_float(c0.y)), a1 = splat2(-__uint_as_float(c0.z));
+      const v2f a2 = splat2(__uint_as_float(c0.w));
+      const float* row = lds + ri * RS;
+      const v2f* wa = reinterpret_cast<const v2f*>(neu ? AN : AF);
+      v2f pi[5], ds[5], z[5];
+      row10u(row + D, pi);
+      row10u(row + 3 * D, ds);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = pi[p] + (neu ? Pjn[p] : Pjf[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[p], a0, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[5 + p], a1, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[10 + p], a2, z[p]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) {
+        const v2f t = (v2f){z[p].x > 0.f ? ds[p].x : 0.f, z[p].y > 0.f ? ds[p].y : 0.f};
+        if (neu) an[p] += t; else af[p] += t;
+      }
+    }
+    c0 = c1;
+    c1 = nx;
+  }
+}
+
+template <int P, bool MIXED, bool PG>
 __global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const int32_t* __restrict__ tile_ptr,
                                                    const int32_t* __restrict__ tile_slice, const int32_t* __restrict__ halo,
                                                    const int32_t* __restrict__ halo_cnt, const int32_t* __restrict__ slice_off,
                                                    const uint8_t* __restrict__ slice_deg, const uint4* __restrict__ ell,
-                                                   const float* __restrict__ W, int lofs, int tofs,
-                                                   const float* __restrict__ h, const float* __restrict__ B,
-                                                   float* __restrict__ out, float* __restrict__ rec) {
+                                                   const uint8_t* __restrict__ flags, const float* __restrict__ W, int nl,
+                                                   int lofs, int tofs, int tnofs, const float* __restrict__ h,
+                                                   const float* __restrict__ B, float* __restrict__ out,
+                                                   float* __restrict__ rec) {
   using L = WLayout<P>;
-  constexpr int RS = 40;  // LDS row = B row: [Pt 10 | Pf 10 | dS_to 10 | dS_fr 10]
+  constexpr int RS = 40;  // LDS row = B row: [Pt 10 | Pf 10 | dS_to 10 | dS_fr 10]; mixed: the rows' Neumann flags behind them
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (tile >= n_tiles) return;
@@ -459,7 +608,20 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const
     const int64_t node = row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t];
     reinterpret_cast<float4*>(lds)[row * 10 + c] = reinterpret_cast<const float4*>(B + node * 4 * D)[c];
   }
-  __syncthreads();
+  int32_t* nflag = reinterpret_cast<int32_t*>(lds + (n_t + n_h) * RS);
+  bool tile_neu = false;
+  if (MIXED) {
+    int any = 0;
+    for (int row = tid; row < n_t + n_h; row += VT) {
+      const int64_t node = row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t];
+      const int f = flags[node] & FLAG_NEUMANN;
+      nflag[row] = f;
+      any |= f;
+    }
+    tile_neu = __syncthreads_or(any) != 0;   // (also the barrier in front of stage 2)
+  } else {
+    __syncthreads();
+  }
   if (tid >= n_t) return;
   const int64_t u = (int64_t)t0 + tid;
   const int lane = tid & 63;
@@ -481,7 +643,17 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const
   for (int p = 0; p < 5; ++p) Pj[p] = splat2(0.f);
   PHASE();
   mvf<D>(T + L::T_W1J_FR, x, Pj);
-  pass_rev<RS, D, 3 * D, SLOT_IN>(slots, nslots, lds, T + L::T_A_FR, -1.f, Pj, af);
+  v2f an[5];
+  if (MIXED && tile_neu) {
+    v2f Pjn[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) Pjn[p] = an[p] = splat2(0.f);
+    PHASE();
+    mvf<D>(W + tnofs + L::N_W1J, x, Pjn);
+    pass_rev_in_mixed<RS>(slots, nslots, lds, nflag, T + L::T_A_FR, W + tnofs + L::N_A, Pj, Pjn, af, an);
+  } else {
+    pass_rev<RS, D, 3 * D, SLOT_IN>(slots, nslots, lds, T + L::T_A_FR, -1.f, Pj, af);
+  }
   if (PG) {  // neighbour-side cotangent sums: W1j gradients are sum_u acc[u] (x) x[u]
     rec_group(rec + u * PGREC + 192, reinterpret_cast<const float*>(at), D);
     rec_group(rec + u * PGREC + 208, reinterpret_cast<const float*>(af), D);
@@ -497,6 +669,10 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const
   mvb<D>(Wto + L::PHI_W1, L::EIN, D, reinterpret_cast<const float*>(at), g);
   PHASE();
   mvb<D>(Wfr + L::PHI_W1, L::EIN, D, reinterpret_cast<const float*>(af), g);
+  if (MIXED && tile_neu) {
+    PHASE();
+    mvb<D>(W + L::phi_neu(nl) + L::PHI_W1, L::EIN, D, reinterpret_cast<const float*>(an), g);
+  }
 #pragma unroll
   for (int p = 0; p < 5; ++p) {
     go[2 * p] = g[p].x;
@@ -506,37 +682,57 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const
 }
 
 // ---------------------------------------------------------------------------------------------- host
-static int tile_vjp_launch(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* w,
-                           float* out, float* work, float* rec, hipStream_t st) {
-  ARG_CHECK(p && p->tiled && !p->mixed && nl == 1, "tiled VJP: dirichlet single-layer plans only");
-  using L = WLayout<2>;
+static int tile_vjp_launch(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* nrm,
+                           const float* w, float* out, float* work, float* rec, hipStream_t st) {
+  ARG_CHECK(p && p->tiled && (p->mixed || nl == 1), "tiled VJP: single-layer dirichlet plans, mixed plans");
+  ARG_CHECK(!p->mixed || (nrm && !rec), "mixed plan: needs unit normals; no parameter-gradient records");
   const int chunk = (int)cdiv(p->n_tiles, 8);
   const unsigned grid = (unsigned)(chunk * 8);
-  const size_t lds_a = (size_t)p->max_rows * 20 * 4, lds_b = (size_t)p->max_rows * 40 * 4;
+  const size_t lds_b = (size_t)p->max_rows * (40 + (p->mixed ? 1 : 0)) * 4;
   ARG_CHECK(lds_b <= 160 * 1024, "tile + halo rows exceed the LDS budget of the tiled VJP");
-#define VJP_ARGS_A (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, \
-                   p->ell, p->flags_p, W, L::layer(0), L::tp_layer(nl, false, 0), h, prb, w, work, out, rec
-#define VJP_ARGS_B (int)p->n_tiles, chunk, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, \
-                   p->ell, W, L::layer(0), L::tp_layer(nl, false, 0), h, work, out, rec
+#define VJP_PLAN p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell, p->flags_p
+  if (p->mixed) {
+    using L = WLayout<3>;
+    const int lofs = L::layer(nl - 1), tofs = L::tp_layer(nl, true, nl - 1), tnofs = L::tp_neu(nl);
+    const int na = (int)p->n_tiles_plain, nb = (int)(p->n_tiles - p->n_tiles_plain);
+    if (na > 0) {   // tiles without Neumann nodes of their own
+      const int ch = (int)cdiv(na, 8);
+      LAUNCH("k_vjp_tile_a", st, (k_vjp_tile_a<3, false, false><<<(unsigned)(ch * 8), VT, (size_t)p->max_rows * 20 * 4, st>>>(
+          na, ch, p->tile_order, VJP_PLAN, W, nl, lofs, tofs, tnofs, h, prb, nrm, w, work, out, rec)));
+    }
+    if (nb > 0) {
+      const int ch = (int)cdiv(nb, 8);
+      LAUNCH("k_vjp_tile_a", st, (k_vjp_tile_a<3, true, false><<<(unsigned)(ch * 8), VT, (size_t)p->max_rows * 32 * 4, st>>>(
+          nb, ch, p->tile_order + na, VJP_PLAN, W, nl, lofs, tofs, tnofs, h, prb, nrm, w, work, out, rec)));
+    }
+    LAUNCH("k_vjp_tile_b", st, (k_vjp_tile_b<3, true, false><<<grid, VT, lds_b, st>>>(
+        (int)p->n_tiles, chunk, VJP_PLAN, W, nl, lofs, tofs, tnofs, h, work, out, rec)));
+    HIP_TRY(hipGetLastError());
+    return PSIGNN_OK;
+  }
+  using L = WLayout<2>;
+  const size_t lds_a = (size_t)p->max_rows * 20 * 4;
+#define VJP_ARGS_A (int)p->n_tiles, chunk, nullptr, VJP_PLAN, W, nl, L::layer(0), L::tp_layer(nl, false, 0), 0, h, prb, nrm, w, work, out, rec
+#define VJP_ARGS_B (int)p->n_tiles, chunk, VJP_PLAN, W, nl, L::layer(0), L::tp_layer(nl, false, 0), 0, h, work, out, rec
   if (rec) {
-    LAUNCH("k_pgrad_tile_a", st, (k_vjp_tile_a<2, true><<<grid, VT, lds_a, st>>>(VJP_ARGS_A)));
-    LAUNCH("k_pgrad_tile_b", st, (k_vjp_tile_b<2, true><<<grid, VT, lds_b, st>>>(VJP_ARGS_B)));
+    LAUNCH("k_pgrad_tile_a", st, (k_vjp_tile_a<2, false, true><<<grid, VT, lds_a, st>>>(VJP_ARGS_A)));
+    LAUNCH("k_pgrad_tile_b", st, (k_vjp_tile_b<2, false, true><<<grid, VT, lds_b, st>>>(VJP_ARGS_B)));
   } else {
-    LAUNCH("k_vjp_tile_a", st, (k_vjp_tile_a<2, false><<<grid, VT, lds_a, st>>>(VJP_ARGS_A)));
-    LAUNCH("k_vjp_tile_b", st, (k_vjp_tile_b<2, false><<<grid, VT, lds_b, st>>>(VJP_ARGS_B)));
+    LAUNCH("k_vjp_tile_a", st, (k_vjp_tile_a<2, false, false><<<grid, VT, lds_a, st>>>(VJP_ARGS_A)));
+    LAUNCH("k_vjp_tile_b", st, (k_vjp_tile_b<2, false, false><<<grid, VT, lds_b, st>>>(VJP_ARGS_B)));
   }
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }
 
-// h, prb, w, out in PLAN order; work: (N, 40) floats for B.
-int psignn_f_tile_vjp(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* w,
-                      float* out, float* work, hipStream_t st) {
-  return tile_vjp_launch(p, W, nl, h, prb, w, out, work, nullptr, st);
+// h, prb, nrm (mixed plans), w, out in PLAN order; work: (N, 40) floats for B.
+int psignn_f_tile_vjp(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* nrm,
+                      const float* w, float* out, float* work, hipStream_t st) {
+  return tile_vjp_launch(p, W, nl, h, prb, nrm, w, out, work, nullptr, st);
 }
-// same, additionally filling the parameter-gradient records rec: (N, PGREC) floats (fgnn_pgrad.hip)
+// same, additionally filling the parameter-gradient records rec: (N, PGREC) floats (fgnn_pgrad.hip; dirichlet family)
 int psignn_f_tile_vjp_rec(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* w,
                           float* out, float* work, float* rec, hipStream_t st) {
   ARG_CHECK(rec, "NULL record buffer");
-  return tile_vjp_launch(p, W, nl, h, prb, w, out, work, rec, st);
+  return tile_vjp_launch(p, W, nl, h, prb, nullptr, w, out, work, rec, st);
 }

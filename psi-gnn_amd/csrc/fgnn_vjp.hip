@@ -21,6 +21,8 @@
 // (mixed/psignn/model.py:236,241), so its cotangent flows through that branch only (Phi_neumann is of the
 // Phi_from type: out-edges of n; pass 2 adds acc_n over u's in-edges).
 #include "fgnn_common.h"
+#include <string.h>
+#include <stdlib.h>
 
 // The kernels below read ~1 500 wave-uniform weights.  Fully unrolled, the compiler hoists all their scalar loads to
 // the top and then spills > 1 000 SGPRs into VGPR lanes; in the record-writing (PG) instantiation of the mixed family
@@ -579,7 +581,7 @@ int psignn_f_gather_vjp_rec(const psignn_plan* p, const float* W, int nl, const 
   return PSIGNN_OK;
 }
 
-int psignn_f_tile_vjp(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* w,
+int psignn_f_tile_vjp(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* nrm, const float* w,
                       float* out, float* work, hipStream_t st);
 
 // plan-order VJP: tiled kernels where the plan has tiles (dirichlet, single layer), gather kernels otherwise
@@ -587,8 +589,8 @@ extern "C" int psignn_f_vjp_p(const psignn_plan_t* p, const float* W, int nl, co
                               const float* nrm, const float* w, float* out, float* work, void* stream) {
   ARG_CHECK(p && W && h && prb && w && out && work, "NULL argument");
   ARG_CHECK(out != w && out != h, "out must not alias its inputs");
-  if (p->tiled && !p->mixed && nl == 1) return psignn_f_tile_vjp(p, W, nl, h, prb, w, out, work, (hipStream_t)stream);
-  ARG_CHECK(!p->tiled, "plan-order VJP of a tiled mixed / multi-layer plan is not available: use psignn_f_vjp");
+  if (p->tiled && (p->mixed || nl == 1)) return psignn_f_tile_vjp(p, W, nl, h, prb, nrm, w, out, work, (hipStream_t)stream);
+  ARG_CHECK(!p->tiled, "plan-order VJP of a tiled multi-layer dirichlet plan is not available");
   return psignn_f_vjp(p, W, nl, h, prb, nrm, w, out, work, stream);
 }
 
@@ -599,19 +601,23 @@ extern "C" int psignn_f_vjp(const psignn_plan_t* p, const float* W, int nl, cons
   ARG_CHECK(!p->mixed || nrm, "mixed plan needs unit normals");
   ARG_CHECK(out != w && out != h, "out must not alias its inputs");
   hipStream_t st = (hipStream_t)stream;
-  if (p->tiled && !p->mixed && nl == 1) {
+  static const bool mixed_tiled = [] { const char* e = getenv("PSIGNN_MIXED_VJP"); return !(e && strcmp(e, "gather") == 0); }();
+  if (p->tiled && (p->mixed ? mixed_tiled : nl == 1)) {
     // caller numbering -> plan order -> tiled kernels -> caller numbering
     const int64_t N = p->N;
+    const int P = p->mixed ? 3 : 2;
     float* Bw = work;                 // (N, 40)
     float* hp = Bw + N * 4 * D;
     float* wp = hp + N * D;
     float* op = wp + N * D;
-    float* pp = op + N * D;           // (N, 2)
+    float* pp = op + N * D;           // (N, P)
+    float* np = pp + N * 3;           // (N, 2) unit normals of a mixed plan
     int rc;
     if ((rc = psignn_plan_permute(p, h, D, hp, 1, stream))) return rc;
     if ((rc = psignn_plan_permute(p, w, D, wp, 1, stream))) return rc;
-    if ((rc = psignn_plan_permute(p, prb, 2, pp, 1, stream))) return rc;
-    if ((rc = psignn_f_tile_vjp(p, W, nl, hp, pp, wp, op, Bw, st))) return rc;
+    if ((rc = psignn_plan_permute(p, prb, P, pp, 1, stream))) return rc;
+    if (p->mixed && (rc = psignn_plan_permute(p, nrm, 2, np, 1, stream))) return rc;
+    if ((rc = psignn_f_tile_vjp(p, W, nl, hp, pp, p->mixed ? np : nullptr, wp, op, Bw, st))) return rc;
     return psignn_plan_permute(p, op, D, out, 0, stream);
   }
   if (p->mixed)

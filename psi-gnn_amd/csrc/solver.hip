@@ -991,8 +991,9 @@ extern "C" int psignn_broyden_solve_adjoint(psignn_broyden_t* s, const float* W,
   ARG_CHECK(W && h_star && prb && grad, "NULL argument");
   hipStream_t st = (hipStream_t)stream;
   const psignn_plan* p = s->plan;
-  // tiled dirichlet plans: the whole solve in plan order on the tiled VJP kernels; otherwise the caller's numbering
-  const bool tiled = p->tiled && !p->mixed && nl == 1;
+  // tiled plans the tiled VJP covers (single-layer dirichlet, mixed): the whole solve in plan order; otherwise the caller's numbering
+  const bool tiled = p->tiled && (p->mixed || nl == 1);
+  ARG_CHECK(!p->mixed || nrm, "mixed plan needs unit normals");
   s->plan_order = tiled ? 1 : 0;
   if (poll_every <= 0) poll_every = 8;
   unsigned g = (unsigned)s->nblk;
@@ -1002,7 +1003,11 @@ extern "C" int psignn_broyden_solve_adjoint(psignn_broyden_t* s, const float* W,
     float* gr_p = hs_p + p->N * D;
     if ((rc = psignn_plan_permute(p, h_star, D, hs_p, 1, st))) return rc;
     if ((rc = psignn_plan_permute(p, grad, D, gr_p, 1, st))) return rc;
-    if ((rc = psignn_plan_permute(p, prb, 2, s->prbp, 1, st))) return rc;
+    if ((rc = psignn_plan_permute(p, prb, p->mixed ? 3 : 2, s->prbp, 1, st))) return rc;
+    if (p->mixed) {
+      if ((rc = psignn_plan_permute(p, nrm, 2, s->nrmp, 1, st))) return rc;
+      nrm = s->nrmp;
+    }
     h_star = hs_p;
     grad = gr_p;
     prb = s->prbp;

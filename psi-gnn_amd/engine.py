@@ -336,11 +336,11 @@ class FixedPointMap:
         return out
 
     def jvp_p(self, Hp, Vp, out=None):
-        """J_f(Hp) Vp with everything in plan order (tiled single-layer dirichlet plans).  ``out``: a contiguous (N, d)
-        float32 tensor to write into (e.g. a row of a Krylov basis)."""
+        """J_f(Hp) Vp with everything in plan order (tiled plans: single-layer dirichlet, mixed of any depth).  ``out``: a
+        contiguous (N, d) float32 tensor to write into (e.g. a row of a Krylov basis)."""
         if self._p is None:
             self.fp(Hp)
-        _, prbp, _ = self._p
+        _, prbp, nrmp = self._p
         Hc, Vc = _f32c(Hp), _f32c(Vp)
         if out is None:
             out = torch.empty_like(Hc)
@@ -348,7 +348,7 @@ class FixedPointMap:
             raise nat.NativeError("jvp_p: out must be a contiguous float32 tensor of the state's size")
         with torch.cuda.device(Hc.device):
             nat.check(nat.lib().psignn_f_jvp_p(self.plan.handle, nat.ptr(self.weights.flat), self.weights.n_layers,
-                                               nat.ptr(Hc), nat.ptr(prbp), nat.ptr(Vc), nat.ptr(out),
+                                               nat.ptr(Hc), nat.ptr(prbp), nat.ptr(nrmp), nat.ptr(Vc), nat.ptr(out),
                                                nat.stream_ptr(Hc.device)), "psignn_f_jvp_p")
         return out
 
@@ -364,7 +364,7 @@ class FixedPointMap:
         return out
 
     def vjp_p(self, Hp, Wp):
-        """vjp with Hp, Wp and the result in plan order (tiled kernels on a tiled single-layer dirichlet plan)."""
+        """vjp with Hp, Wp and the result in plan order (tiled kernels: single-layer dirichlet plans, mixed plans)."""
         if self._p is None:
             self.fp(Hp)
         _, prbp, nrmp = self._p

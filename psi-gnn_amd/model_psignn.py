@@ -279,7 +279,7 @@ class DeepEquilibrium(nn.Module):
     def _vjp_in_plan_order(fmap, H_star):
         """(vjp, to_plan, from_plan) working in plan order where the tiled VJP applies (saves the four permutation
         passes of the caller-order entry point per product; norms and inner products do not depend on the numbering)."""
-        if fmap.plan.tiled and not fmap.weights.mixed and fmap.weights.n_layers == 1:
+        if fmap.plan.tiled and (fmap.weights.mixed or fmap.weights.n_layers == 1):
             Hp = fmap.to_plan(H_star)
             return (lambda w: fmap.vjp_p(Hp, w)), fmap.to_plan, fmap.from_plan
         ident = lambda t: t

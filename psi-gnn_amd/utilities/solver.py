@@ -242,8 +242,9 @@ def newton_krylov(f, x0, threshold=30, eps=1e-5, inner_m=200, inner_tol=1e-2, ma
     if not isinstance(f, FixedPointMap):
         raise nat.NativeError("newton_krylov needs the analytic JVP of a FixedPointMap")
     nat.require_cuda(x0, "x0")
-    if not (f.plan.tiled and not f.weights.mixed and f.weights.n_layers == 1):
-        raise nat.NativeError("newton_krylov runs on tiled single-layer dirichlet plans (the tiled JVP kernel)")
+    if not (f.plan.tiled and (f.weights.mixed or f.weights.n_layers == 1)):
+        raise nat.NativeError("newton_krylov runs on tiled plans whose block the tiled JVP kernel covers "
+                              "(single-layer dirichlet; mixed of any depth)")
     from ..engine import DeviceGmres
     shape = x0.shape
     n_feval = 0

@@ -48,6 +48,19 @@ def test_config2_mixed_100k(dev):
     assert len(d_idx) > 100 and len(n_idx) > 100
     assert torch.equal(got1.cpu()[d_idx], h0[d_idx])
     assert rel_l2(got1.cpu()[n_idx], want1[n_idx]) < 2e-6
+    # tiled mixed JVP (interior rows and the Neumann rows' third slot walk) against the oracle's autograd JVP at this size
+    v = torch.randn(mesh.num_nodes, 10, generator=torch.Generator().manual_seed(7))
+    jv_ref = orc.function_jvp(sd, want1, h0, mesh, v)
+    jv = fm.jvp(want1.to(dev), v.to(dev))
+    assert rel_l2(jv, jv_ref) < 1e-5, rel_l2(jv, jv_ref)
+    assert rel_l2(jv.cpu()[n_idx], jv_ref[n_idx]) < 1e-5 and torch.count_nonzero(jv.cpu()[d_idx]) == 0
+    # tiled mixed VJP against the oracle's autograd VJP, and <w, J v> == <J^T w, v> between the two kernels
+    wv = torch.randn(mesh.num_nodes, 10, generator=torch.Generator().manual_seed(8))
+    vj_ref = orc.function_vjp(sd, want1, h0, mesh, wv)
+    vj = fm.vjp(want1.to(dev), wv.to(dev))
+    assert rel_l2(vj, vj_ref) < 2e-5, rel_l2(vj, vj_ref)
+    lhs, rhs = float((wv.double() * jv.cpu().double()).sum()), float((vj.cpu().double() * v.double()).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
     # full on-device Broyden: K = 12 iterations against the oracle's solver on the same mesh
     K = 12
     with torch.no_grad():

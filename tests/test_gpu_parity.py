@@ -620,6 +620,17 @@ def test_newton_krylov_with_analytic_jvp(dev):
     assert set(solver.broyden(fmap, fmap.h0, threshold=5, eps=1e-3)) >= {"result", "lowest", "nstep", "rel_trace"}
 
 
+def test_newton_krylov_mixed_family(dev):
+    """Newton-Krylov on the mixed family (Dirichlet + Neumann rows): the tiled JVP's Neumann branch is the operator of
+    every Krylov step; the result meets the fp64 fixed point of the fixture like Broyden's does."""
+    g, mesh, md, sd, fmap = bind("hex13_mixed_s1", dev)
+    solver = pkg("utilities.solver")
+    out = solver.newton_krylov(fmap, fmap.h0, threshold=40, eps=5e-7, inner_m=80, warm_start=30)
+    print("hex13 mixed NK: lowest", out["lowest"], "outer", out["n_outer"], "n_feval", out["n_feval"])
+    assert out["lowest"] < 1e-6, out["lowest"]
+    assert rel_l2(out["result"], g["fp64_result"]) < 1e-5
+
+
 def test_device_gmres_solves_a_known_linear_system(dev):
     """csrc/krylov.hip on its own: A = P - shift I with a dense P applied by torch, 700 unknowns (two blocks of the vector
     kernels, ragged tail), against torch.linalg.solve in float64; residual history monotone; early stop at eta."""
@@ -731,14 +742,17 @@ def test_vjp_parity(name, dev):
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
 
 
-@pytest.mark.parametrize("name", ["original_dirichlet_s0", "hex13_dirichlet_s0", "hex26_dirichlet_s0"])
+@pytest.mark.parametrize("name", ["original_dirichlet_s0", "hex13_dirichlet_s0", "hex26_dirichlet_s0", "hex13_mixed_s1"])
 def test_tiled_vjp_equals_gather_vjp(name, dev):
     """Tiled VJP (LDS-staged B rows, pair-merged slots) vs the global-gather VJP on an untiled plan of the same mesh;
-    plan-order entry point; several tile sizes; bitwise reproducible (no atomics)."""
+    plan-order entry point; several tile sizes; bitwise reproducible (no atomics).  Mixed family: Neumann rows send through
+    Phi_neumann's weights (pass B tells the sender's kind from the staged flags, also for halo rows of tiles that hold no
+    Neumann node themselves -- tile sizes 32/100 produce those)."""
     g, mesh, md, sd, fmap = bind(name, dev)
     eng = pkg("engine")
     assert fmap.plan.tiled
-    flat = eng.FixedPointMap(eng.MeshPlan(md, tile_target=-1), fmap.weights, fmap.h0, md.prb_data, None)
+    nrm = getattr(md, "unit_normal_vector", None)
+    flat = eng.FixedPointMap(eng.MeshPlan(md, tile_target=-1), fmap.weights, fmap.h0, md.prb_data, nrm)
     assert not flat.plan.tiled
     x = torch.from_numpy(g["f1"]).to(dev)
     w = torch.randn(x.shape, generator=torch.Generator().manual_seed(11)).to(dev)
@@ -750,8 +764,14 @@ def test_tiled_vjp_equals_gather_vjp(name, dev):
     assert torch.equal(fmap.from_plan(ap), a)
     assert torch.equal(a, fmap.vjp(x, w))
     for tt in (32, 100):
-        fm = eng.FixedPointMap(eng.MeshPlan(md, tile_target=tt), fmap.weights, fmap.h0, md.prb_data, None)
+        fm = eng.FixedPointMap(eng.MeshPlan(md, tile_target=tt), fmap.weights, fmap.h0, md.prb_data, nrm)
         assert rel_l2(fm.vjp(x, w), a) < 1e-6, tt
+    if fmap.weights.mixed:   # a cotangent on the Neumann rows alone: everything flows through the Neumann branch
+        neu = (mesh.tags[:, 2] == 1)
+        wn = torch.zeros_like(w)
+        wn[neu.to(dev)] = w[neu.to(dev)]
+        wantn = orc.function_vjp(sd, x.cpu(), torch.from_numpy(g["h0"]), mesh, wn.cpu())
+        assert float(wantn.norm()) > 0 and rel_l2(fmap.vjp(x, wn), wantn) < 2e-5
     # adjoint identity against the JVP kernel
     v = torch.randn(x.shape, generator=torch.Generator().manual_seed(12)).to(dev)
     lhs = float((w.double() * fmap.jvp(x, v).double()).sum())
@@ -759,13 +779,15 @@ def test_tiled_vjp_equals_gather_vjp(name, dev):
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
 
 
-@pytest.mark.parametrize("name", ["original_dirichlet_s0", "hex26_dirichlet_s0"])
+@pytest.mark.parametrize("name", ["original_dirichlet_s0", "hex26_dirichlet_s0", "hex13_mixed_s1"])
 def test_tiled_jvp_equals_gather_jvp(name, dev):
     """Tiled JVP (state and tangent rows staged in LDS) vs the global-gather JVP on an untiled plan and vs fp64 autograd;
-    plan-order entry point; other tile sizes."""
+    plan-order entry point; other tile sizes.  Mixed family: the Neumann rows' tangent (a third slot walk over the
+    Phi_neumann columns) and the two-group launch (tile sizes 32/100 give tiles with and without Neumann nodes)."""
     g, mesh, md, sd, fmap = bind(name, dev)
     eng = pkg("engine")
-    flat = eng.FixedPointMap(eng.MeshPlan(md, tile_target=-1), fmap.weights, fmap.h0, md.prb_data, None)
+    nrm = getattr(md, "unit_normal_vector", None)
+    flat = eng.FixedPointMap(eng.MeshPlan(md, tile_target=-1), fmap.weights, fmap.h0, md.prb_data, nrm)
     x = torch.from_numpy(g["f1"]).to(dev)
     v = torch.randn(x.shape, generator=torch.Generator().manual_seed(13)).to(dev)
     a, b = fmap.jvp(x, v), flat.jvp(x, v)
@@ -776,8 +798,13 @@ def test_tiled_jvp_equals_gather_jvp(name, dev):
     assert rel_l2(a, b) < 2e-6
     assert torch.equal(fmap.from_plan(fmap.jvp_p(fmap.to_plan(x), fmap.to_plan(v))), a)
     for tt in (32, 100):
-        fm = eng.FixedPointMap(eng.MeshPlan(md, tile_target=tt), fmap.weights, fmap.h0, md.prb_data, None)
+        fm = eng.FixedPointMap(eng.MeshPlan(md, tile_target=tt), fmap.weights, fmap.h0, md.prb_data, nrm)
         assert rel_l2(fm.jvp(x, v), a) < 1e-6, tt
+    if fmap.weights.mixed:   # Neumann and Dirichlet rows: tangent of a replaced row / of a constant row
+        tags = mesh.tags
+        assert torch.count_nonzero(a.cpu()[tags[:, 1] == 1]) == 0
+        neu = (tags[:, 2] == 1)
+        assert neu.any() and rel_l2(a.cpu()[neu], want[neu]) < 1e-5
 
 
 def test_implicit_backward_solve(dev):
@@ -827,6 +854,24 @@ def test_implicit_backward_solve(dev):
     ev2, rho2 = net.deqdss.power_method(h_star.to(dev), h0.to(dev), md, n_iters=40, v0=v0.to(dev))
     assert abs(float(rho2) - abs(float(val))) < 2e-4 * abs(float(val)), (float(rho2), float(val))
     assert min(rel_l2(ev2, evc), rel_l2(ev2, -evc)) < 5e-3
+
+
+def test_implicit_backward_solve_mixed(dev):
+    """Same adjoint solve on the mixed family (mixed/psignn/model.py:141-152 hook): plan-order device solve on the tiled
+    mixed VJP vs the oracle's VJP in the adjoint equation, and the two diagnostics on fixed probes."""
+    g, mesh, md, sd, fmap = bind("hex13_mixed_s1", dev)
+    h_star = torch.from_numpy(g["broyden_e7_result"])
+    h0 = torch.from_numpy(g["h0"])
+    grad = torch.randn(h_star.shape, generator=torch.Generator().manual_seed(9))
+    sv = pkg("engine").DeviceBroyden(fmap.plan, 600, keep_trace=False)
+    out = sv.solve_adjoint(fmap, h_star.to(dev), grad.to(dev), 1e-6)
+    assert out["lowest"] < 1e-6
+    y = out["result"]
+    r = orc.function_vjp(sd, h_star, h0, mesh, y.cpu()) + grad - y.cpu()
+    assert float(r.norm() / y.cpu().norm()) < 1e-4
+    ref = orc.broyden(lambda yy: orc.function_vjp(sd, h_star, h0, mesh, yy) + grad, torch.zeros_like(grad),
+                      threshold=600, eps=1e-6)
+    assert rel_l2(y, ref["result"]) < 1e-3
 
 
 def test_eval_harness_reference_protocol(dev):
