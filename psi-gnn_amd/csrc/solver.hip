@@ -519,6 +519,12 @@ static int broyden_alloc(psignn_broyden* s) {
   s->nblk = (int)cdiv(s->M, (int64_t)s->vec * TB);
   const int64_t eff_blk = cdiv(eff, (int64_t)s->vec * TB);
   s->jgroups = eff_blk >= 768 ? 1 : (int)std::min<int64_t>(8, cdiv(768, eff_blk));
+  // Shard of short vectors (8 x 50 k nodes: 123 blocks per mesh, 983 together): the chip is covered, but every block then walks
+  // all stored pairs alone; the dots pass split 4 ways over the pairs and the axpy pass unsplit at 4 floats per lane
+  // (3 930 blocks) measured 305 / 310 us against 325 / 313 us per launch (K = 100; profiles/r2_batch_sweep_ab.txt)
+  const bool short_shard = s->size_hint > s->M && s->vec == 16 && s->nblk < 512;
+  if (short_shard) s->jgroups = 4;
+  if (const char* e = getenv("PSIGNN_JGROUPS")) s->jgroups = std::max(1, std::min(8, atoi(e)));   // A/B knob
   s->npart = s->nblk * (TB / 64);
   // Mid-size vectors (16 floats per lane, but too few blocks to fill the chip): the dots pass is split over the stored
   // pairs (free: every pair's partial sums are independent), the axpy pass would need a combine launch after such a split
@@ -526,7 +532,9 @@ static int broyden_alloc(psignn_broyden* s) {
   // is per kernel; only the pair partials that k_final reads must follow the axpy pass's block count.
   s->vec_ax = s->vec;
   s->nblk_ax = s->nblk;
-  if (s->vec == 16 && s->jgroups > 1 && cdiv(s->M, (int64_t)4 * TB) >= 512) {
+  const char* e_ax = getenv("PSIGNN_VEC_AX4");   // A/B knob: 1 forces the 4-float unsplit axpy pass, 0 forbids it
+  if (e_ax ? (atoi(e_ax) != 0 && s->vec == 16)
+           : (s->vec == 16 && s->jgroups > 1 && (short_shard || cdiv(s->M, (int64_t)4 * TB) >= 512))) {
     s->vec_ax = 4;
     s->nblk_ax = (int)cdiv(s->M, (int64_t)4 * TB);
   }
