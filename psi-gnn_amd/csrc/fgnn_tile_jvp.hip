@@ -74,8 +74,16 @@ __device__ __forceinline__ float edge_pass_jvp(const uint4* __restrict__ slots, 
   return deg;
 }
 
+#ifndef JVP_WAVES
+#define JVP_WAVES 0   // > 0: hold the register allocator to this many waves per SIMD (A/B in DESIGN.md)
+#endif
+#if JVP_WAVES > 0
+#define JVP_OCC __attribute__((amdgpu_waves_per_eu(JVP_WAVES, JVP_WAVES)))
+#else
+#define JVP_OCC
+#endif
 template <int P, bool MIXED, bool MFMA1>
-__global__ __launch_bounds__(TILE_THREADS) void k_jvp_tile(int n_tiles, int chunk, const int32_t* __restrict__ tile_list,
+__global__ __launch_bounds__(TILE_THREADS) JVP_OCC void k_jvp_tile(int n_tiles, int chunk, const int32_t* __restrict__ tile_list,
                                                            const int32_t* __restrict__ tile_ptr,
                                                            const int32_t* __restrict__ tile_slice,
                                                            const int32_t* __restrict__ halo, const int32_t* __restrict__ halo_cnt,

@@ -156,8 +156,16 @@ __device__ __forceinline__ void ln_fwd_bwd(const float* __restrict__ W, float mu
   for (int o = 0; o < D; ++o) dy[o] = rs * (dyh[o] - m1 - y[o] * m2);
 }
 
+#ifndef VJPA_WAVES
+#define VJPA_WAVES 0   // > 0: hold the register allocator of pass A to this many waves per SIMD
+#endif
+#if VJPA_WAVES > 0
+#define VJPA_OCC __attribute__((amdgpu_waves_per_eu(VJPA_WAVES, VJPA_WAVES)))
+#else
+#define VJPA_OCC
+#endif
 template <int P, bool MIXED, bool PG>
-__global__ __launch_bounds__(VT) void k_vjp_tile_a(int n_tiles, int chunk, const int32_t* __restrict__ tile_list,
+__global__ __launch_bounds__(VT) VJPA_OCC void k_vjp_tile_a(int n_tiles, int chunk, const int32_t* __restrict__ tile_list,
                                                    const int32_t* __restrict__ tile_ptr,
                                                    const int32_t* __restrict__ tile_slice, const int32_t* __restrict__ halo,
                                                    const int32_t* __restrict__ halo_cnt, const int32_t* __restrict__ slice_off,
