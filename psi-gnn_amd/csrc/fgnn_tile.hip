@@ -122,10 +122,22 @@ struct FuseArgs {
 static long long* g_tile_stamps = nullptr;
 extern "C" void psignn_prof_tile_stamps(void* d_buf) { g_tile_stamps = (long long*)d_buf; }
 
+// wave sum of the fused epilogue's norm partials: DPP adds inside the rows of 16, row sums through v_readlane (vec_helpers.h)
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_perm_f<0xB1>(v);
+  v += dpp_perm_f<0x4E>(v);
+  v += dpp_perm_f<0x141>(v);
+  v += dpp_perm_f<0x140>(v);
+  const int vi = __builtin_bit_cast(int, v);   // (the builtin is typed int: a float argument would be converted by value)
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 // One tile: body of k_f_tile.  `slot` = position in the launch's tile list.  Every thread of the workgroup reaches the

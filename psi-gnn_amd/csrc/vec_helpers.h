@@ -7,10 +7,34 @@
 // the grid still covers the 256 CUs; chosen at solver creation).
 #define TB 256           // threads per block
 
+// Sum over the 64 lanes of a wave, the same value in every lane, fixed association (bitwise reproducible):
+// quad pairs, quads, half rows, rows of 16 as DPP operands of the adds (no LDS-path permutes), then the four row sums
+// through v_readlane.  The xor-shuffle form (`__shfl_xor` = ds_bpermute_b32, six dependent LDS round trips per value) held the
+// dots pass 10 % behind the axpy pass; -DWAVE_SUM_SHFL=1 rebuilds it for A/B runs.
+#ifndef WAVE_SUM_SHFL
+#define WAVE_SUM_SHFL 0
+#endif
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
+#if WAVE_SUM_SHFL
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
+#else
+  v += dpp_perm<0xB1>(v);    // quad_perm:[1,0,3,2]
+  v += dpp_perm<0x4E>(v);    // quad_perm:[2,3,0,1]
+  v += dpp_perm<0x141>(v);   // row_half_mirror
+  v += dpp_perm<0x140>(v);   // row_mirror: every lane of a row of 16 holds the row's sum
+  const int vi = __builtin_bit_cast(int, v);   // (the builtin is typed int: a float argument would be converted by value)
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+  return (r0 + r1) + (r2 + r3);
+#endif
 }
 
 // Two per-lane values -> ONE pair per block (wave shuffles, then the 4 wave sums through LDS, fixed order).
