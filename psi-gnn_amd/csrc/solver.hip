@@ -236,6 +236,9 @@ __device__ void check_block(Status* st, const float* __restrict__ part, int npar
   }
 }
 
+#ifndef DOTS_PART4
+#define DOTS_PART4 1   // layout of the dots partials (A/B in profiles/r2_batch_sweep_ab.txt)
+#endif
 // dots pass: per-wave partials of a_j = dx.U_j, c_j = V_j.dg, b_j = V_j.g   for j < k
 template <int VEC>
 __device__ __forceinline__ void dots_body(int64_t M, int k, const Status* __restrict__ st,
@@ -278,9 +281,13 @@ __device__ __forceinline__ void dots_body(int64_t M, int k, const Status* __rest
     sc = wave_sum(sc);
     sb = wave_sum(sb);
     if (lead) {
+#if DOTS_PART4   // one 16-byte store per wave and stored pair: {a, c, b, -} of wave w at part[(j * npart + w) * 4]
+      *reinterpret_cast<float4*>(part + ((int64_t)j * npart + w) * 4) = make_float4(sa, sc, sb, 0.f);
+#else
       part[((int64_t)0 * thr + j) * npart + w] = sa;
       part[((int64_t)1 * thr + j) * npart + w] = sc;
       part[((int64_t)2 * thr + j) * npart + w] = sb;
+#endif
     }
   }
 }
@@ -309,7 +316,11 @@ __device__ __forceinline__ void reduce_check_body(Status* st, const float* __res
   if (st->done) return;
   int j = blockIdx.x, c = blockIdx.y;
   if (j >= k) return;
+#if DOTS_PART4
+  double s = block_sum_partials<4>(part + (int64_t)j * npart * 4 + c, npart, sh);
+#else
   double s = block_sum_partials(part + ((int64_t)c * thr + j) * npart, npart, sh);
+#endif
   if (threadIdx.x == 0) coef[c * thr + j] = (float)s;
 }
 __global__ __launch_bounds__(TB) void k_reduce_check(Status* st, const float* __restrict__ part, int npart, int thr, int k,
@@ -545,7 +556,7 @@ static int broyden_alloc(psignn_broyden* s) {
   struct { void** p; size_t n; } allocs[] = {
       {(void**)&s->U, thr * ld * 4},  {(void**)&s->V, thr * ld * 4},   {(void**)&s->xbuf, nx * M * 4},
       {(void**)&s->gx, M * 4},        {(void**)&s->dg, M * 4},        {(void**)&s->upd, M * 4},
-      {(void**)&s->fx, M * 4},        {(void**)&s->part, 3 * thr * (size_t)s->npart * 4 + 16},
+      {(void**)&s->fx, M * 4},        {(void**)&s->part, 4 * thr * (size_t)s->npart * 4 + 16},
       {(void**)&s->coef, 3 * thr * 4 + 16}, {(void**)&s->st, sizeof(Status)},
       {(void**)&s->nrm_part, 2 * (size_t)s->nn_cap * 4 + 16},
       {(void**)&s->rel_trace, thr * 8 + 8}, {(void**)&s->abs_trace, thr * 8 + 8}};

@@ -112,16 +112,17 @@ __device__ __forceinline__ void stv(float* __restrict__ p, int64_t e0, int64_t M
   }
 }
 
+template <int STRIDE = 1>
 __device__ inline double block_sum_partials(const float* __restrict__ p, int n, double* sh) {
   // fixed summation shape (lane-strided, 4 independent accumulators, then a tree): reproducible, and the
   // loads of one lane do not wait on each other (a dependent scalar loop here cost 20-30 us per call)
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   int i = threadIdx.x;
   for (; i + 3 * TB < n; i += 4 * TB) {
-    float a = p[i], b = p[i + TB], c = p[i + 2 * TB], d = p[i + 3 * TB];
+    float a = p[(int64_t)i * STRIDE], b = p[(int64_t)(i + TB) * STRIDE], c = p[(int64_t)(i + 2 * TB) * STRIDE], d = p[(int64_t)(i + 3 * TB) * STRIDE];
     s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
   }
-  for (; i < n; i += TB) s0 += (double)p[i];
+  for (; i < n; i += TB) s0 += (double)p[(int64_t)i * STRIDE];
   double s = (s0 + s1) + (s2 + s3);
   sh[threadIdx.x] = s;
   __syncthreads();
