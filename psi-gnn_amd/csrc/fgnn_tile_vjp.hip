@@ -550,6 +550,28 @@ __device__ __forceinline__ void pass_rev(const uint4* __restrict__ slots, int ns
 
 // IN slots of a mixed plan: the sender n of edge (n -> u) is an interior row (Phi_from: weights AF, projection Pjf, sum af) or
 // a Neumann row (Phi_neumann: AN, Pjn, an) -- nflag[row] tells; both kinds keep Pi at row[10..] and dS at row[30..].
+// one IN slot seen from the receiver: acc[o] += 1[row[10 + o] + Pj[o] + AT . (-a0, -a1, a2) > 0] * row[30 + o]
+__device__ __forceinline__ void rev_slot_in(const float* __restrict__ row, const float* __restrict__ AT, const uint4& c, const v2f* Pj,
+                                            v2f* acc) {
+  const v2f* wa = reinterpret_cast<const v2f*>(AT);   // wave-uniform address: the weights stay in scalar registers
+  const v2f a0 = splat2(-__uint_as_float(c.y)), a1 = splat2(-__uint_as_float(c.z)), a2 = splat2(__uint_as_float(c.w));
+  v2f pi[5], ds[5], z[5];
+  row10u(row + D, pi);
+  row10u(row + 3 * D, ds);
+#pragma unroll
+  for (int p = 0; p < 5; ++p) z[p] = pi[p] + Pj[p];
+#pragma unroll
+  for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[p], a0, z[p]);
+#pragma unroll
+  for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[5 + p], a1, z[p]);
+#pragma unroll
+  for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[10 + p], a2, z[p]);
+#pragma unroll
+  for (int p = 0; p < 5; ++p) acc[p] += (v2f){z[p].x > 0.f ? ds[p].x : 0.f, z[p].y > 0.f ? ds[p].y : 0.f};
+}
+
+// IN slots of a mixed plan: the sender n of edge (n -> u) is an interior row (Phi_from: weights AF, projection Pjf, sum af) or
+// a Neumann row (Phi_neumann: AN, Pjn, an) -- nflag[row] tells; both kinds keep Pi at row[10..] and dS at row[30..].
 template <int RS>
 __device__ __forceinline__ void pass_rev_in_mixed(const uint4* __restrict__ slots, int nslots, const float* __restrict__ lds,
                                                   const int32_t* __restrict__ nflag, const float* __restrict__ AF,
@@ -563,27 +585,9 @@ __device__ __forceinline__ void pass_rev_in_mixed(const uint4* __restrict__ slot
     const unsigned w = c0.x;
     if ((w & 0xFFFFu) != ELL_EMPTY && (w & SLOT_IN)) {
       const int ri = (int)(w & 0xFFFFu);
-      const bool neu = nflag[ri] != 0;
-      const v2f a0 = splat2(-__uint_as_float(c0.y)), a1 = splat2(-__uint_as_float(c0.z));
-      const v2f a2 = splat2(__uint_as_float(c0.w));
       const float* row = lds + ri * RS;
-      const v2f* wa = reinterpret_cast<const v2f*>(neu ? AN : AF);
-      v2f pi[5], ds[5], z[5];
-      row10u(row + D, pi);
-      row10u(row + 3 * D, ds);
-#pragma unroll
-      for (int p = 0; p < 5; ++p) z[p] = pi[p] + (neu ? Pjn[p] : Pjf[p]);
-#pragma unroll
-      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[p], a0, z[p]);
-#pragma unroll
-      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[5 + p], a1, z[p]);
-#pragma unroll
-      for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(wa[10 + p], a2, z[p]);
-#pragma unroll
-      for (int p = 0; p < 5; ++p) {
-        const v2f t = (v2f){z[p].x > 0.f ? ds[p].x : 0.f, z[p].y > 0.f ? ds[p].y : 0.f};
-        if (neu) an[p] += t; else af[p] += t;
-      }
+      if (nflag[ri] != 0) rev_slot_in(row, AN, c0, Pjn, an);   // (rare: boundary rows only)
+      else rev_slot_in(row, AF, c0, Pjf, af);
     }
     c0 = c1;
     c1 = nx;

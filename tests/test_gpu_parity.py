@@ -175,6 +175,17 @@ def test_mixed_multi_layer_quirk(dev):
     with torch.no_grad():
         want = orc.function_forward(sd, h.clone(), h0, mesh)
     assert rel_l2(got, want) < 3e-6
+    # the tiled JVP / VJP of a two-layer mixed block = those of its last layer at the ORIGINAL h (weights of layer 1, Phi_neumann)
+    eng = pkg("engine")
+    md = mesh.to(dev)
+    fm = eng.FixedPointMap(eng.plan_for(md), eng.PackedWeights(sd, dev), h0.to(dev), md.prb_data, md.unit_normal_vector)
+    assert fm.plan.tiled and fm.weights.n_layers == 2
+    gen = torch.Generator().manual_seed(16)
+    v, w = torch.randn(h.shape, generator=gen), torch.randn(h.shape, generator=gen)
+    jv, wj = fm.jvp(h.to(dev), v.to(dev)), fm.vjp(h.to(dev), w.to(dev))
+    assert rel_l2(jv, orc.function_jvp(sd, h, h0, mesh, v)) < 1e-5
+    assert rel_l2(wj, orc.function_vjp(sd, h, h0, mesh, w)) < 2e-5
+    assert torch.equal(fm.from_plan(fm.jvp_p(fm.to_plan(h.to(dev)), fm.to_plan(v.to(dev)))), jv)
 
 
 # ------------------------------------------------------------------------------------------ JVP
