@@ -21,6 +21,11 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # the ctypes table binds exactly the declared functions
     assert set(nat.SIGNATURES) == declared
+    # ... with as many arguments as the header declares (a drifted signature would corrupt the call silently)
+    for name, params in re.findall(r"\b(psignn_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", hdr):
+        params = params.strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert len(nat.SIGNATURES[name][1]) == n, (name, n, len(nat.SIGNATURES[name][1]))
 
 
 def test_pure_host_entry_points():
