@@ -15,7 +15,12 @@
 #ifndef TILE_WPE
 #define TILE_WPE 0    // > 0: __attribute__((amdgpu_waves_per_eu(TILE_WPE, TILE_WPE))) on k_f_tile: the register allocator is held to 96 VGPRs (5 waves per SIMD)
 #endif
-#if TILE_WPE
+#ifndef FUSED_WPE
+#define FUSED_WPE 0   // > 0: the FUSED instantiations only are held to this many waves per SIMD (6 = 80 VGPRs; they need 83 - 86)
+#endif
+#if FUSED_WPE
+#define TILE_WPE_ATTR __attribute__((amdgpu_waves_per_eu(FUSED ? FUSED_WPE : 1, FUSED ? FUSED_WPE : 8)))
+#elif TILE_WPE
 #define TILE_WPE_ATTR __attribute__((amdgpu_waves_per_eu(TILE_WPE, TILE_WPE)))
 #else
 #define TILE_WPE_ATTR
