@@ -687,8 +687,16 @@ static unsigned tile_grid(int chunk);
 // tile_base[m] + n_tiles[m])); a workgroup looks its slot's mesh up, loads that mesh's pointers from its descriptor and runs
 // the same tile body as the single-mesh kernel -- same arithmetic per node, same per-tile norm partials.  A mesh whose stop
 // test has fired is skipped tile by tile.
+#ifndef BATCH_WPE
+#define BATCH_WPE 0   // > 0: the batched fused kernel is held to this many waves per SIMD (A/B in profiles/r2_f_tile_ab_runs.txt)
+#endif
+#if BATCH_WPE
+#define BATCH_WPE_ATTR __attribute__((amdgpu_waves_per_eu(BATCH_WPE, BATCH_WPE)))
+#else
+#define BATCH_WPE_ATTR
+#endif
 template <int P>
-__global__ __launch_bounds__(TILE_THREADS) void k_f_tile_batch(const BatchDesc* __restrict__ descs, int n_mesh, int n_slots, int chunk,
+__global__ __launch_bounds__(TILE_THREADS) BATCH_WPE_ATTR void k_f_tile_batch(const BatchDesc* __restrict__ descs, int n_mesh, int n_slots, int chunk,
                                                               int off_done, int off_cur, int off_nxt,
                                                               const float* __restrict__ W, int lofs, int tofs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
