@@ -29,6 +29,7 @@ One JSON line on stdout (rank 0).  Extra objects:
                 the kernel north_star's 60 % target is about
   f_only        plain f (k_f_tile), 100 back-to-back evaluations: us per evaluation, edges/s, fraction of the HBM peak
   roofline_jvp  the analytic JVP kernel of the Newton-Krylov path (k_jvp_tile), 50 back-to-back products
+  newton_krylov one inner solve of that path: 30 Arnoldi steps of the device GMRES around the JVP (time, bytes, fraction of the peak)
   roofline_iter whole-iteration algorithmic bytes / un-instrumented wall time
   cpu_baseline  the CPU oracle (port of the reference path) timed on this box's host cores on a bounded sample
 """
@@ -380,6 +381,29 @@ def main():
                                       "traffic": None, "avg_launch_us": us_j, "alg_bytes_per_launch": per_launch["jvp"],
                                       "note": "analytic J_f(x) v of the Newton-Krylov path (BASELINE configs[4]); 50 back-to-back "
                                               "products, HIP events on the launch stream (includes the host's launch overhead)"}
+            # one inner solve of that path: m Arnoldi steps of the device GMRES (csrc/krylov.hip) on (J - I) dx = -g at this
+            # iterate -- step j = one JVP + classical Gram-Schmidt twice against j + 1 basis vectors (4 (j + 1) sweeps of M floats)
+            m_nk = 30
+            gm = eng.DeviceGmres(xp.numel(), dev, m_nk)
+            neg_g = torch.empty_like(xp)
+            gm.residual_norms(xp, fmap.fp(xp), neg_g=neg_g)
+
+            def arnoldi():
+                gm.begin(neg_g)
+                for j in range(m_nk):
+                    fmap.jvp_p(xp, gm.row(j, xp.shape), out=gm.row(j + 1, xp.shape))
+                    gm.step(j, 1.0, 0.0, poll=False)
+            us_nk = timed(arnoldi, 3)
+            hist = gm.history()
+            Mb = xp.numel() * 4
+            nk_bytes = sum(per_launch["jvp"] + (4 * (j + 1) + 3) * Mb for j in range(m_nk))
+            result["newton_krylov"] = {"arnoldi_steps": m_nk, "us_per_inner_solve": us_nk, "us_per_step_avg": us_nk / m_nk,
+                                       "alg_bytes": nk_bytes, "achieved": nk_bytes / us_nk * 1e-3, "unit": "GB/s",
+                                       "frac": nk_bytes / us_nk * 1e-3 / HBM_PEAK_GBS,
+                                       "linear_residual_after_m": float(hist[-1]) if len(hist) else None,
+                                       "note": "device GMRES without restarts around the analytic JVP, Hessenberg / Givens on the "
+                                               "device, no host synchronisation inside the m steps"}
+            gm.close()
     for sv in solvers:
         sv.close()
 
