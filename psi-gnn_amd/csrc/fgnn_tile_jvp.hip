@@ -82,6 +82,98 @@ __device__ __forceinline__ float edge_pass_jvp(const uint4* __restrict__ slots, 
 #else
 #define JVP_OCC
 #endif
+#ifndef JVP_XRELOAD
+#define JVP_XRELOAD 1
+#endif
+#ifndef JVP_BOTH
+#define JVP_BOTH 1    // interior rows: both directions in ONE slot walk, clamp form of the relu / of its mask (A/B in DESIGN.md)
+#endif
+__device__ __forceinline__ v2f pk_mul_clamp(v2f a, v2f b) {   // clamp(a * b, 0, 1)
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// Both directions of the neighbour sums and of their tangents in one walk over the pair-merged slots (the f kernel's
+// edge_pass_both_clamp plus the tangent): the 160-byte LDS row [Pj_to | Pj_fr | dPj_to | dPj_fr] of the neighbour is read once.
+// relu(z) = 2^40 clamp(2^-40 z) as there; the mask 1[z > 0] = clamp(2^126 * clamp(2^-40 z)) is a packed multiply instead of two
+// compares and two selects per pair (exact for |z| >= 2^-86; below that the f kernel's relu has already flushed the edge to 0
+// while this factor is a fraction -- a pre-activation that small does not occur on finite inputs of O(1) weights).
+template <int RS>
+__device__ __forceinline__ void edge_pass_jvp_both(const uint4* __restrict__ slots, int nslots, const float* __restrict__ lds,
+                                                   const float* __restrict__ AT_to, const float* __restrict__ AT_fr,
+                                                   const v2f* Pi_to, const v2f* dPi_to, const v2f* Pi_fr, const v2f* dPi_fr,
+                                                   v2f* S_to, v2f* dS_to, v2f* S_fr, v2f* dS_fr, float& deg_in, float& deg_out) {
+  v2f wt[15], wf[15], pt[5], pf[5];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) {
+    wt[i] = reinterpret_cast<const v2f*>(AT_to)[i];
+    wf[i] = reinterpret_cast<const v2f*>(AT_fr)[i];
+  }
+  const v2f sc = splat(RELU_SCALE), big = splat(8.507059173023462e37f);   // 2^-40, 2^126
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    pt[p] = Pi_to[p] * sc;
+    pf[p] = Pi_fr[p] * sc;
+  }
+  deg_in = deg_out = 0.f;
+  if (nslots <= 0) return;
+  uint4 c0 = slots[0];
+  for (int r = 0; r < nslots; ++r) {
+    const uint4 nx = slots[(int64_t)min(r + 1, nslots - 1) * 64];
+    const unsigned w = c0.x;
+    if ((w & 0xFFFFu) != ELL_EMPTY) {
+      const v2f a01 = (v2f){__uint_as_float(c0.y), __uint_as_float(c0.z)} * sc;
+      const v2f a2 = (v2f){__uint_as_float(c0.w) * RELU_SCALE, 0.f};
+      const float4* row = reinterpret_cast<const float4*>(lds + (int)(w & 0xFFFFu) * RS);
+      if (w & SLOT_IN) {
+        const float4 v0 = row[0], v1 = row[1], v2 = row[2], v5 = row[5], v6 = row[6], v7 = row[7];
+        v2f z[5] = {(v2f){v0.x, v0.y}, (v2f){v0.z, v0.w}, (v2f){v1.x, v1.y}, (v2f){v1.z, v1.w}, (v2f){v2.x, v2.y}};
+        const v2f d[5] = {(v2f){v5.x, v5.y}, (v2f){v5.z, v5.w}, (v2f){v6.x, v6.y}, (v2f){v6.z, v6.w}, (v2f){v7.x, v7.y}};
+        deg_in += 1.f;
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(z[p], sc, pt[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = pk_fma_lo(wt[p], a01, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = pk_fma_hi(wt[5 + p], a01, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = pk_fma_lo_clamp(wt[10 + p], a2, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+          S_to[p] += z[p];
+          dS_to[p] = __builtin_elementwise_fma(dPi_to[p] + d[p], pk_mul_clamp(z[p], big), dS_to[p]);
+        }
+      }
+      if (w & SLOT_OUT) {
+        const float4 v2 = row[2], v3 = row[3], v4 = row[4], v7 = row[7], v8 = row[8], v9 = row[9];
+        v2f z[5] = {(v2f){v2.z, v2.w}, (v2f){v3.x, v3.y}, (v2f){v3.z, v3.w}, (v2f){v4.x, v4.y}, (v2f){v4.z, v4.w}};
+        const v2f d[5] = {(v2f){v7.z, v7.w}, (v2f){v8.x, v8.y}, (v2f){v8.z, v8.w}, (v2f){v9.x, v9.y}, (v2f){v9.z, v9.w}};
+        deg_out += 1.f;
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = __builtin_elementwise_fma(z[p], sc, pf[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = pk_fma_lo(wf[p], a01, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = pk_fma_hi(wf[5 + p], a01, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) z[p] = pk_fma_lo_clamp(wf[10 + p], a2, z[p]);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+          S_fr[p] += z[p];
+          dS_fr[p] = __builtin_elementwise_fma(dPi_fr[p] + d[p], pk_mul_clamp(z[p], big), dS_fr[p]);
+        }
+      }
+    }
+    c0 = nx;
+  }
+  const v2f us = splat(RELU_UNSCALE);
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    S_to[p] *= us;
+    S_fr[p] *= us;
+  }
+}
+
 template <int P, bool MIXED, bool MFMA1>
 __global__ __launch_bounds__(TILE_THREADS) JVP_OCC void k_jvp_tile(int n_tiles, int chunk, const int32_t* __restrict__ tile_list,
                                                            const int32_t* __restrict__ tile_ptr,
@@ -266,21 +358,50 @@ __global__ __launch_bounds__(TILE_THREADS) JVP_OCC void k_jvp_tile(int n_tiles, 
     for (int o = 0; o < D; ++o) mu += y[o];
   } else {
   // ---- stage 2: neighbour sums and their tangents
-  v2f Pi[5], dPi[5], S_to[5], S_fr[5], dS_to[5], dS_fr[5];
+  v2f S_to[5], S_fr[5], dS_to[5], dS_fr[5];
+  float deg_in, deg_out;
+#pragma unroll
+  for (int p = 0; p < 5; ++p) S_to[p] = S_fr[p] = dS_to[p] = dS_fr[p] = splat(0.f);
+#if JVP_BOTH
+  {
+    v2f Pi[5], dPi[5], Pi2[5], dPi2[5];
+    ld5(T + L::T_B1_TO, Pi);
+    ld5(T + L::T_B1_FR, Pi2);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) dPi[p] = dPi2[p] = splat(0.f);
+    PHASE();
+    mv2<D>(T + L::T_W1I_TO, x, Pi);
+    mv2<D>(T + L::T_W1I_TO, dx, dPi);
+    PHASE();
+    mv2<D>(T + L::T_W1I_FR, x, Pi2);
+    mv2<D>(T + L::T_W1I_FR, dx, dPi2);
+    edge_pass_jvp_both<RS>(slots, nslots, lds, T + L::T_A_TO, T + L::T_A_FR, Pi, dPi, Pi2, dPi2, S_to, dS_to, S_fr, dS_fr, deg_in,
+                           deg_out);
+  }
+#if JVP_XRELOAD
+  PHASE();   // x / dx are not needed during the walk: re-read them (L2 hits) instead of holding 20 VGPRs across it
+  load10(h + n * D, x);
+  load10(tv + n * D, dx);
+#endif
+#else
+  {
+  v2f Pi[5], dPi[5];
   ld5(T + L::T_B1_TO, Pi);
 #pragma unroll
-  for (int p = 0; p < 5; ++p) S_to[p] = S_fr[p] = dS_to[p] = dS_fr[p] = dPi[p] = splat(0.f);
+  for (int p = 0; p < 5; ++p) dPi[p] = splat(0.f);
   PHASE();
   mv2<D>(T + L::T_W1I_TO, x, Pi);
   mv2<D>(T + L::T_W1I_TO, dx, dPi);
-  const float deg_in = edge_pass_jvp<RS, 0, 2 * D, SLOT_IN>(slots, nslots, lds, T + L::T_A_TO, Pi, dPi, S_to, dS_to);
+  deg_in = edge_pass_jvp<RS, 0, 2 * D, SLOT_IN>(slots, nslots, lds, T + L::T_A_TO, Pi, dPi, S_to, dS_to);
   ld5(T + L::T_B1_FR, Pi);
 #pragma unroll
   for (int p = 0; p < 5; ++p) dPi[p] = splat(0.f);
   PHASE();
   mv2<D>(T + L::T_W1I_FR, x, Pi);
   mv2<D>(T + L::T_W1I_FR, dx, dPi);
-  const float deg_out = edge_pass_jvp<RS, D, 3 * D, SLOT_OUT>(slots, nslots, lds, T + L::T_A_FR, Pi, dPi, S_fr, dS_fr);
+  deg_out = edge_pass_jvp<RS, D, 3 * D, SLOT_OUT>(slots, nslots, lds, T + L::T_A_FR, Pi, dPi, S_fr, dS_fr);
+  }
+#endif
   // ---- gate and update MLP (second Phi layer folded), values and tangents
   const float* Wf = W + lofs + L::L_FOLD;
   const float* Wa = W + L::AL_W;
