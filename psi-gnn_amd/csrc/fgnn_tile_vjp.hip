@@ -7,15 +7,15 @@
 //           slots) that additionally counts, per output, the edges whose pre-activation is positive.  The masked
 //           cotangent sum over a node's OWN edges is then just  dS * count  (dS_to[n] is per node, not per edge),
 //           so no second sweep over the slots is needed.  Backward through LayerNorm, the folded gate / update
-//           MLP; writes the node-local result and B[n] = { Pt[n], Pf[n], dS_to[n], dS_fr[n] } (40 floats).
-//   pass B  (k_vjp_tile_b)  stages B[tile + halo] in LDS (160-byte rows) and, for node u, walks the same slots
+//           MLP; writes the node-local result and B[n] = { Pt[n], dS_to[n], Pf[n], dS_fr[n] } (40 floats).
+//   pass B  (k_vjp_tile_b)  stages B[tile + halo] in LDS (one 80-byte half row at a time) and, for node u, walks the same slots
 //           from the neighbour's side:  OUT slot (edge u -> n): acc_t += dS_to[n] * 1[Pt[n] + Pjt[u] + At a > 0]
 //                                       IN  slot (edge n -> u): acc_f += dS_fr[n] * 1[Pf[n] + Pjf[u] + Af m(a) > 0]
 //           out[u] += W1j_to^T acc_t + W1j_fr^T acc_f.
 // Mixed family: a Neumann row n is update_neumann([h | Phi_neumann(h) | prb | normal]) with Phi_neumann summing over the
 // node's OUT edges (mixed/psignn/model.py:225,233-236,241).  Pass A runs the tiles that hold Neumann nodes with a third
 // projection column in LDS (128-byte rows; the other tiles in a launch of their own, like k_f_tile) and writes
-// B[n] = { 0, Pn[n], 0, dS_n[n] } for such a row -- the Phi_from positions, its dS_to is zero.  Pass B keeps the rows' Neumann
+// B[n] = { 0, 0, Pn[n], dS_n[n] } for such a row -- the Phi_from half, its dS_to is zero.  Pass B keeps the rows' Neumann
 // flag beside the B rows in LDS: an IN slot (edge n -> u) whose sender n is a Neumann row uses Phi_neumann's weights and
 // accumulates into a third sum, out[u] += W1j_neu^T acc_n.  A tile without Neumann rows among tile + halo skips all of it.
 // All tensors in plan order.  The parameter-gradient records (PG) exist for the dirichlet family only.
@@ -298,12 +298,10 @@ __global__ __launch_bounds__(VT) VJPA_OCC void k_vjp_tile_a(int n_tiles, int chu
     mvb<D>(Un + L::NEU_W1, L::NEU_CAT, 0, dq, g);
     PHASE();
     mvb<D>(W + L::nfold(nl) + L::NF_G, D, 0, dq, dS_n);   // dS_n[k] = sum_o Gn[o][k] dq[o]
-    Bn[0] = Bn[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    Bn[2] = make_float4(0.f, 0.f, Pn[0].x, Pn[0].y);
-    Bn[3] = make_float4(Pn[1].x, Pn[1].y, Pn[2].x, Pn[2].y);
-    Bn[4] = make_float4(Pn[3].x, Pn[3].y, Pn[4].x, Pn[4].y);
-    Bn[5] = Bn[6] = make_float4(0.f, 0.f, 0.f, 0.f);
-    Bn[7] = make_float4(0.f, 0.f, dS_n[0].x, dS_n[0].y);
+    Bn[0] = Bn[1] = Bn[2] = Bn[3] = Bn[4] = make_float4(0.f, 0.f, 0.f, 0.f);   // sends nothing through Phi_to
+    Bn[5] = make_float4(Pn[0].x, Pn[0].y, Pn[1].x, Pn[1].y);
+    Bn[6] = make_float4(Pn[2].x, Pn[2].y, Pn[3].x, Pn[3].y);
+    Bn[7] = make_float4(Pn[4].x, Pn[4].y, dS_n[0].x, dS_n[0].y);
     Bn[8] = make_float4(dS_n[1].x, dS_n[1].y, dS_n[2].x, dS_n[2].y);
     Bn[9] = make_float4(dS_n[3].x, dS_n[3].y, dS_n[4].x, dS_n[4].y);
     float gn[D], go[D];
@@ -423,12 +421,12 @@ __global__ __launch_bounds__(VT) VJPA_OCC void k_vjp_tile_a(int n_tiles, int chu
   mvb<D>(Wf + L::F_GFR, D, 0, dq, dS_fr);
   Bn[0] = make_float4(Pt[0].x, Pt[0].y, Pt[1].x, Pt[1].y);
   Bn[1] = make_float4(Pt[2].x, Pt[2].y, Pt[3].x, Pt[3].y);
-  Bn[2] = make_float4(Pt[4].x, Pt[4].y, Pf[0].x, Pf[0].y);
-  Bn[3] = make_float4(Pf[1].x, Pf[1].y, Pf[2].x, Pf[2].y);
-  Bn[4] = make_float4(Pf[3].x, Pf[3].y, Pf[4].x, Pf[4].y);
-  Bn[5] = make_float4(dS_to[0].x, dS_to[0].y, dS_to[1].x, dS_to[1].y);
-  Bn[6] = make_float4(dS_to[2].x, dS_to[2].y, dS_to[3].x, dS_to[3].y);
-  Bn[7] = make_float4(dS_to[4].x, dS_to[4].y, dS_fr[0].x, dS_fr[0].y);
+  Bn[2] = make_float4(Pt[4].x, Pt[4].y, dS_to[0].x, dS_to[0].y);
+  Bn[3] = make_float4(dS_to[1].x, dS_to[1].y, dS_to[2].x, dS_to[2].y);
+  Bn[4] = make_float4(dS_to[3].x, dS_to[3].y, dS_to[4].x, dS_to[4].y);
+  Bn[5] = make_float4(Pf[0].x, Pf[0].y, Pf[1].x, Pf[1].y);
+  Bn[6] = make_float4(Pf[2].x, Pf[2].y, Pf[3].x, Pf[3].y);
+  Bn[7] = make_float4(Pf[4].x, Pf[4].y, dS_fr[0].x, dS_fr[0].y);
   Bn[8] = make_float4(dS_fr[1].x, dS_fr[1].y, dS_fr[2].x, dS_fr[2].y);
   Bn[9] = make_float4(dS_fr[3].x, dS_fr[3].y, dS_fr[4].x, dS_fr[4].y);
   // ---- the node's own edges: masked cotangent sum = dS * (number of active edges per output)
@@ -549,15 +547,15 @@ __device__ __forceinline__ void pass_rev(const uint4* __restrict__ slots, int ns
 }
 
 // IN slots of a mixed plan: the sender n of edge (n -> u) is an interior row (Phi_from: weights AF, projection Pjf, sum af) or
-// a Neumann row (Phi_neumann: AN, Pjn, an) -- nflag[row] tells; both kinds keep Pi at row[10..] and dS at row[30..].
-// one IN slot seen from the receiver: acc[o] += 1[row[10 + o] + Pj[o] + AT . (-a0, -a1, a2) > 0] * row[30 + o]
+// a Neumann row (Phi_neumann: AN, Pjn, an) -- nflag[row] tells; both kinds keep Pi and dS in the second half of their B row.
+// one IN slot seen from the receiver: acc[o] += 1[row[o] + Pj[o] + AT . (-a0, -a1, a2) > 0] * row[10 + o]   (half-row [P | dS])
 __device__ __forceinline__ void rev_slot_in(const float* __restrict__ row, const float* __restrict__ AT, const uint4& c, const v2f* Pj,
                                             v2f* acc) {
   const v2f* wa = reinterpret_cast<const v2f*>(AT);   // wave-uniform address: the weights stay in scalar registers
   const v2f a0 = splat2(-__uint_as_float(c.y)), a1 = splat2(-__uint_as_float(c.z)), a2 = splat2(__uint_as_float(c.w));
   v2f pi[5], ds[5], z[5];
-  row10u(row + D, pi);
-  row10u(row + 3 * D, ds);
+  row10(row, pi);
+  row10u(row + D, ds);
 #pragma unroll
   for (int p = 0; p < 5; ++p) z[p] = pi[p] + Pj[p];
 #pragma unroll
@@ -571,7 +569,7 @@ __device__ __forceinline__ void rev_slot_in(const float* __restrict__ row, const
 }
 
 // IN slots of a mixed plan: the sender n of edge (n -> u) is an interior row (Phi_from: weights AF, projection Pjf, sum af) or
-// a Neumann row (Phi_neumann: AN, Pjn, an) -- nflag[row] tells; both kinds keep Pi at row[10..] and dS at row[30..].
+// a Neumann row (Phi_neumann: AN, Pjn, an) -- nflag[row] tells; both kinds keep Pi and dS in the second half of their B row.
 template <int RS>
 __device__ __forceinline__ void pass_rev_in_mixed(const uint4* __restrict__ slots, int nslots, const float* __restrict__ lds,
                                                   const int32_t* __restrict__ nflag, const float* __restrict__ AF,
@@ -604,7 +602,10 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const
                                                    const float* __restrict__ B, float* __restrict__ out,
                                                    float* __restrict__ rec) {
   using L = WLayout<P>;
-  constexpr int RS = 40;  // LDS row = B row: [Pt 10 | Pf 10 | dS_to 10 | dS_fr 10]; mixed: the rows' Neumann flags behind them
+  // B row in memory: [Pt 10 | dS_to 10 | Pf 10 | dS_fr 10].  The OUT slots need the first half of the senders' rows, the IN slots the
+  // second: the halves are staged one after the other into 80-byte LDS rows -- 26 KB per workgroup instead of 52, so six workgroups
+  // fit a CU where three did (the kernel needs < 96 VGPRs: LDS was what held it at three waves per SIMD); same bytes from memory.
+  constexpr int RS = 20;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (tile >= n_tiles) return;
@@ -614,12 +615,14 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const
   const int n_h = halo_cnt[tile];
   const int32_t* hl = halo + (int64_t)tile * HALO_CAP;
   const float* T = W + tofs;
-  // ---- stage 1: B rows of tile + halo -> LDS (float4 units: 10 per row)
-  for (int i = tid; i < (n_t + n_h) * 10; i += VT) {
-    const int row = i / 10, c = i - row * 10;
-    const int64_t node = row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t];
-    reinterpret_cast<float4*>(lds)[row * 10 + c] = reinterpret_cast<const float4*>(B + node * 4 * D)[c];
-  }
+  auto stage = [&](int half) {   // float4 units: 5 per half row
+    for (int i = tid; i < (n_t + n_h) * 5; i += VT) {
+      const int row = i / 5, c = i - row * 5;
+      const int64_t node = row < n_t ? (int64_t)(t0 + row) : (int64_t)hl[row - n_t];
+      reinterpret_cast<float4*>(lds)[row * 5 + c] = reinterpret_cast<const float4*>(B + node * 4 * D)[half * 5 + c];
+    }
+  };
+  stage(0);
   int32_t* nflag = reinterpret_cast<int32_t*>(lds + (n_t + n_h) * RS);
   bool tile_neu = false;
   if (MIXED) {
@@ -630,42 +633,45 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const
       nflag[row] = f;
       any |= f;
     }
-    tile_neu = __syncthreads_or(any) != 0;   // (also the barrier in front of stage 2)
+    tile_neu = __syncthreads_or(any) != 0;   // (also the barrier in front of the first walk)
   } else {
     __syncthreads();
   }
-  if (tid >= n_t) return;
-  const int64_t u = (int64_t)t0 + tid;
+  const bool active = tid < n_t;            // (every thread stays for the second staging pass and its barriers)
+  const int64_t u = (int64_t)t0 + min(tid, n_t - 1);
   const int lane = tid & 63;
-  const int slice = tile_slice[tile] + (tid >> 6);
+  const int slice = tile_slice[tile] + (min(tid, n_t - 1) >> 6);
   const uint4* slots = ell + (int64_t)slice_off[slice] * 64 + lane;
-  const int nslots = slice_deg[slice];
+  const int nslots = active ? slice_deg[slice] : 0;
   float x[D];
   load10(h + u * D, x);
-  v2f Pj[5], at[5], af[5];
+  v2f Pj[5], at[5], af[5], an[5];
 #pragma unroll
-  for (int p = 0; p < 5; ++p) Pj[p] = at[p] = af[p] = splat2(0.f);
-  // OUT slots: edge (u -> n) is an in-edge of n (Phi_to of n): Pt[n] at 0, dS_to[n] at 20, attr = the slot's own
+  for (int p = 0; p < 5; ++p) Pj[p] = at[p] = af[p] = an[p] = splat2(0.f);
+  // OUT slots: edge (u -> n) is an in-edge of n (Phi_to of n): Pt[n], dS_to[n] = first half row, attr = the slot's own
   // (T_A_TO holds the mirrored rows -> flip = -1 restores the plain attr weights)
   PHASE();
   mvf<D>(T + L::T_W1J_TO, x, Pj);
-  pass_rev<RS, 0, 2 * D, SLOT_OUT>(slots, nslots, lds, T + L::T_A_TO, -1.f, Pj, at);
-  // IN slots: edge (n -> u) is an out-edge of n (Phi_from of n): Pf[n] at 10, dS_fr[n] at 30, attr = mirror of the slot's
+  pass_rev<RS, 0, D, SLOT_OUT>(slots, nslots, lds, T + L::T_A_TO, -1.f, Pj, at);
+  __syncthreads();   // every wave is done with the first halves
+  stage(1);
+  __syncthreads();
+  // IN slots: edge (n -> u) is an out-edge of n (Phi_from of n): Pf[n], dS_fr[n] = second half row, attr = mirror of the slot's
 #pragma unroll
   for (int p = 0; p < 5; ++p) Pj[p] = splat2(0.f);
   PHASE();
   mvf<D>(T + L::T_W1J_FR, x, Pj);
-  v2f an[5];
   if (MIXED && tile_neu) {
     v2f Pjn[5];
 #pragma unroll
-    for (int p = 0; p < 5; ++p) Pjn[p] = an[p] = splat2(0.f);
+    for (int p = 0; p < 5; ++p) Pjn[p] = splat2(0.f);
     PHASE();
     mvf<D>(W + tnofs + L::N_W1J, x, Pjn);
     pass_rev_in_mixed<RS>(slots, nslots, lds, nflag, T + L::T_A_FR, W + tnofs + L::N_A, Pj, Pjn, af, an);
   } else {
-    pass_rev<RS, D, 3 * D, SLOT_IN>(slots, nslots, lds, T + L::T_A_FR, -1.f, Pj, af);
+    pass_rev<RS, 0, D, SLOT_IN>(slots, nslots, lds, T + L::T_A_FR, -1.f, Pj, af);
   }
+  if (!active) return;
   if (PG) {  // neighbour-side cotangent sums: W1j gradients are sum_u acc[u] (x) x[u]
     rec_group(rec + u * PGREC + 192, reinterpret_cast<const float*>(at), D);
     rec_group(rec + u * PGREC + 208, reinterpret_cast<const float*>(af), D);
@@ -700,7 +706,7 @@ static int tile_vjp_launch(const psignn_plan* p, const float* W, int nl, const f
   ARG_CHECK(!p->mixed || (nrm && !rec), "mixed plan: needs unit normals; no parameter-gradient records");
   const int chunk = (int)cdiv(p->n_tiles, 8);
   const unsigned grid = (unsigned)(chunk * 8);
-  const size_t lds_b = (size_t)p->max_rows * (40 + (p->mixed ? 1 : 0)) * 4;
+  const size_t lds_b = (size_t)p->max_rows * (20 + (p->mixed ? 1 : 0)) * 4;
   ARG_CHECK(lds_b <= 160 * 1024, "tile + halo rows exceed the LDS budget of the tiled VJP");
 #define VJP_PLAN p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell, p->flags_p
   if (p->mixed) {
