@@ -387,6 +387,9 @@ int psignn_gmres_step(psignn_gmres_t* s, int j, double shift, double eta, int* h
  * NULL).  h_info (may be NULL): [steps completed, |b|, |residual|].  d_dst may alias d_base. */
 int psignn_gmres_solution(psignn_gmres_t* s, int k, const float* d_base, double scale, float* d_dst, double* h_info, void* stream);
 int psignn_gmres_history(psignn_gmres_t* s, double* h_res /* m_max + 1 */, void* stream);
+/* Steps of the current solve whose second Gram-Schmidt pass ran (the pass is conditional: Daniel-Gragg-Kaufman-Stewart test on
+ * the device, |w'|^2 < 1/2 |w|^2; PSIGNN_GMRES_REORTH=always makes it unconditional). */
+int psignn_gmres_reorth_count(psignn_gmres_t* s, int* h_count, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline line;

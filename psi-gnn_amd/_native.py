@@ -119,6 +119,7 @@ SIGNATURES = {
     "psignn_gmres_step": (_INT, [_P, _INT, C.c_double, C.c_double, C.POINTER(_INT), _P]),
     "psignn_gmres_solution": (_INT, [_P, _INT, _P, C.c_double, _P, C.POINTER(C.c_double), _P]),
     "psignn_gmres_history": (_INT, [_P, C.POINTER(C.c_double), _P]),
+    "psignn_gmres_reorth_count": (_INT, [_P, C.POINTER(C.c_int), _P]),
     "psignn_prof_enable": (None, [_INT]),
     "psignn_prof_tile_stamps": (None, [_P]),
     "psignn_prof_collect": (_INT, []),

