@@ -172,4 +172,6 @@ struct BatchDesc {
   double *rel_trace, *abs_trace;
   const struct TileCtx* ctx;
   const float *h0p, *prbp;
+  float* part2;                // three-sweep update: block partials of vT.dg, vT.g
+  int32_t nblk_u, npart_u;     // its blocks / per-wave partials per stored pair
 };

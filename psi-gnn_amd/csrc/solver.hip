@@ -52,6 +52,9 @@ struct psignn_broyden {
   float* xbuf = nullptr;    // (thr+2, M) with trace, else (3, M)
   float *gx = nullptr, *dg = nullptr, *upd = nullptr, *fx = nullptr, *fwork = nullptr;
   float* nrm_part = nullptr;  // norm partials of the f / residual kernel: 2 * nn floats
+  float* part2 = nullptr;     // three-sweep update: block partials of vT.dg, vT.g (2 * nblk floats)
+  int uvu = 0;                // the update runs as three single-array sweeps U, V, U (broyden_alloc)
+  int vec_u = 0, nblk_u = 0, npart_u = 0;   // their vector width / blocks / per-wave partials per stored pair
   int nn_cap = 0;
   float *h0p = nullptr, *prbp = nullptr, *nrmp = nullptr;  // plan-order copies of h_initial, prb_data, normals
   float* part = nullptr;    // (3, thr, npart) dot partials; reused for the norm / s,beta partials
@@ -331,6 +334,179 @@ __global__ __launch_bounds__(TB) void k_reduce_check(Status* st, const float* __
   reduce_check_body(st, part, npart, thr, k, coef, nrm_part, nn, rel_trace, abs_trace, eps, seq_len, keep_trace, sh);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Three-sweep form of the update (long vectors; launch_update_uvu).  The two-pass form reads U and V twice per iteration:
+// dots (a = U^T dx, c = V^T dg, b = V^T g), then axpy (vT = -dx + V a, D1 = dx + dg - U c, D2 = g - U b).  But V a needs only
+// a, and U c / U b need only c and b: sweep 1 reads U for a; sweep 2 reads V ONCE for c, b AND V a; sweep 3 reads U for
+// U c, U b -- three single-array sweeps instead of four, the same arithmetic on every element and the same partial-sum shapes
+// (results bit-identical to the two-pass form; tests/test_gpu_parity.py::test_three_sweep_update_is_bitwise_identical).
+template <int VEC>
+__device__ __forceinline__ void sweep_u1_body(int64_t M, int k, const Status* __restrict__ st, const float* __restrict__ U,
+                                              const float* __restrict__ dxv, float* __restrict__ part, int npart, int64_t ld) {
+  if (st->done) return;
+  int64_t e0 = elem0<VEC>();
+  float dx[VEC];
+  const bool act = e0 < M;
+  if (act) {
+    ldv<VEC>(dxv, e0, M, dx);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) dx[i] = 0.f;
+  }
+  const int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+  const bool lead = (threadIdx.x & 63) == 0;
+  for (int j = 0; j < k; ++j) {
+    float u[VEC];
+    float sa = 0.f;
+    if (act) {
+      ldv_stream<VEC>(U + (int64_t)j * ld, e0, M, u);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) sa = fmaf(dx[i], u[i], sa);
+    }
+    sa = wave_sum(sa);
+    if (lead) part[((int64_t)j * npart + w) * 4] = sa;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(TB) void k_sweep_u1(int64_t M, int k, const Status* __restrict__ st, const float* __restrict__ U,
+                                                 const float* __restrict__ dxv, float* __restrict__ part, int npart, int64_t ld) {
+  sweep_u1_body<VEC>(M, k, st, U, dxv, part, npart, ld);
+}
+
+// grid (max(k, 1), 2): blocks (j, 0): coef_a[j]; block (0, 1): the iteration's bookkeeping (as k_reduce_check's)
+__device__ __forceinline__ void reduce_a_check_body(Status* st, const float* __restrict__ part, int npart, int thr, int k,
+                                                    float* __restrict__ coef, const float* __restrict__ nrm_part, int nn,
+                                                    double* __restrict__ rel_trace, double* __restrict__ abs_trace,
+                                                    double eps, int seq_len, int keep_trace, double* sh) {
+  if (blockIdx.y == 1) {
+    if (blockIdx.x == 0) check_block(st, nrm_part, nn, rel_trace, abs_trace, eps, thr, seq_len, keep_trace, sh);
+    return;
+  }
+  if (st->done) return;
+  const int j = blockIdx.x;
+  if (j >= k) return;
+  const double s = block_sum_partials<4>(part + (int64_t)j * npart * 4, npart, sh);
+  if (threadIdx.x == 0) coef[j] = (float)s;
+}
+__global__ __launch_bounds__(TB) void k_reduce_a_check(Status* st, const float* __restrict__ part, int npart, int thr, int k,
+                                                       float* __restrict__ coef, const float* __restrict__ nrm_part, int nn,
+                                                       double* __restrict__ rel_trace, double* __restrict__ abs_trace,
+                                                       double eps, int seq_len, int keep_trace) {
+  __shared__ double sh[TB];
+  reduce_a_check_body(st, part, npart, thr, k, coef, nrm_part, nn, rel_trace, abs_trace, eps, seq_len, keep_trace, sh);
+}
+
+// sweep 2: reads V once: partials of c_j = V_j.dg, b_j = V_j.g AND vT = -dx + sum_j a_j V_j; then vT's part of axpy_finish
+// (vT.dg with the raw vT, NaN -> 0, vT.g; V[k] = vT; block partials into part2)
+template <int VEC>
+__device__ __forceinline__ void sweep_v_body(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ V,
+                                             const float* __restrict__ dxv, const float* __restrict__ dgv,
+                                             const float* __restrict__ gv, const float* __restrict__ coef,
+                                             float* __restrict__ part, int npart, float* __restrict__ part2, int nblk, int64_t ld) {
+  if (st->done) return;
+  int64_t e0 = elem0<VEC>();
+  float dg[VEC], g[VEC], av[VEC];
+  const bool act = e0 < M;
+  if (act) {
+    ldv<VEC>(dxv, e0, M, av);
+    ldv<VEC>(dgv, e0, M, dg);
+    ldv<VEC>(gv, e0, M, g);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) av[i] = -av[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) dg[i] = g[i] = av[i] = 0.f;
+  }
+  const int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+  const bool lead = (threadIdx.x & 63) == 0;
+  for (int j = 0; j < k; ++j) {
+    float v[VEC];
+    float sc = 0.f, sb = 0.f;
+    const float ca = coef[j];
+    if (act) {
+      ldv_stream<VEC>(V + (int64_t)j * ld, e0, M, v);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        sc = fmaf(v[i], dg[i], sc);
+        sb = fmaf(v[i], g[i], sb);
+        av[i] = fmaf(ca, v[i], av[i]);
+      }
+    }
+    sc = wave_sum(sc);
+    sb = wave_sum(sb);
+    if (lead) *reinterpret_cast<float2*>(part + ((int64_t)j * npart + w) * 4 + 1) = make_float2(sc, sb);
+  }
+  float p1 = 0.f, p2 = 0.f;
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      p1 = fmaf(av[i], dg[i], p1);       // with the raw vT, as the reference divides before scrubbing
+      av[i] = (av[i] != av[i]) ? 0.f : av[i];
+      p2 = fmaf(av[i], g[i], p2);
+    }
+    stv<VEC>(V + (int64_t)k * ld, e0, M, av);
+  }
+  block_pair_store(p1, p2, part2, nblk);
+}
+template <int VEC>
+__global__ __launch_bounds__(TB) void k_sweep_v(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ V,
+                                                const float* __restrict__ dxv, const float* __restrict__ dgv,
+                                                const float* __restrict__ gv, const float* __restrict__ coef,
+                                                float* __restrict__ part, int npart, float* __restrict__ part2, int nblk,
+                                                int64_t ld) {
+  sweep_v_body<VEC>(M, k, st, V, dxv, dgv, gv, coef, part, npart, part2, nblk, ld);
+}
+
+// grid (k, 2): coef_c[j], coef_b[j]
+__device__ __forceinline__ void reduce_cb_body(const Status* __restrict__ st, const float* __restrict__ part, int npart, int thr,
+                                               int k, float* __restrict__ coef, double* sh) {
+  if (st->done) return;
+  const int j = blockIdx.x, c = 1 + blockIdx.y;
+  if (j >= k) return;
+  const double s = block_sum_partials<4>(part + (int64_t)j * npart * 4 + c, npart, sh);
+  if (threadIdx.x == 0) coef[c * thr + j] = (float)s;
+}
+__global__ __launch_bounds__(TB) void k_reduce_cb(const Status* __restrict__ st, const float* __restrict__ part, int npart, int thr,
+                                                  int k, float* __restrict__ coef) {
+  __shared__ double sh[TB];
+  reduce_cb_body(st, part, npart, thr, k, coef, sh);
+}
+
+// sweep 3: reads U once: D1 = dx + dg - sum_j c_j U_j -> U[k] (unscaled), D2 = g - sum_j b_j U_j -> upd
+template <int VEC>
+__device__ __forceinline__ void sweep_u2_body(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
+                                              float* __restrict__ upd, const float* __restrict__ dgv,
+                                              const float* __restrict__ gv, const float* __restrict__ coef, int thr, int64_t ld) {
+  if (st->done) return;
+  int64_t e0 = elem0<VEC>();
+  if (e0 >= M) return;
+  float a1[VEC], a2[VEC], dg[VEC];
+  ldv<VEC>(upd, e0, M, a1);
+  ldv<VEC>(dgv, e0, M, dg);
+  ldv<VEC>(gv, e0, M, a2);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) a1[i] = a1[i] + dg[i];
+  for (int j = 0; j < k; ++j) {
+    float u[VEC];
+    const float cc = coef[thr + j], cb = coef[2 * thr + j];
+    ldv_stream<VEC>(U + (int64_t)j * ld, e0, M, u);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      a1[i] = fmaf(-cc, u[i], a1[i]);
+      a2[i] = fmaf(-cb, u[i], a2[i]);
+    }
+  }
+  stv<VEC>(U + (int64_t)k * ld, e0, M, a1);
+  stv<VEC>(upd, e0, M, a2);
+}
+template <int VEC>
+__global__ __launch_bounds__(TB) void k_sweep_u2(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
+                                                 float* __restrict__ upd, const float* __restrict__ dgv,
+                                                 const float* __restrict__ gv, const float* __restrict__ coef, int thr, int64_t ld) {
+  sweep_u2_body<VEC>(M, k, st, U, upd, dgv, gv, coef, thr, ld);
+}
+
 // axpy pass.  Writes vT (NaN->0) to V[k], D1 to U[k] (unscaled), D2 to upd, partials of vT.dg, vT.g.
 // gridDim.y == 1: the whole sum over j in one block column.  gridDim.y > 1 (short vectors): block row y sums its
 // j-range into jpart[y][3][M] and k_axpy_combine finishes -- fixed grouping, so still reproducible.
@@ -549,6 +725,18 @@ static int broyden_alloc(psignn_broyden* s) {
     s->vec_ax = 4;
     s->nblk_ax = (int)cdiv(s->M, (int64_t)4 * TB);
   }
+  // three-sweep update (launch_update): where an UNSPLIT sweep covers the chip -- long vectors at 16 floats per lane, mid-size
+  // vectors and shards of short vectors at the 4-float width of their axpy pass.  PSIGNN_UVU=0|1 overrides (A/B, tests).
+  s->uvu = 0;
+  if (DOTS_PART4) {
+    if (s->vec == 16 && s->jgroups == 1 && s->vec_ax == 16) {
+      s->uvu = 1; s->vec_u = 16; s->nblk_u = s->nblk;
+    } else if (s->vec_ax == 4 && s->vec == 16) {
+      s->uvu = 1; s->vec_u = 4; s->nblk_u = s->nblk_ax;
+    }
+    if (const char* e = getenv("PSIGNN_UVU")) if (atoi(e) == 0) s->uvu = 0;
+  }
+  s->npart_u = s->nblk_u * (TB / 64);
   s->nn_cap = std::max<int>(std::max(s->nblk, s->nblk_ax), s->plan ? (int)s->plan->n_tiles : 0);
   size_t nx = s->keep_trace ? thr + 2 : 3;
   s->ld = (s->M + 63) / 64 * 64;  // row pitch of U and V: every stored vector starts on a 256-byte boundary
@@ -556,9 +744,9 @@ static int broyden_alloc(psignn_broyden* s) {
   struct { void** p; size_t n; } allocs[] = {
       {(void**)&s->U, thr * ld * 4},  {(void**)&s->V, thr * ld * 4},   {(void**)&s->xbuf, nx * M * 4},
       {(void**)&s->gx, M * 4},        {(void**)&s->dg, M * 4},        {(void**)&s->upd, M * 4},
-      {(void**)&s->fx, M * 4},        {(void**)&s->part, 4 * thr * (size_t)s->npart * 4 + 16},
+      {(void**)&s->fx, M * 4},        {(void**)&s->part, 4 * thr * (size_t)std::max(s->npart, s->npart_u) * 4 + 16},
       {(void**)&s->coef, 3 * thr * 4 + 16}, {(void**)&s->st, sizeof(Status)},
-      {(void**)&s->nrm_part, 2 * (size_t)s->nn_cap * 4 + 16},
+      {(void**)&s->nrm_part, 2 * (size_t)s->nn_cap * 4 + 16}, {(void**)&s->part2, 2 * (size_t)std::max(s->nblk, s->nblk_u) * 4 + 16},
       {(void**)&s->rel_trace, thr * 8 + 8}, {(void**)&s->abs_trace, thr * 8 + 8}};
   for (auto& a : allocs) {
     if (hipMalloc(a.p, a.n ? a.n : 16) != hipSuccess) {
@@ -599,7 +787,7 @@ static int broyden_alloc(psignn_broyden* s) {
 
 extern "C" void psignn_broyden_destroy(psignn_broyden_t* s) {
   if (!s) return;
-  void* ptrs[] = {s->U, s->V, s->xbuf, s->gx, s->dg, s->upd, s->fx, s->fwork, s->part, s->coef, s->st, s->nrm_part,
+  void* ptrs[] = {s->U, s->V, s->xbuf, s->gx, s->dg, s->upd, s->fx, s->fwork, s->part, s->coef, s->st, s->nrm_part, s->part2,
                   s->rel_trace, s->abs_trace, s->h0p, s->prbp, s->nrmp, s->jpart};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -674,6 +862,20 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
   if (!fused_npart)
     VLAUNCH("k_resid", st, s->vec, k_resid, (g, TB, 0, st), s->M, s->st, s->xbuf, s->fx, s->gx, s->dg, s->nrm_part, s->nblk);
   const int np = fused_npart ? fused_npart : s->nblk;  // one partial pair per block / per tile
+  if (s->uvu) {
+    const int kd = k >= s->thr ? 0 : k;
+    const unsigned gu = (unsigned)s->nblk_u;
+    if (kd > 0)
+      VLAUNCH("k_sweep_u1", st, s->vec_u, k_sweep_u1, (gu, TB, 0, st), s->M, kd, s->st, s->U, s->upd, s->part, s->npart_u, s->ld);
+    LAUNCH("k_reduce_check", st, (k_reduce_a_check<<<dim3(std::max(kd, 1), 2), TB, 0, st>>>(
+        s->st, s->part, s->npart_u, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace)));
+    if (k >= s->thr) return;
+    VLAUNCH("k_sweep_v", st, s->vec_u, k_sweep_v, (gu, TB, 0, st), s->M, k, s->st, s->V, s->upd, s->dg, s->gx, s->coef, s->part, s->npart_u, s->part2, s->nblk_u, s->ld);
+    if (k > 0) LAUNCH("k_reduce_cb", st, (k_reduce_cb<<<dim3(k, 2), TB, 0, st>>>(s->st, s->part, s->npart_u, s->thr, k, s->coef)));
+    VLAUNCH("k_sweep_u2", st, s->vec_u, k_sweep_u2, (gu, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->ld);
+    VLAUNCH("k_final", st, s->vec_u, k_final, (gu, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->ld, s->part2, s->nblk_u);
+    return;
+  }
   // split of the sweeps over the stored pairs: only when there are enough pairs to share out
   const int G = (s->jgroups > 1 && k >= 4 * s->jgroups) ? s->jgroups : 1;
   const int js = (int)cdiv(std::max(k, 1), G);
@@ -870,6 +1072,44 @@ __global__ __launch_bounds__(TB) void kb_final(const BatchDesc* __restrict__ des
   if ((int)blockIdx.x >= nb) return;
   final_body<VEC>(d.M, k, reinterpret_cast<Status*>(d.st), d.U, d.upd, d.ld, d.part, nb, sh);
 }
+// three-sweep update, batched (grid (blocks, 1 | 2, meshes))
+template <int VEC>
+__global__ __launch_bounds__(TB) void kb_sweep_u1(const BatchDesc* __restrict__ descs, int k) {
+  const BatchDesc& d = descs[blockIdx.z];
+  if ((int)blockIdx.x >= d.nblk_u) return;
+  sweep_u1_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, d.part, d.npart_u, d.ld);
+}
+__global__ __launch_bounds__(TB) void kb_reduce_a_check(const BatchDesc* __restrict__ descs, int k, double eps) {
+  __shared__ double sh[TB];
+  const BatchDesc& d = descs[blockIdx.z];
+  reduce_a_check_body(reinterpret_cast<Status*>(d.st), d.part, d.npart_u, d.thr, k, d.coef, d.nrm_part, d.n_tiles, d.rel_trace,
+                      d.abs_trace, eps, d.seq_len, d.keep_trace, sh);
+}
+template <int VEC>
+__global__ __launch_bounds__(TB) void kb_sweep_v(const BatchDesc* __restrict__ descs, int k) {
+  const BatchDesc& d = descs[blockIdx.z];
+  if ((int)blockIdx.x >= d.nblk_u) return;
+  sweep_v_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.V, d.upd, d.dg, d.gx, d.coef, d.part, d.npart_u, d.part2,
+                    d.nblk_u, d.ld);
+}
+__global__ __launch_bounds__(TB) void kb_reduce_cb(const BatchDesc* __restrict__ descs, int k) {
+  __shared__ double sh[TB];
+  const BatchDesc& d = descs[blockIdx.z];
+  reduce_cb_body(reinterpret_cast<const Status*>(d.st), d.part, d.npart_u, d.thr, k, d.coef, sh);
+}
+template <int VEC>
+__global__ __launch_bounds__(TB) void kb_sweep_u2(const BatchDesc* __restrict__ descs, int k) {
+  const BatchDesc& d = descs[blockIdx.z];
+  if ((int)blockIdx.x >= d.nblk_u) return;
+  sweep_u2_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, d.dg, d.gx, d.coef, d.thr, d.ld);
+}
+template <int VEC>
+__global__ __launch_bounds__(TB) void kb_final_u(const BatchDesc* __restrict__ descs, int k) {
+  __shared__ double sh[TB];
+  const BatchDesc& d = descs[blockIdx.z];
+  if ((int)blockIdx.x >= d.nblk_u) return;
+  final_body<VEC>(d.M, k, reinterpret_cast<Status*>(d.st), d.U, d.upd, d.ld, d.part2, d.nblk_u, sh);
+}
 // *all_done = 1 when every mesh's stop test has fired
 __global__ void kb_all_done(const BatchDesc* __restrict__ descs, int n, int off_done, int32_t* __restrict__ all_done) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -891,15 +1131,16 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
   if (poll_every <= 0) poll_every = 8;
   // one vector width / split layout / threshold for the whole shard (meshes of one shard are of one size class)
   const psignn_broyden* s0 = sv[0];
-  int max_g = 0, max_ga = 0, max_G = 1, max_rows = 0, n_slots = 0;
+  int max_g = 0, max_ga = 0, max_gu = 0, max_G = 1, max_rows = 0, n_slots = 0;
   for (int m = 0; m < n; ++m) {
     const psignn_broyden* s = sv[m];
     ARG_CHECK(s && s->plan && s->plan->tiled && !s->plan->mixed, "batched solve: tiled dirichlet plans only");
-    ARG_CHECK(s->vec == s0->vec && s->vec_ax == s0->vec_ax && s->thr == s0->thr,
+    ARG_CHECK(s->vec == s0->vec && s->vec_ax == s0->vec_ax && s->uvu == s0->uvu && s->vec_u == s0->vec_u && s->thr == s0->thr,
               "batched solve: meshes of different size classes (vector width / threshold differ)");
     ARG_CHECK(h0[m] && prb[m], "NULL argument");
     max_g = std::max(max_g, s->nblk);
     max_ga = std::max(max_ga, s->nblk_ax);
+    max_gu = std::max(max_gu, s->nblk_u);
     max_G = std::max(max_G, s->jgroups);
     max_rows = std::max(max_rows, s->plan->max_rows);
     n_slots += (int)s->plan->n_tiles;
@@ -924,6 +1165,7 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
     d.U = s->U; d.V = s->V; d.xbuf = s->xbuf; d.gx = s->gx; d.dg = s->dg; d.upd = s->upd; d.part = s->part; d.coef = s->coef;
     d.nrm_part = s->nrm_part; d.jpart = s->jpart; d.rel_trace = s->rel_trace; d.abs_trace = s->abs_trace;
     d.ctx = p->d_ctx; d.h0p = s->h0p; d.prbp = s->prbp;
+    d.part2 = s->part2; d.nblk_u = s->nblk_u; d.npart_u = s->npart_u;
     base += (int)p->n_tiles;
   }
   BatchDesc* d_descs = nullptr;
@@ -953,6 +1195,15 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
     if (rc) { cleanup(); return rc; }
     const int k = it;
     const int kd = k >= thr ? 0 : k;
+    if (s0->uvu) {
+      const dim3 gu((unsigned)max_gu, 1, (unsigned)n);
+      if (kd > 0) VLAUNCH("k_sweep_u1", st, s0->vec_u, kb_sweep_u1, (gu, TB, 0, st), d_descs, kd);
+      LAUNCH("k_reduce_check", st, (kb_reduce_a_check<<<dim3((unsigned)std::max(kd, 1), 2, (unsigned)n), TB, 0, st>>>(d_descs, kd, eps)));
+      VLAUNCH("k_sweep_v", st, s0->vec_u, kb_sweep_v, (gu, TB, 0, st), d_descs, k);
+      if (k > 0) LAUNCH("k_reduce_cb", st, (kb_reduce_cb<<<dim3((unsigned)k, 2, (unsigned)n), TB, 0, st>>>(d_descs, k)));
+      VLAUNCH("k_sweep_u2", st, s0->vec_u, kb_sweep_u2, (gu, TB, 0, st), d_descs, k);
+      VLAUNCH("k_final", st, s0->vec_u, kb_final_u, (gu, TB, 0, st), d_descs, k);
+    } else {
     if (kd > 0)
       VLAUNCH("k_dots", st, s0->vec, kb_dots, (dim3((unsigned)max_g, (unsigned)max_G, (unsigned)n), TB, 0, st), d_descs, kd);
     LAUNCH("k_reduce_check", st, (kb_reduce_check<<<dim3((unsigned)std::max(kd, 1), 4, (unsigned)n), TB, 0, st>>>(d_descs, kd, eps)));
@@ -964,6 +1215,7 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
       if (max_G > 1 && k >= 4 * 2)   // some mesh may split from k = 4 * jgroups on (jgroups >= 2)
         VLAUNCH("k_axpy_combine", st, s0->vec, kb_axpy_combine, (dim3((unsigned)max_g, 1, (unsigned)n), TB, 0, st), d_descs, k);
       VLAUNCH("k_final", st, s0->vec, kb_final, (dim3((unsigned)max_g, 1, (unsigned)n), TB, 0, st), d_descs, k, 0);
+    }
     }
     if ((it + 1) % poll_every == 0 || it + 1 == thr) {
       kb_all_done<<<1, 64, 0, st>>>(d_descs, n, off_done, d_done);

@@ -9,7 +9,7 @@ for kernels whose traffic does not depend on k), which bench.py evaluates for wh
 
 Corrections follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: counters are in KiB; on gfx950 FETCH_SIZE
 reports exactly 1/2 of the bytes of wide (16 B/lane) coalesced streaming reads -> doubled for the
-streaming kernels (k_dots, k_axpy, k_resid, k_final, k_xnext: float4 loads only).  The tile kernel mixes
+streaming kernels (k_dots, k_axpy, k_sweep_*, k_resid, k_final, k_xnext: float4 loads only).  The tile kernel mixes
 16-byte slot loads with 8-byte row loads; its read side is reported raw (true value between raw and 2x raw).
 WRITE_SIZE is exact for 16-byte stores.
 """
@@ -38,9 +38,11 @@ def load(d, counter):
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 K, nodes = int(sys.argv[4]), int(sys.argv[5])
-STREAM = {"k_dots", "k_axpy", "k_resid", "k_final", "k_xnext"}
+STREAM = {"k_dots", "k_axpy", "k_resid", "k_final", "k_xnext", "k_sweep_u1", "k_sweep_v", "k_sweep_u2"}
+SWEEPS = ("k_dots", "k_axpy", "k_sweep_u1", "k_sweep_v", "k_sweep_u2")
 KS = {"k_dots": list(range(1, K)), "k_axpy": list(range(0, K)), "k_final": list(range(0, K)), "k_f_tile_fused": list(range(0, K)),
-      "k_reduce_check": list(range(0, K))}
+      "k_reduce_check": list(range(0, K)), "k_sweep_u1": list(range(1, K)), "k_sweep_v": list(range(0, K)),
+      "k_sweep_u2": list(range(0, K))}
 out = {}
 for k in sorted(set(fetch) | set(write)):
     f = np.array(fetch.get(k, [0.0])) * 1024.0
@@ -51,7 +53,7 @@ for k in sorted(set(fetch) | set(write)):
     ks = KS.get(k)
     if ks and n >= len(ks) and len(ks) >= 2:
         y = tot[-len(ks):]
-        b, a = np.polyfit(np.array(ks, dtype=float), y, 1) if k in ("k_dots", "k_axpy") else (0.0, float(np.mean(y)))
+        b, a = np.polyfit(np.array(ks, dtype=float), y, 1) if k in SWEEPS else (0.0, float(np.mean(y)))
         fit_n = len(ks)
     else:
         a, b, fit_n = float(np.mean(tot)), 0.0, n

@@ -109,6 +109,37 @@ def test_mixed_two_group_launch_at_natural_size(dev, monkeypatch):
     assert rel_l2(two, want) < 2e-6, rel_l2(two, want)
 
 
+def test_three_sweep_update_is_bitwise_identical(dev, monkeypatch):
+    """Long vectors run the Broyden update as three single-array sweeps (U for a; V once for c, b and V a; U for U c, U b:
+    csrc/solver.hip launch_update, k_sweep_u1 / _v / _u2) instead of two passes over both arrays.  Same arithmetic on every
+    element, same partial-sum shapes: every iterate, the traces and the adjoint solve are bit-identical to the two-pass form."""
+    data, solver, eng = pkg("data"), pkg("utilities.solver"), pkg("engine")
+    sd = load_weights("dirichlet")
+    mesh = data.make_hex_problem(data.hex_n_for_nodes(330000), seed=4, compute_sol=False)
+    md, h0, plan, fm = _fmap(mesh, sd, dev)
+    assert plan.N * 10 >= 768 * 4096          # long-vector regime: 16 floats per lane, no split over the stored pairs
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PSIGNN_UVU", mode)
+        out = solver.broyden(fm, fm.h0, threshold=14, eps=1e-12, keep_trace=True)
+        out["its"] = [out["xest_trace"][i].clone() for i in (1, 5, 13)]      # (the trace is read out of the solver lazily)
+        sv = eng.DeviceBroyden(fm.plan, 9, keep_trace=False)
+        gen = torch.Generator().manual_seed(3)
+        adj = sv.solve_adjoint(fm, out["result"], torch.randn(h0.shape, generator=gen).to(dev), 1e-12)
+        sv.close()
+        runs[mode] = (out, adj)
+    monkeypatch.delenv("PSIGNN_UVU")
+    (a, aa), (b, ba) = runs["1"], runs["0"]
+    assert a["n_iter"] == b["n_iter"] == 14
+    assert list(a["rel_trace"][:14]) == list(b["rel_trace"][:14]) and list(a["abs_trace"][:14]) == list(b["abs_trace"][:14])
+    assert torch.equal(a["result"], b["result"])
+    assert all(torch.equal(x, y) for x, y in zip(a["its"], b["its"]))
+    assert torch.equal(aa["result"], ba["result"]) and list(aa["rel_trace"][:9]) == list(ba["rel_trace"][:9])
+    # and the default at this size IS the three-sweep form: same bits without the variable
+    d = solver.broyden(fm, fm.h0, threshold=14, eps=1e-12, keep_trace=False)
+    assert torch.equal(d["result"], a["result"])
+
+
 def test_config3_shard_of_eight_50k_meshes(dev):
     """BASELINE configs[3]: one GPU's share of the 64 x 50k batch = 8 independent 50 311-node meshes.  The concurrent
     form (8 HIP streams / host threads) and the batched device solver give bit-identical results to solving the meshes
