@@ -106,7 +106,7 @@ def algorithmic_bytes(N, Ep, K, mixed):
     sweeps3 = {"k_sweep_u1": [(k + 1) * M * 4 for k in range(1, K)],          # k columns of U + dx
                "k_sweep_v": [(k + 4) * M * 4 for k in range(0, K)],           # k columns of V + dx, dg, g; writes V[k]
                "k_sweep_u2": [(k + 5) * M * 4 for k in range(0, K)]}          # k columns of U + dx, dg, g; writes U[k], update
-    total_iter3 = sum(12 * k * M + 56 * M + b_f for k in range(K)) + b_f      # + fused f's 16 M + k_final's 16 M
+    total_iter3 = sum(12 * k * M + 56 * M + b_f for k in range(K)) + b_f      # sweeps 12 k M + 40 M, fused f's extra 16 M (no k_final: merged into sweep 3)
     per_launch["_sweeps3"] = sweeps3
     per_launch["_total_iter3"] = total_iter3
     return per_launch, dots, axpy, total_iter

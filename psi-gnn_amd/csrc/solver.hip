@@ -458,22 +458,34 @@ __global__ __launch_bounds__(TB) void k_sweep_v(int64_t M, int k, const Status* 
   sweep_v_body<VEC>(M, k, st, V, dxv, dgv, gv, coef, part, npart, part2, nblk, ld);
 }
 
-// grid (k, 2): coef_c[j], coef_b[j]
-__device__ __forceinline__ void reduce_cb_body(const Status* __restrict__ st, const float* __restrict__ part, int npart, int thr,
-                                               int k, float* __restrict__ coef, double* sh) {
+// grid (max(k, 1), 3): blocks (j, 0 | 1): coef_c[j], coef_b[j]; block (0, 2): s = vT.dg, beta = vT.g from sweep 2's block partials
+// (fixed order, fp64, rounded to fp32 like the reference's .item() values -- what every block of k_final used to repeat)
+__device__ __forceinline__ void reduce_cb_body(Status* __restrict__ st, const float* __restrict__ part, int npart, int thr, int k,
+                                               float* __restrict__ coef, const float* __restrict__ part2, int nblk, double* sh) {
   if (st->done) return;
+  if (blockIdx.y == 2) {
+    if (blockIdx.x != 0) return;
+    const float sv = (float)block_sum_partials(part2, nblk, sh);
+    const float beta = (float)block_sum_partials(part2 + nblk, nblk, sh);
+    if (threadIdx.x == 0) {
+      st->s = (double)sv;
+      st->beta = (double)beta;
+    }
+    return;
+  }
   const int j = blockIdx.x, c = 1 + blockIdx.y;
   if (j >= k) return;
   const double s = block_sum_partials<4>(part + (int64_t)j * npart * 4 + c, npart, sh);
   if (threadIdx.x == 0) coef[c * thr + j] = (float)s;
 }
-__global__ __launch_bounds__(TB) void k_reduce_cb(const Status* __restrict__ st, const float* __restrict__ part, int npart, int thr,
-                                                  int k, float* __restrict__ coef) {
+__global__ __launch_bounds__(TB) void k_reduce_cb(Status* __restrict__ st, const float* __restrict__ part, int npart, int thr, int k,
+                                                  float* __restrict__ coef, const float* __restrict__ part2, int nblk) {
   __shared__ double sh[TB];
-  reduce_cb_body(st, part, npart, thr, k, coef, sh);
+  reduce_cb_body(st, part, npart, thr, k, coef, part2, nblk, sh);
 }
 
-// sweep 3: reads U once: D1 = dx + dg - sum_j c_j U_j -> U[k] (unscaled), D2 = g - sum_j b_j U_j -> upd
+// sweep 3: reads U once: D1 = dx + dg - sum_j c_j U_j, D2 = g - sum_j b_j U_j, and -- s and beta being known by now -- the
+// final step of the update in the same registers: u = D1 / s (NaN -> 0) -> U[k], update = D2 - u * beta (k_final's arithmetic)
 template <int VEC>
 __device__ __forceinline__ void sweep_u2_body(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
                                               float* __restrict__ upd, const float* __restrict__ dgv,
@@ -496,6 +508,14 @@ __device__ __forceinline__ void sweep_u2_body(int64_t M, int k, const Status* __
       a1[i] = fmaf(-cc, u[i], a1[i]);
       a2[i] = fmaf(-cb, u[i], a2[i]);
     }
+  }
+  const float sv = (float)st->s, beta = (float)st->beta;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    float q = a1[i] / sv;
+    q = (q != q) ? 0.f : q;
+    a1[i] = q;
+    a2[i] = fmaf(-q, beta, a2[i]);
   }
   stv<VEC>(U + (int64_t)k * ld, e0, M, a1);
   stv<VEC>(upd, e0, M, a2);
@@ -871,9 +891,8 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
         s->st, s->part, s->npart_u, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace)));
     if (k >= s->thr) return;
     VLAUNCH("k_sweep_v", st, s->vec_u, k_sweep_v, (gu, TB, 0, st), s->M, k, s->st, s->V, s->upd, s->dg, s->gx, s->coef, s->part, s->npart_u, s->part2, s->nblk_u, s->ld);
-    if (k > 0) LAUNCH("k_reduce_cb", st, (k_reduce_cb<<<dim3(k, 2), TB, 0, st>>>(s->st, s->part, s->npart_u, s->thr, k, s->coef)));
+    LAUNCH("k_reduce_cb", st, (k_reduce_cb<<<dim3(std::max(k, 1), 3), TB, 0, st>>>(s->st, s->part, s->npart_u, s->thr, k, s->coef, s->part2, s->nblk_u)));
     VLAUNCH("k_sweep_u2", st, s->vec_u, k_sweep_u2, (gu, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->ld);
-    VLAUNCH("k_final", st, s->vec_u, k_final, (gu, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->ld, s->part2, s->nblk_u);
     return;
   }
   // split of the sweeps over the stored pairs: only when there are enough pairs to share out
@@ -1095,20 +1114,13 @@ __global__ __launch_bounds__(TB) void kb_sweep_v(const BatchDesc* __restrict__ d
 __global__ __launch_bounds__(TB) void kb_reduce_cb(const BatchDesc* __restrict__ descs, int k) {
   __shared__ double sh[TB];
   const BatchDesc& d = descs[blockIdx.z];
-  reduce_cb_body(reinterpret_cast<const Status*>(d.st), d.part, d.npart_u, d.thr, k, d.coef, sh);
+  reduce_cb_body(reinterpret_cast<Status*>(d.st), d.part, d.npart_u, d.thr, k, d.coef, d.part2, d.nblk_u, sh);
 }
 template <int VEC>
 __global__ __launch_bounds__(TB) void kb_sweep_u2(const BatchDesc* __restrict__ descs, int k) {
   const BatchDesc& d = descs[blockIdx.z];
   if ((int)blockIdx.x >= d.nblk_u) return;
   sweep_u2_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, d.dg, d.gx, d.coef, d.thr, d.ld);
-}
-template <int VEC>
-__global__ __launch_bounds__(TB) void kb_final_u(const BatchDesc* __restrict__ descs, int k) {
-  __shared__ double sh[TB];
-  const BatchDesc& d = descs[blockIdx.z];
-  if ((int)blockIdx.x >= d.nblk_u) return;
-  final_body<VEC>(d.M, k, reinterpret_cast<Status*>(d.st), d.U, d.upd, d.ld, d.part2, d.nblk_u, sh);
 }
 // *all_done = 1 when every mesh's stop test has fired
 __global__ void kb_all_done(const BatchDesc* __restrict__ descs, int n, int off_done, int32_t* __restrict__ all_done) {
@@ -1200,9 +1212,8 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
       if (kd > 0) VLAUNCH("k_sweep_u1", st, s0->vec_u, kb_sweep_u1, (gu, TB, 0, st), d_descs, kd);
       LAUNCH("k_reduce_check", st, (kb_reduce_a_check<<<dim3((unsigned)std::max(kd, 1), 2, (unsigned)n), TB, 0, st>>>(d_descs, kd, eps)));
       VLAUNCH("k_sweep_v", st, s0->vec_u, kb_sweep_v, (gu, TB, 0, st), d_descs, k);
-      if (k > 0) LAUNCH("k_reduce_cb", st, (kb_reduce_cb<<<dim3((unsigned)k, 2, (unsigned)n), TB, 0, st>>>(d_descs, k)));
+      LAUNCH("k_reduce_cb", st, (kb_reduce_cb<<<dim3((unsigned)std::max(k, 1), 3, (unsigned)n), TB, 0, st>>>(d_descs, k)));
       VLAUNCH("k_sweep_u2", st, s0->vec_u, kb_sweep_u2, (gu, TB, 0, st), d_descs, k);
-      VLAUNCH("k_final", st, s0->vec_u, kb_final_u, (gu, TB, 0, st), d_descs, k);
     } else {
     if (kd > 0)
       VLAUNCH("k_dots", st, s0->vec, kb_dots, (dim3((unsigned)max_g, (unsigned)max_G, (unsigned)n), TB, 0, st), d_descs, kd);
