@@ -55,6 +55,7 @@ struct psignn_broyden {
   float* part2 = nullptr;     // three-sweep update: block partials of vT.dg, vT.g (2 * nblk floats)
   int uvu = 0;                // the update runs as three single-array sweeps U, V, U (broyden_alloc)
   int vec_u = 0, nblk_u = 0, npart_u = 0;   // their vector width / blocks / per-wave partials per stored pair
+  int u2d_kmax = 0, nblk4 = 0, a_ready = 0; // k_sweep_u2d: up to this many stored pairs; its blocks; a of the next iteration is already reduced-ready
   int nn_cap = 0;
   float *h0p = nullptr, *prbp = nullptr, *nrmp = nullptr;  // plan-order copies of h_initial, prb_data, normals
   float* part = nullptr;    // (3, thr, npart) dot partials; reused for the norm / s,beta partials
@@ -527,6 +528,92 @@ __global__ __launch_bounds__(TB) void k_sweep_u2(int64_t M, int k, const Status*
   sweep_u2_body<VEC>(M, k, st, U, upd, dgv, gv, coef, thr, ld);
 }
 
+// Sweep 3 with the NEXT iteration's first sweep folded in (k <= U2D_KMAX stored pairs).  a_j(next) = U_j . update_new needs
+// every U_j value twice: once to build update_new, once for the dot product with it.  For few stored pairs a thread can keep
+// the U_j values it streams -- 4 floats per pair -- in a private LDS slot (256 threads x 16 k bytes per block: registers by
+// another name, no sharing, no barrier) and take the dot products from there once its piece of update_new is finished:
+// the following iteration then needs no sweep over U for a (V and U read once each while k is small -- all of a K = 20
+// solve).  Direct dot products, exact; other partial-sum shapes than k_sweep_u1 (4 floats per lane here), so the last bits of
+// a differ from the three-sweep form's.  Writes the per-wave partials of a_0 .. a_k into slot 0 of rows 0 .. k of `part`.
+#ifndef U2D_UNROLL
+#define U2D_UNROLL 8   // stored pairs whose loads are in flight together (one wave per SIMD has to keep the memory pipe busy alone)
+#endif
+__global__ __launch_bounds__(TB) void k_sweep_u2d(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
+                                                  float* __restrict__ upd, const float* __restrict__ dgv,
+                                                  const float* __restrict__ gv, const float* __restrict__ coef, int thr,
+                                                  float* __restrict__ part, int npart4, int64_t ld) {
+  extern __shared__ __attribute__((aligned(16))) float4 keep[];   // keep[j * TB + tid] = this thread's 4 values of U_j
+  if (st->done) return;
+  const int64_t e0 = elem0<4>();
+  const bool act = e0 + 4 <= M;          // (M = 10 N: a multiple of... not of 4 in general -> the ragged last quad goes the slow way)
+  const bool tail = !act && e0 < M;
+  float a1[4], a2[4];
+  if (act || tail) {
+    float dg[4];
+    ldv<4>(upd, e0, M, a1);
+    ldv<4>(dgv, e0, M, dg);
+    ldv<4>(gv, e0, M, a2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a1[i] = a1[i] + dg[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a1[i] = a2[i] = 0.f;
+  }
+  const int tid = threadIdx.x;
+  int j = 0;
+  if (act) {
+    for (; j + U2D_UNROLL <= k; j += U2D_UNROLL) {
+      float4 u[U2D_UNROLL];
+#pragma unroll
+      for (int q = 0; q < U2D_UNROLL; ++q) u[q] = *reinterpret_cast<const float4*>(U + (int64_t)(j + q) * ld + e0);
+#pragma unroll
+      for (int q = 0; q < U2D_UNROLL; ++q) {
+        const float cc = coef[thr + j + q], cb = coef[2 * thr + j + q];
+        keep[(j + q) * TB + tid] = u[q];
+        a1[0] = fmaf(-cc, u[q].x, a1[0]); a1[1] = fmaf(-cc, u[q].y, a1[1]); a1[2] = fmaf(-cc, u[q].z, a1[2]); a1[3] = fmaf(-cc, u[q].w, a1[3]);
+        a2[0] = fmaf(-cb, u[q].x, a2[0]); a2[1] = fmaf(-cb, u[q].y, a2[1]); a2[2] = fmaf(-cb, u[q].z, a2[2]); a2[3] = fmaf(-cb, u[q].w, a2[3]);
+      }
+    }
+  }
+  for (; j < k; ++j) {
+    float u[4] = {0.f, 0.f, 0.f, 0.f};
+    const float cc = coef[thr + j], cb = coef[2 * thr + j];
+    if (act || tail) ldv<4>(U + (int64_t)j * ld, e0, M, u);
+    keep[j * TB + tid] = make_float4(u[0], u[1], u[2], u[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a1[i] = fmaf(-cc, u[i], a1[i]);
+      a2[i] = fmaf(-cb, u[i], a2[i]);
+    }
+  }
+  if (act || tail) {
+    const float sv = (float)st->s, beta = (float)st->beta;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float q = a1[i] / sv;
+      q = (q != q) ? 0.f : q;
+      a1[i] = q;
+      a2[i] = fmaf(-q, beta, a2[i]);
+    }
+    stv<4>(U + (int64_t)k * ld, e0, M, a1);
+    stv<4>(upd, e0, M, a2);
+    if (tail) {   // lanes past the end contribute nothing to the dot products
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (e0 + i >= M) a1[i] = a2[i] = 0.f;
+    }
+  }
+  // a_j(next) = U_j . update_new for j <= k (U_k = a1, update_new = a2)
+  const int w = blockIdx.x * (TB / 64) + (tid >> 6);
+  const bool lead = (tid & 63) == 0;
+  for (int jj = 0; jj <= k; ++jj) {
+    float4 u = jj < k ? keep[jj * TB + tid] : make_float4(a1[0], a1[1], a1[2], a1[3]);
+    float sa = fmaf(u.x, a2[0], fmaf(u.y, a2[1], fmaf(u.z, a2[2], u.w * a2[3])));
+    sa = wave_sum(sa);
+    if (lead) part[((int64_t)jj * npart4 + w) * 4] = sa;
+  }
+}
+
 // axpy pass.  Writes vT (NaN->0) to V[k], D1 to U[k] (unscaled), D2 to upd, partials of vT.dg, vT.g.
 // gridDim.y == 1: the whole sum over j in one block column.  gridDim.y > 1 (short vectors): block row y sums its
 // j-range into jpart[y][3][M] and k_axpy_combine finishes -- fixed grouping, so still reproducible.
@@ -757,6 +844,9 @@ static int broyden_alloc(psignn_broyden* s) {
     if (const char* e = getenv("PSIGNN_UVU")) if (atoi(e) == 0) s->uvu = 0;
   }
   s->npart_u = s->nblk_u * (TB / 64);
+  s->nblk4 = (int)cdiv(s->M, (int64_t)4 * TB);
+  s->u2d_kmax = (s->uvu && s->vec_u == 16) ? 24 : 0;   // 96 KB of LDS per block at most; 20 ... 32 measure alike at K = 50, K = 20 needs >= 19
+  if (const char* e = getenv("PSIGNN_U2D_KMAX")) s->u2d_kmax = (s->uvu && s->vec_u == 16) ? std::max(0, std::min(38, atoi(e))) : 0;
   s->nn_cap = std::max<int>(std::max(s->nblk, s->nblk_ax), s->plan ? (int)s->plan->n_tiles : 0);
   size_t nx = s->keep_trace ? thr + 2 : 3;
   s->ld = (s->M + 63) / 64 * 64;  // row pitch of U and V: every stored vector starts on a 256-byte boundary
@@ -764,7 +854,7 @@ static int broyden_alloc(psignn_broyden* s) {
   struct { void** p; size_t n; } allocs[] = {
       {(void**)&s->U, thr * ld * 4},  {(void**)&s->V, thr * ld * 4},   {(void**)&s->xbuf, nx * M * 4},
       {(void**)&s->gx, M * 4},        {(void**)&s->dg, M * 4},        {(void**)&s->upd, M * 4},
-      {(void**)&s->fx, M * 4},        {(void**)&s->part, 4 * thr * (size_t)std::max(s->npart, s->npart_u) * 4 + 16},
+      {(void**)&s->fx, M * 4},        {(void**)&s->part, std::max(4 * thr * (size_t)std::max(s->npart, s->npart_u), (size_t)4 * (s->u2d_kmax + 2) * s->nblk4 * (TB / 64)) * 4 + 16},
       {(void**)&s->coef, 3 * thr * 4 + 16}, {(void**)&s->st, sizeof(Status)},
       {(void**)&s->nrm_part, 2 * (size_t)s->nn_cap * 4 + 16}, {(void**)&s->part2, 2 * (size_t)std::max(s->nblk, s->nblk_u) * 4 + 16},
       {(void**)&s->rel_trace, thr * 8 + 8}, {(void**)&s->abs_trace, thr * 8 + 8}};
@@ -885,14 +975,28 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
   if (s->uvu) {
     const int kd = k >= s->thr ? 0 : k;
     const unsigned gu = (unsigned)s->nblk_u;
-    if (kd > 0)
+    if (k == 0) s->a_ready = 0;
+    const int np_a = s->a_ready ? s->nblk4 * (TB / 64) : s->npart_u;   // who wrote the partials of a: k_sweep_u2d of the last iteration, or sweep 1
+    if (kd > 0 && !s->a_ready)
       VLAUNCH("k_sweep_u1", st, s->vec_u, k_sweep_u1, (gu, TB, 0, st), s->M, kd, s->st, s->U, s->upd, s->part, s->npart_u, s->ld);
     LAUNCH("k_reduce_check", st, (k_reduce_a_check<<<dim3(std::max(kd, 1), 2), TB, 0, st>>>(
-        s->st, s->part, s->npart_u, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace)));
+        s->st, s->part, np_a, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace)));
+    s->a_ready = 0;
     if (k >= s->thr) return;
     VLAUNCH("k_sweep_v", st, s->vec_u, k_sweep_v, (gu, TB, 0, st), s->M, k, s->st, s->V, s->upd, s->dg, s->gx, s->coef, s->part, s->npart_u, s->part2, s->nblk_u, s->ld);
     LAUNCH("k_reduce_cb", st, (k_reduce_cb<<<dim3(std::max(k, 1), 3), TB, 0, st>>>(s->st, s->part, s->npart_u, s->thr, k, s->coef, s->part2, s->nblk_u)));
-    VLAUNCH("k_sweep_u2", st, s->vec_u, k_sweep_u2, (gu, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->ld);
+    if (k <= s->u2d_kmax && k + 1 < s->thr) {   // few stored pairs: sweep 3 keeps them and delivers the next iteration's a as well
+      const size_t lds = (size_t)std::max(k, 1) * TB * 16;
+      static const bool lds_ok = [] {   // more than 64 KB of dynamic LDS has to be asked for once
+        return hipFuncSetAttribute((const void*)k_sweep_u2d, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+      }();
+      (void)lds_ok;
+      LAUNCH("k_sweep_u2d", st, (k_sweep_u2d<<<(unsigned)s->nblk4, TB, lds, st>>>(s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->part,
+                                                                                  s->nblk4 * (TB / 64), s->ld)));
+      s->a_ready = 1;
+    } else {
+      VLAUNCH("k_sweep_u2", st, s->vec_u, k_sweep_u2, (gu, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->ld);
+    }
     return;
   }
   // split of the sweeps over the stored pairs: only when there are enough pairs to share out
@@ -1353,6 +1457,7 @@ extern "C" int psignn_broyden_ext_trial_x(psignn_broyden_t* s, double step, floa
 extern "C" int psignn_broyden_ext_scale_step(psignn_broyden_t* s, double step, void* stream) {
   ARG_CHECK(s, "NULL argument");
   VPLAIN(s->vec, k_xtrial, ((unsigned)s->nblk, TB, 0, (hipStream_t)stream), s->M, s->st, s->xbuf, s->upd, (float)step, nullptr, 1);
+  s->a_ready = 0;   // the update changed: a = U^T dx has to be swept again
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }

@@ -119,6 +119,7 @@ def test_three_sweep_update_is_bitwise_identical(dev, monkeypatch):
     md, h0, plan, fm = _fmap(mesh, sd, dev)
     assert plan.N * 10 >= 768 * 4096          # long-vector regime: 16 floats per lane, no split over the stored pairs
     runs = {}
+    monkeypatch.setenv("PSIGNN_U2D_KMAX", "0")      # (the folded form of sweep 3 has other partial-sum shapes: compared below)
     for mode in ("1", "0"):
         monkeypatch.setenv("PSIGNN_UVU", mode)
         out = solver.broyden(fm, fm.h0, threshold=14, eps=1e-12, keep_trace=True)
@@ -138,6 +139,13 @@ def test_three_sweep_update_is_bitwise_identical(dev, monkeypatch):
     # and the default at this size IS the three-sweep form: same bits without the variable
     d = solver.broyden(fm, fm.h0, threshold=14, eps=1e-12, keep_trace=False)
     assert torch.equal(d["result"], a["result"])
+    # default build: while there are few stored pairs, sweep 3 keeps the U values it streams and delivers the next iteration's
+    # a = U^T dx itself (k_sweep_u2d: direct dot products over other partial-sum shapes) -- same trajectory up to rounding
+    monkeypatch.delenv("PSIGNN_U2D_KMAX")
+    e = solver.broyden(fm, fm.h0, threshold=14, eps=1e-12, keep_trace=True)
+    np.testing.assert_allclose(e["rel_trace"][:8], a["rel_trace"][:8], rtol=1e-5)
+    np.testing.assert_allclose(e["rel_trace"][:14], a["rel_trace"][:14], rtol=2e-2)
+    assert rel_l2(e["xest_trace"][5], a["its"][1]) < 1e-5
 
 
 def test_config3_shard_of_eight_50k_meshes(dev):
