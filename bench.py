@@ -98,15 +98,32 @@ def algorithmic_bytes(N, Ep, K, mixed):
     }
     # k-dependent sweeps: iteration it (0-based) has k = it stored pairs
     dots = [2 * k * M * 4 + 3 * M * 4 for k in range(1, K)]     # launched only when k > 0
-    axpy = [2 * k * M * 4 + 6 * M * 4 for k in range(0, K)]
+    axpy = [2 * k * M * 4 + 6 * M * 4 for k in range(0, K - 1)]  # (iteration K's stop test fires first: its axpy / final return at once)
     per_launch["f_fused"] = b_f + 16 * M                        # + upd, g_old reads; g, dg writes (x_next replaces f(x))
     # whole iteration, BASELINE.md: B_broyden(k) = 16 k M + 48 M + B_f  (U and V swept twice, ~12 state-vector passes)
-    total_iter = sum(16 * k * M + 48 * M + b_f for k in range(K)) + b_f
-    # three-sweep form of the update (csrc/solver.hip launch_update, long vectors): U for a; V ONCE for c, b and V a; U for U c, U b
-    sweeps3 = {"k_sweep_u1": [(k + 1) * M * 4 for k in range(1, K)],          # k columns of U + dx
-               "k_sweep_v": [(k + 4) * M * 4 for k in range(0, K)],           # k columns of V + dx, dg, g; writes V[k]
-               "k_sweep_u2": [(k + 5) * M * 4 for k in range(0, K)]}          # k columns of U + dx, dg, g; writes U[k], update
-    total_iter3 = sum(12 * k * M + 56 * M + b_f for k in range(K)) + b_f      # sweeps 12 k M + 40 M, fused f's extra 16 M (no k_final: merged into sweep 3)
+    total_iter = sum(16 * k * M + 48 * M + b_f for k in range(K)) + b_f - (8 * (K - 1) * M + 40 * M)   # (minus the last iteration's axpy + final)
+    # three-sweep form of the update (csrc/solver.hip launch_update, long vectors): U for a; V ONCE for c, b and V a; U for U c, U b.
+    # While there are few stored pairs (k <= KMAX) sweep 3 is k_sweep_u2d, which also delivers the next iteration's a: that
+    # iteration then launches no k_sweep_u1.
+    KMAX = int(os.environ.get("PSIGNN_U2D_KMAX", "24"))
+
+    def sweeps3_for(kmax):
+        u2d_ks = [k for k in range(0, K) if k <= kmax and k + 1 < K]
+        u2_ks = [k for k in range(0, K) if k not in u2d_ks]
+        u1_ks = [k for k in range(1, K) if (k - 1) not in u2d_ks]
+        # iteration K's stop test (threshold) fires in front of its sweeps 2 and 3: those two launches return at once and move nothing
+        u2_ks = [k for k in u2_ks if k < K - 1]
+        byts = {"k_sweep_u1": [(k + 1) * M * 4 for k in u1_ks],                # k columns of U + dx
+                "k_sweep_v": [(k + 4) * M * 4 for k in range(0, K - 1)],       # k columns of V + dx, dg, g; writes V[k]
+                "k_sweep_u2": [(k + 5) * M * 4 for k in u2_ks],                # k columns of U + dx, dg, g; writes U[k], update
+                "k_sweep_u2d": [(k + 5) * M * 4 for k in u2d_ks]}
+        ks = {"k_sweep_u1": u1_ks, "k_sweep_v": list(range(0, K - 1)), "k_sweep_u2": u2_ks, "k_sweep_u2d": u2d_ks}
+        # sweeps + fused f's extra 16 M (no k_final: merged into sweep 3)
+        return byts, ks, sum(sum(v) for v in byts.values()) + K * (16 * M + b_f) + b_f
+    sweeps3, ks3, total_iter3 = sweeps3_for(-1)          # plain three-sweep form (mid-size vectors, batched shards)
+    sweeps3d, ks3d, total_iter3d = sweeps3_for(KMAX)     # long vectors: folded sweep 3 while k <= KMAX
+    per_launch["_sweeps3d"], per_launch["_sweeps3d_ks"], per_launch["_total_iter3d"] = sweeps3d, ks3d, total_iter3d
+    per_launch["_sweeps3_ks"] = ks3
     per_launch["_sweeps3"] = sweeps3
     per_launch["_total_iter3"] = total_iter3
     return per_launch, dots, axpy, total_iter
@@ -289,11 +306,12 @@ def main():
     # long vectors run the update as three single-array sweeps (csrc/solver.hip broyden_alloc: 16 floats per lane, no split):
     # the iteration's algorithmic bytes are then 12 k M + 56 M + B_f
     if MPG == 1 and N * D >= 768 * 4096 and os.environ.get("PSIGNN_UVU", "1") != "0":
-        tb3 = per_launch["_total_iter3"]
+        tb3 = per_launch["_total_iter3d"]
         result["roofline_iter"].update({
             "achieved": tb3 / elapsed / 1e9, "frac": tb3 / elapsed / 1e9 / HBM_PEAK_GBS,
             "note": "sum of algorithmic bytes of all kernels in the K iterations / wall time of this rank; the update runs as three "
-                    "single-array sweeps (12 k M + 56 M + B_f bytes per iteration instead of BASELINE.md's 16 k M + 48 M + B_f)",
+                    "single-array sweeps (12 k M + 56 M + B_f bytes per iteration instead of BASELINE.md's 16 k M + 48 M + B_f), two "
+                    "(8 k M + 52 M + B_f) while there are few stored pairs",
             "frac_by_the_two_pass_formula": total_iter_bytes / elapsed / 1e9 / HBM_PEAK_GBS})
 
     # ---- per-kernel durations: HIP events on the launch stream, instrumented repeat of the same K steps
@@ -321,10 +339,12 @@ def main():
             if name in prof:
                 kern[name] = (prof[name][0], prof[name][1], per_launch[name] * prof[name][0] * nmesh_launch)
         if "k_sweep_v" in prof:   # three-sweep update: its own algorithmic bytes, and the iteration's total with them
-            for name, lst in per_launch["_sweeps3"].items():
+            folded = "k_sweep_u2d" in prof
+            for name, lst in per_launch["_sweeps3d" if folded else "_sweeps3"].items():
                 if name in prof:
                     kern[name] = (prof[name][0], prof[name][1], sum(lst) * nmesh_launch)
-            tb3 = per_launch["_total_iter3"]
+            tb3 = per_launch["_total_iter3d" if folded else "_total_iter3"]
+            per_launch["_ks_used"] = per_launch["_sweeps3d_ks" if folded else "_sweeps3_ks"]
             result["roofline_iter"].update({
                 "achieved": MPG * tb3 / elapsed / 1e9, "frac": MPG * tb3 / elapsed / 1e9 / HBM_PEAK_GBS,
                 "note": "sum of algorithmic bytes of all kernels in the K iterations / wall time of this rank; the update runs as three "
@@ -369,8 +389,7 @@ def main():
             try:
                 t = json.load(open(pmc))
                 if t.get("_nodes") == N:
-                    ks = {"k_dots": range(1, K), "k_axpy": range(0, K), "k_sweep_u1": range(1, K), "k_sweep_v": range(0, K),
-                          "k_sweep_u2": range(0, K)}
+                    ks = {"k_dots": range(1, K), "k_axpy": range(0, K), **per_launch.get("_ks_used", per_launch["_sweeps3_ks"])}
                     for key, row in (("roofline", dom), ("roofline_f", fr)):
                         e = t["kernels"].get(row["kernel"])
                         if e:

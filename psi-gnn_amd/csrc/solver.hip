@@ -56,6 +56,7 @@ struct psignn_broyden {
   int uvu = 0;                // the update runs as three single-array sweeps U, V, U (broyden_alloc)
   int vec_u = 0, nblk_u = 0, npart_u = 0;   // their vector width / blocks / per-wave partials per stored pair
   int u2d_kmax = 0, nblk4 = 0, a_ready = 0; // k_sweep_u2d: up to this many stored pairs; its blocks; a of the next iteration is already reduced-ready
+  float* parta = nullptr;                   // its per-wave partials of a, contiguous per stored pair: (u2d_kmax + 2, nblk4 * 4)
   int nn_cap = 0;
   float *h0p = nullptr, *prbp = nullptr, *nrmp = nullptr;  // plan-order copies of h_initial, prb_data, normals
   float* part = nullptr;    // (3, thr, npart) dot partials; reused for the norm / s,beta partials
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(TB) void k_sweep_u1(int64_t M, int k, const Status*
 __device__ __forceinline__ void reduce_a_check_body(Status* st, const float* __restrict__ part, int npart, int thr, int k,
                                                     float* __restrict__ coef, const float* __restrict__ nrm_part, int nn,
                                                     double* __restrict__ rel_trace, double* __restrict__ abs_trace,
-                                                    double eps, int seq_len, int keep_trace, double* sh) {
+                                                    double eps, int seq_len, int keep_trace, double* sh, int contig = 0) {
   if (blockIdx.y == 1) {
     if (blockIdx.x == 0) check_block(st, nrm_part, nn, rel_trace, abs_trace, eps, thr, seq_len, keep_trace, sh);
     return;
@@ -387,15 +388,16 @@ __device__ __forceinline__ void reduce_a_check_body(Status* st, const float* __r
   if (st->done) return;
   const int j = blockIdx.x;
   if (j >= k) return;
-  const double s = block_sum_partials<4>(part + (int64_t)j * npart * 4, npart, sh);
+  const double s = contig ? block_sum_partials<1>(part + (int64_t)j * npart, npart, sh)      // k_sweep_u2d's layout
+                          : block_sum_partials<4>(part + (int64_t)j * npart * 4, npart, sh);
   if (threadIdx.x == 0) coef[j] = (float)s;
 }
 __global__ __launch_bounds__(TB) void k_reduce_a_check(Status* st, const float* __restrict__ part, int npart, int thr, int k,
                                                        float* __restrict__ coef, const float* __restrict__ nrm_part, int nn,
                                                        double* __restrict__ rel_trace, double* __restrict__ abs_trace,
-                                                       double eps, int seq_len, int keep_trace) {
+                                                       double eps, int seq_len, int keep_trace, int contig) {
   __shared__ double sh[TB];
-  reduce_a_check_body(st, part, npart, thr, k, coef, nrm_part, nn, rel_trace, abs_trace, eps, seq_len, keep_trace, sh);
+  reduce_a_check_body(st, part, npart, thr, k, coef, nrm_part, nn, rel_trace, abs_trace, eps, seq_len, keep_trace, sh, contig);
 }
 
 // sweep 2: reads V once: partials of c_j = V_j.dg, b_j = V_j.g AND vT = -dx + sum_j a_j V_j; then vT's part of axpy_finish
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(TB) void k_sweep_u2(int64_t M, int k, const Status*
 // another name, no sharing, no barrier) and take the dot products from there once its piece of update_new is finished:
 // the following iteration then needs no sweep over U for a (V and U read once each while k is small -- all of a K = 20
 // solve).  Direct dot products, exact; other partial-sum shapes than k_sweep_u1 (4 floats per lane here), so the last bits of
-// a differ from the three-sweep form's.  Writes the per-wave partials of a_0 .. a_k into slot 0 of rows 0 .. k of `part`.
+// a differ from the three-sweep form's.  Writes the per-wave partials of a_0 .. a_k contiguously: part[j * npart4 + wave].
 #ifndef U2D_UNROLL
 #define U2D_UNROLL 8   // stored pairs whose loads are in flight together (one wave per SIMD has to keep the memory pipe busy alone)
 #endif
@@ -610,7 +612,7 @@ __global__ __launch_bounds__(TB) void k_sweep_u2d(int64_t M, int k, const Status
     float4 u = jj < k ? keep[jj * TB + tid] : make_float4(a1[0], a1[1], a1[2], a1[3]);
     float sa = fmaf(u.x, a2[0], fmaf(u.y, a2[1], fmaf(u.z, a2[2], u.w * a2[3])));
     sa = wave_sum(sa);
-    if (lead) part[((int64_t)jj * npart4 + w) * 4] = sa;
+    if (lead) part[(int64_t)jj * npart4 + w] = sa;
   }
 }
 
@@ -854,7 +856,7 @@ static int broyden_alloc(psignn_broyden* s) {
   struct { void** p; size_t n; } allocs[] = {
       {(void**)&s->U, thr * ld * 4},  {(void**)&s->V, thr * ld * 4},   {(void**)&s->xbuf, nx * M * 4},
       {(void**)&s->gx, M * 4},        {(void**)&s->dg, M * 4},        {(void**)&s->upd, M * 4},
-      {(void**)&s->fx, M * 4},        {(void**)&s->part, std::max(4 * thr * (size_t)std::max(s->npart, s->npart_u), (size_t)4 * (s->u2d_kmax + 2) * s->nblk4 * (TB / 64)) * 4 + 16},
+      {(void**)&s->fx, M * 4},        {(void**)&s->part, 4 * thr * (size_t)std::max(s->npart, s->npart_u) * 4 + 16}, {(void**)&s->parta, (size_t)(s->u2d_kmax + 2) * s->nblk4 * (TB / 64) * 4 + 16},
       {(void**)&s->coef, 3 * thr * 4 + 16}, {(void**)&s->st, sizeof(Status)},
       {(void**)&s->nrm_part, 2 * (size_t)s->nn_cap * 4 + 16}, {(void**)&s->part2, 2 * (size_t)std::max(s->nblk, s->nblk_u) * 4 + 16},
       {(void**)&s->rel_trace, thr * 8 + 8}, {(void**)&s->abs_trace, thr * 8 + 8}};
@@ -897,7 +899,7 @@ static int broyden_alloc(psignn_broyden* s) {
 
 extern "C" void psignn_broyden_destroy(psignn_broyden_t* s) {
   if (!s) return;
-  void* ptrs[] = {s->U, s->V, s->xbuf, s->gx, s->dg, s->upd, s->fx, s->fwork, s->part, s->coef, s->st, s->nrm_part, s->part2,
+  void* ptrs[] = {s->U, s->V, s->xbuf, s->gx, s->dg, s->upd, s->fx, s->fwork, s->part, s->coef, s->st, s->nrm_part, s->part2, s->parta,
                   s->rel_trace, s->abs_trace, s->h0p, s->prbp, s->nrmp, s->jpart};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -980,7 +982,8 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
     if (kd > 0 && !s->a_ready)
       VLAUNCH("k_sweep_u1", st, s->vec_u, k_sweep_u1, (gu, TB, 0, st), s->M, kd, s->st, s->U, s->upd, s->part, s->npart_u, s->ld);
     LAUNCH("k_reduce_check", st, (k_reduce_a_check<<<dim3(std::max(kd, 1), 2), TB, 0, st>>>(
-        s->st, s->part, np_a, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace)));
+        s->st, s->a_ready ? s->parta : s->part, np_a, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len,
+        s->keep_trace, s->a_ready)));
     s->a_ready = 0;
     if (k >= s->thr) return;
     VLAUNCH("k_sweep_v", st, s->vec_u, k_sweep_v, (gu, TB, 0, st), s->M, k, s->st, s->V, s->upd, s->dg, s->gx, s->coef, s->part, s->npart_u, s->part2, s->nblk_u, s->ld);
@@ -991,7 +994,7 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
         return hipFuncSetAttribute((const void*)k_sweep_u2d, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       }();
       (void)lds_ok;
-      LAUNCH("k_sweep_u2d", st, (k_sweep_u2d<<<(unsigned)s->nblk4, TB, lds, st>>>(s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->part,
+      LAUNCH("k_sweep_u2d", st, (k_sweep_u2d<<<(unsigned)s->nblk4, TB, lds, st>>>(s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->parta,
                                                                                   s->nblk4 * (TB / 64), s->ld)));
       s->a_ready = 1;
     } else {

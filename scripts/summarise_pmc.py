@@ -38,11 +38,14 @@ def load(d, counter):
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 K, nodes = int(sys.argv[4]), int(sys.argv[5])
-STREAM = {"k_dots", "k_axpy", "k_resid", "k_final", "k_xnext", "k_sweep_u1", "k_sweep_v", "k_sweep_u2"}
-SWEEPS = ("k_dots", "k_axpy", "k_sweep_u1", "k_sweep_v", "k_sweep_u2")
+STREAM = {"k_dots", "k_axpy", "k_resid", "k_final", "k_xnext", "k_sweep_u1", "k_sweep_v", "k_sweep_u2", "k_sweep_u2d"}
+SWEEPS = ("k_dots", "k_axpy", "k_sweep_u1", "k_sweep_v", "k_sweep_u2", "k_sweep_u2d")
+import os
+KMAX = int(os.environ.get("PSIGNN_U2D_KMAX", "24"))          # as bench.py: which sweep-3 form / whether sweep 1 ran at each k
+_u2d = [k for k in range(0, K) if k <= KMAX and k + 1 < K]
 KS = {"k_dots": list(range(1, K)), "k_axpy": list(range(0, K)), "k_final": list(range(0, K)), "k_f_tile_fused": list(range(0, K)),
-      "k_reduce_check": list(range(0, K)), "k_sweep_u1": list(range(1, K)), "k_sweep_v": list(range(0, K)),
-      "k_sweep_u2": list(range(0, K))}
+      "k_reduce_check": list(range(0, K)), "k_sweep_u1": [k for k in range(1, K) if (k - 1) not in _u2d], "k_sweep_v": list(range(0, K)),
+      "k_sweep_u2": [k for k in range(0, K) if k not in _u2d], "k_sweep_u2d": _u2d}
 out = {}
 for k in sorted(set(fetch) | set(write)):
     f = np.array(fetch.get(k, [0.0])) * 1024.0
@@ -53,6 +56,8 @@ for k in sorted(set(fetch) | set(write)):
     ks = KS.get(k)
     if ks and n >= len(ks) and len(ks) >= 2:
         y = tot[-len(ks):]
+        if k in SWEEPS and k not in ("k_sweep_u1", "k_dots") and ks[-1] == K - 1:
+            ks, y = ks[:-1], y[:-1]    # iteration K's stop test fires in front of these sweeps: the last launch moves nothing
         b, a = np.polyfit(np.array(ks, dtype=float), y, 1) if k in SWEEPS else (0.0, float(np.mean(y)))
         fit_n = len(ks)
     else:
