@@ -388,7 +388,7 @@ __device__ __forceinline__ void reduce_a_check_body(Status* st, const float* __r
   if (st->done) return;
   const int j = blockIdx.x;
   if (j >= k) return;
-  const double s = contig ? block_sum_partials<1>(part + (int64_t)j * npart, npart, sh)      // k_sweep_u2d's layout
+  const double s = contig ? block_sum_contig(part + (int64_t)j * npart, npart, sh)            // k_sweep_u2d's layout
                           : block_sum_partials<4>(part + (int64_t)j * npart * 4, npart, sh);
   if (threadIdx.x == 0) coef[j] = (float)s;
 }

@@ -135,6 +135,35 @@ __device__ inline double block_sum_partials(const float* __restrict__ p, int n, 
   return r;
 }
 
+// Sum of n CONTIGUOUS float partials (n a multiple of 4, 16-byte aligned), fixed shape: a thread takes every TB-th quad, four quads in
+// flight per trip (tens of thousands of partials per coefficient: the trip count, not the bytes, is what such a reduction waits for).
+__device__ inline double block_sum_contig(const float* __restrict__ p, int n, double* sh) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+  const int nq = n >> 2;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * TB < nq; i += 4 * TB) {
+    const float4 a = q[i], b = q[i + TB], c = q[i + 2 * TB], d = q[i + 3 * TB];
+    s0 += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+    s1 += ((double)b.x + (double)b.y) + ((double)b.z + (double)b.w);
+    s2 += ((double)c.x + (double)c.y) + ((double)c.z + (double)c.w);
+    s3 += ((double)d.x + (double)d.y) + ((double)d.z + (double)d.w);
+  }
+  for (; i < nq; i += TB) {
+    const float4 a = q[i];
+    s0 += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+  }
+  sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  for (int o = TB / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
 // launch a VEC-templated kernel with the solver's vector width
 #define VPLAIN(vec, kern, cfg, ...)                                     \
   do {                                                                  \
