@@ -107,20 +107,25 @@ def algorithmic_bytes(N, Ep, K, mixed):
     # iteration then launches no k_sweep_u1.
     KMAX = int(os.environ.get("PSIGNN_U2D_KMAX", "24"))
 
+    KEEP = int(os.environ.get("PSIGNN_U2D_KEEP", "16"))
+
     def sweeps3_for(kmax):
-        u2d_ks = [k for k in range(0, K) if k <= kmax and k + 1 < K]
-        u2_ks = [k for k in range(0, K) if k not in u2d_ks]
-        u1_ks = [k for k in range(1, K) if (k - 1) not in u2d_ks]
-        # iteration K's stop test (threshold) fires in front of its sweeps 2 and 3: those two launches return at once and move nothing
-        u2_ks = [k for k in u2_ks if k < K - 1]
-        byts = {"k_sweep_u1": [(k + 1) * M * 4 for k in u1_ks],                # k columns of U + dx
+        # sweep 3 of iteration k (k stored pairs): the folded kernel keeps the pairs from keep0(k) on (all of them while k <= kmax,
+        # the most recent KEEP afterwards) and delivers their a_j for iteration k + 1, whose sweep 1 then covers keep0(k) pairs only
+        folded = [kmax >= -1 and k + 1 < K and (k <= kmax or KEEP > 0) and kmax > 0 for k in range(K)]
+        keep0 = [(0 if k <= kmax else k - KEEP) if folded[k] else k + 1 for k in range(K)]
+        u1_cols = {k: (keep0[k - 1] if folded[k - 1] else k) for k in range(1, K)}
+        u1_ks = [c for k, c in u1_cols.items() if c > 0]                       # regressor of sweep 1: the pairs it reads
+        u2d_ks = [k for k in range(K) if folded[k]]
+        u2_ks = [k for k in range(K - 1) if not folded[k]]                     # (iteration K's stop test fires in front of its sweeps 2 and 3)
+        byts = {"k_sweep_u1": [(c + 1) * M * 4 for c in u1_ks],                # its columns of U + dx
                 "k_sweep_v": [(k + 4) * M * 4 for k in range(0, K - 1)],       # k columns of V + dx, dg, g; writes V[k]
                 "k_sweep_u2": [(k + 5) * M * 4 for k in u2_ks],                # k columns of U + dx, dg, g; writes U[k], update
                 "k_sweep_u2d": [(k + 5) * M * 4 for k in u2d_ks]}
         ks = {"k_sweep_u1": u1_ks, "k_sweep_v": list(range(0, K - 1)), "k_sweep_u2": u2_ks, "k_sweep_u2d": u2d_ks}
         # sweeps + fused f's extra 16 M (no k_final: merged into sweep 3)
         return byts, ks, sum(sum(v) for v in byts.values()) + K * (16 * M + b_f) + b_f
-    sweeps3, ks3, total_iter3 = sweeps3_for(-1)          # plain three-sweep form (mid-size vectors, batched shards)
+    sweeps3, ks3, total_iter3 = sweeps3_for(-2)          # plain three-sweep form (mid-size vectors, batched shards)
     sweeps3d, ks3d, total_iter3d = sweeps3_for(KMAX)     # long vectors: folded sweep 3 while k <= KMAX
     per_launch["_sweeps3d"], per_launch["_sweeps3d_ks"], per_launch["_total_iter3d"] = sweeps3d, ks3d, total_iter3d
     per_launch["_sweeps3_ks"] = ks3

@@ -55,7 +55,8 @@ struct psignn_broyden {
   float* part2 = nullptr;     // three-sweep update: block partials of vT.dg, vT.g (2 * nblk floats)
   int uvu = 0;                // the update runs as three single-array sweeps U, V, U (broyden_alloc)
   int vec_u = 0, nblk_u = 0, npart_u = 0;   // their vector width / blocks / per-wave partials per stored pair
-  int u2d_kmax = 0, nblk4 = 0, a_ready = 0; // k_sweep_u2d: up to this many stored pairs; its blocks; a of the next iteration is already reduced-ready
+  int u2d_kmax = 0, nblk4 = 0, a_ready = 0; // k_sweep_u2d: up to this many stored pairs are all kept; its blocks; a of the next iteration comes (partly) from it
+  int u2d_keep = 0, a_from = 0;             // beyond u2d_kmax: the most recent u2d_keep pairs are kept; pairs before a_from still need sweep 1
   float* parta = nullptr;                   // its per-wave partials of a, contiguous per stored pair: (u2d_kmax + 2, nblk4 * 4)
   int nn_cap = 0;
   float *h0p = nullptr, *prbp = nullptr, *nrmp = nullptr;  // plan-order copies of h_initial, prb_data, normals
@@ -380,7 +381,8 @@ __global__ __launch_bounds__(TB) void k_sweep_u1(int64_t M, int k, const Status*
 __device__ __forceinline__ void reduce_a_check_body(Status* st, const float* __restrict__ part, int npart, int thr, int k,
                                                     float* __restrict__ coef, const float* __restrict__ nrm_part, int nn,
                                                     double* __restrict__ rel_trace, double* __restrict__ abs_trace,
-                                                    double eps, int seq_len, int keep_trace, double* sh, int contig = 0) {
+                                                    double eps, int seq_len, int keep_trace, double* sh,
+                                                    const float* __restrict__ parta = nullptr, int npart4 = 0, int a_from = 1 << 30) {
   if (blockIdx.y == 1) {
     if (blockIdx.x == 0) check_block(st, nrm_part, nn, rel_trace, abs_trace, eps, thr, seq_len, keep_trace, sh);
     return;
@@ -388,16 +390,18 @@ __device__ __forceinline__ void reduce_a_check_body(Status* st, const float* __r
   if (st->done) return;
   const int j = blockIdx.x;
   if (j >= k) return;
-  const double s = contig ? block_sum_contig(part + (int64_t)j * npart, npart, sh)            // k_sweep_u2d's layout
-                          : block_sum_partials<4>(part + (int64_t)j * npart * 4, npart, sh);
+  // pairs from a_from on: partials of the folded sweep 3 of the last iteration (contiguous); before: sweep 1's (slot 0 of quads)
+  const double s = j >= a_from ? block_sum_contig(parta + (int64_t)j * npart4, npart4, sh)
+                               : block_sum_partials<4>(part + (int64_t)j * npart * 4, npart, sh);
   if (threadIdx.x == 0) coef[j] = (float)s;
 }
 __global__ __launch_bounds__(TB) void k_reduce_a_check(Status* st, const float* __restrict__ part, int npart, int thr, int k,
                                                        float* __restrict__ coef, const float* __restrict__ nrm_part, int nn,
                                                        double* __restrict__ rel_trace, double* __restrict__ abs_trace,
-                                                       double eps, int seq_len, int keep_trace, int contig) {
+                                                       double eps, int seq_len, int keep_trace, const float* __restrict__ parta,
+                                                       int npart4, int a_from) {
   __shared__ double sh[TB];
-  reduce_a_check_body(st, part, npart, thr, k, coef, nrm_part, nn, rel_trace, abs_trace, eps, seq_len, keep_trace, sh, contig);
+  reduce_a_check_body(st, part, npart, thr, k, coef, nrm_part, nn, rel_trace, abs_trace, eps, seq_len, keep_trace, sh, parta, npart4, a_from);
 }
 
 // sweep 2: reads V once: partials of c_j = V_j.dg, b_j = V_j.g AND vT = -dx + sum_j a_j V_j; then vT's part of axpy_finish
@@ -543,8 +547,10 @@ __global__ __launch_bounds__(TB) void k_sweep_u2(int64_t M, int k, const Status*
 __global__ __launch_bounds__(TB) void k_sweep_u2d(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
                                                   float* __restrict__ upd, const float* __restrict__ dgv,
                                                   const float* __restrict__ gv, const float* __restrict__ coef, int thr,
-                                                  float* __restrict__ part, int npart4, int64_t ld) {
-  extern __shared__ __attribute__((aligned(16))) float4 keep[];   // keep[j * TB + tid] = this thread's 4 values of U_j
+                                                  float* __restrict__ part, int npart4, int64_t ld, int j_keep0) {
+  // j_keep0: first stored pair that is kept (0 while k <= U2D_KMAX: all of them; later only the most recent ones -- the next
+  // iteration's sweep 1 then covers the pairs before j_keep0 only)
+  extern __shared__ __attribute__((aligned(16))) float4 keep[];   // keep[(j - j_keep0) * TB + tid] = this thread's 4 values of U_j
   if (st->done) return;
   const int64_t e0 = elem0<4>();
   const bool act = e0 + 4 <= M;          // (M = 10 N: a multiple of... not of 4 in general -> the ragged last quad goes the slow way)
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(TB) void k_sweep_u2d(int64_t M, int k, const Status
 #pragma unroll
       for (int q = 0; q < U2D_UNROLL; ++q) {
         const float cc = coef[thr + j + q], cb = coef[2 * thr + j + q];
-        keep[(j + q) * TB + tid] = u[q];
+        if (j + q >= j_keep0) keep[(j + q - j_keep0) * TB + tid] = u[q];
         a1[0] = fmaf(-cc, u[q].x, a1[0]); a1[1] = fmaf(-cc, u[q].y, a1[1]); a1[2] = fmaf(-cc, u[q].z, a1[2]); a1[3] = fmaf(-cc, u[q].w, a1[3]);
         a2[0] = fmaf(-cb, u[q].x, a2[0]); a2[1] = fmaf(-cb, u[q].y, a2[1]); a2[2] = fmaf(-cb, u[q].z, a2[2]); a2[3] = fmaf(-cb, u[q].w, a2[3]);
       }
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(TB) void k_sweep_u2d(int64_t M, int k, const Status
     float u[4] = {0.f, 0.f, 0.f, 0.f};
     const float cc = coef[thr + j], cb = coef[2 * thr + j];
     if (act || tail) ldv<4>(U + (int64_t)j * ld, e0, M, u);
-    keep[j * TB + tid] = make_float4(u[0], u[1], u[2], u[3]);
+    if (j >= j_keep0) keep[(j - j_keep0) * TB + tid] = make_float4(u[0], u[1], u[2], u[3]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       a1[i] = fmaf(-cc, u[i], a1[i]);
@@ -608,8 +614,8 @@ __global__ __launch_bounds__(TB) void k_sweep_u2d(int64_t M, int k, const Status
   // a_j(next) = U_j . update_new for j <= k (U_k = a1, update_new = a2)
   const int w = blockIdx.x * (TB / 64) + (tid >> 6);
   const bool lead = (tid & 63) == 0;
-  for (int jj = 0; jj <= k; ++jj) {
-    float4 u = jj < k ? keep[jj * TB + tid] : make_float4(a1[0], a1[1], a1[2], a1[3]);
+  for (int jj = j_keep0; jj <= k; ++jj) {
+    float4 u = jj < k ? keep[(jj - j_keep0) * TB + tid] : make_float4(a1[0], a1[1], a1[2], a1[3]);
     float sa = fmaf(u.x, a2[0], fmaf(u.y, a2[1], fmaf(u.z, a2[2], u.w * a2[3])));
     sa = wave_sum(sa);
     if (lead) part[(int64_t)jj * npart4 + w] = sa;
@@ -849,6 +855,8 @@ static int broyden_alloc(psignn_broyden* s) {
   s->nblk4 = (int)cdiv(s->M, (int64_t)4 * TB);
   s->u2d_kmax = (s->uvu && s->vec_u == 16) ? 24 : 0;   // 96 KB of LDS per block at most; 20 ... 32 measure alike at K = 50, K = 20 needs >= 19
   if (const char* e = getenv("PSIGNN_U2D_KMAX")) s->u2d_kmax = (s->uvu && s->vec_u == 16) ? std::max(0, std::min(38, atoi(e))) : 0;
+  s->u2d_keep = s->u2d_kmax > 0 ? 16 : 0;
+  if (const char* e = getenv("PSIGNN_U2D_KEEP")) s->u2d_keep = s->u2d_kmax > 0 ? std::max(0, std::min(s->u2d_kmax, atoi(e))) : 0;
   s->nn_cap = std::max<int>(std::max(s->nblk, s->nblk_ax), s->plan ? (int)s->plan->n_tiles : 0);
   size_t nx = s->keep_trace ? thr + 2 : 3;
   s->ld = (s->M + 63) / 64 * 64;  // row pitch of U and V: every stored vector starts on a 256-byte boundary
@@ -856,7 +864,7 @@ static int broyden_alloc(psignn_broyden* s) {
   struct { void** p; size_t n; } allocs[] = {
       {(void**)&s->U, thr * ld * 4},  {(void**)&s->V, thr * ld * 4},   {(void**)&s->xbuf, nx * M * 4},
       {(void**)&s->gx, M * 4},        {(void**)&s->dg, M * 4},        {(void**)&s->upd, M * 4},
-      {(void**)&s->fx, M * 4},        {(void**)&s->part, 4 * thr * (size_t)std::max(s->npart, s->npart_u) * 4 + 16}, {(void**)&s->parta, (size_t)(s->u2d_kmax + 2) * s->nblk4 * (TB / 64) * 4 + 16},
+      {(void**)&s->fx, M * 4},        {(void**)&s->part, 4 * thr * (size_t)std::max(s->npart, s->npart_u) * 4 + 16}, {(void**)&s->parta, (size_t)(s->u2d_kmax > 0 ? thr + 2 : 2) * s->nblk4 * (TB / 64) * 4 + 16},
       {(void**)&s->coef, 3 * thr * 4 + 16}, {(void**)&s->st, sizeof(Status)},
       {(void**)&s->nrm_part, 2 * (size_t)s->nn_cap * 4 + 16}, {(void**)&s->part2, 2 * (size_t)std::max(s->nblk, s->nblk_u) * 4 + 16},
       {(void**)&s->rel_trace, thr * 8 + 8}, {(void**)&s->abs_trace, thr * 8 + 8}};
@@ -978,25 +986,29 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
     const int kd = k >= s->thr ? 0 : k;
     const unsigned gu = (unsigned)s->nblk_u;
     if (k == 0) s->a_ready = 0;
-    const int np_a = s->a_ready ? s->nblk4 * (TB / 64) : s->npart_u;   // who wrote the partials of a: k_sweep_u2d of the last iteration, or sweep 1
-    if (kd > 0 && !s->a_ready)
-      VLAUNCH("k_sweep_u1", st, s->vec_u, k_sweep_u1, (gu, TB, 0, st), s->M, kd, s->st, s->U, s->upd, s->part, s->npart_u, s->ld);
+    // a_j of this iteration: pairs j >= a_from were delivered by the folded sweep 3 of the last iteration, the others need sweep 1
+    const int a_from = s->a_ready ? s->a_from : kd;
+    const int np4 = s->nblk4 * (TB / 64);
+    if (std::min(a_from, kd) > 0)
+      VLAUNCH("k_sweep_u1", st, s->vec_u, k_sweep_u1, (gu, TB, 0, st), s->M, std::min(a_from, kd), s->st, s->U, s->upd, s->part, s->npart_u, s->ld);
     LAUNCH("k_reduce_check", st, (k_reduce_a_check<<<dim3(std::max(kd, 1), 2), TB, 0, st>>>(
-        s->st, s->a_ready ? s->parta : s->part, np_a, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len,
-        s->keep_trace, s->a_ready)));
+        s->st, s->part, s->npart_u, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace,
+        s->parta, np4, a_from)));
     s->a_ready = 0;
     if (k >= s->thr) return;
     VLAUNCH("k_sweep_v", st, s->vec_u, k_sweep_v, (gu, TB, 0, st), s->M, k, s->st, s->V, s->upd, s->dg, s->gx, s->coef, s->part, s->npart_u, s->part2, s->nblk_u, s->ld);
     LAUNCH("k_reduce_cb", st, (k_reduce_cb<<<dim3(std::max(k, 1), 3), TB, 0, st>>>(s->st, s->part, s->npart_u, s->thr, k, s->coef, s->part2, s->nblk_u)));
-    if (k <= s->u2d_kmax && k + 1 < s->thr) {   // few stored pairs: sweep 3 keeps them and delivers the next iteration's a as well
-      const size_t lds = (size_t)std::max(k, 1) * TB * 16;
+    const int keep0 = k <= s->u2d_kmax ? 0 : k - s->u2d_keep;      // few stored pairs: all kept; later the most recent ones
+    if (s->u2d_kmax > 0 && (k <= s->u2d_kmax || s->u2d_keep > 0) && k + 1 < s->thr) {
+      const size_t lds = (size_t)std::max(k - keep0, 1) * TB * 16;
       static const bool lds_ok = [] {   // more than 64 KB of dynamic LDS has to be asked for once
         return hipFuncSetAttribute((const void*)k_sweep_u2d, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       }();
       (void)lds_ok;
       LAUNCH("k_sweep_u2d", st, (k_sweep_u2d<<<(unsigned)s->nblk4, TB, lds, st>>>(s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->parta,
-                                                                                  s->nblk4 * (TB / 64), s->ld)));
+                                                                                  np4, s->ld, keep0)));
       s->a_ready = 1;
+      s->a_from = keep0;
     } else {
       VLAUNCH("k_sweep_u2", st, s->vec_u, k_sweep_u2, (gu, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->ld);
     }

@@ -41,10 +41,14 @@ K, nodes = int(sys.argv[4]), int(sys.argv[5])
 STREAM = {"k_dots", "k_axpy", "k_resid", "k_final", "k_xnext", "k_sweep_u1", "k_sweep_v", "k_sweep_u2", "k_sweep_u2d"}
 SWEEPS = ("k_dots", "k_axpy", "k_sweep_u1", "k_sweep_v", "k_sweep_u2", "k_sweep_u2d")
 import os
-KMAX = int(os.environ.get("PSIGNN_U2D_KMAX", "24"))          # as bench.py: which sweep-3 form / whether sweep 1 ran at each k
-_u2d = [k for k in range(0, K) if k <= KMAX and k + 1 < K]
+KMAX = int(os.environ.get("PSIGNN_U2D_KMAX", "24"))          # as bench.py: which sweep-3 form ran at each k / what sweep 1 read
+KEEP = int(os.environ.get("PSIGNN_U2D_KEEP", "16"))
+_fold = [KMAX > 0 and k + 1 < K and (k <= KMAX or KEEP > 0) for k in range(K)]
+_keep0 = [(0 if k <= KMAX else k - KEEP) if _fold[k] else k + 1 for k in range(K)]
+_u2d = [k for k in range(K) if _fold[k]]
+_u1 = [c for c in ((_keep0[k - 1] if _fold[k - 1] else k) for k in range(1, K)) if c > 0]
 KS = {"k_dots": list(range(1, K)), "k_axpy": list(range(0, K)), "k_final": list(range(0, K)), "k_f_tile_fused": list(range(0, K)),
-      "k_reduce_check": list(range(0, K)), "k_sweep_u1": [k for k in range(1, K) if (k - 1) not in _u2d], "k_sweep_v": list(range(0, K)),
+      "k_reduce_check": list(range(0, K)), "k_sweep_u1": _u1, "k_sweep_v": list(range(0, K)),
       "k_sweep_u2": [k for k in range(0, K) if k not in _u2d], "k_sweep_u2d": _u2d}
 out = {}
 for k in sorted(set(fetch) | set(write)):
