@@ -853,8 +853,10 @@ static int broyden_alloc(psignn_broyden* s) {
   }
   s->npart_u = s->nblk_u * (TB / 64);
   s->nblk4 = (int)cdiv(s->M, (int64_t)4 * TB);
-  s->u2d_kmax = (s->uvu && s->vec_u == 16) ? 24 : 0;   // 96 KB of LDS per block at most; 20 ... 32 measure alike at K = 50, K = 20 needs >= 19
-  if (const char* e = getenv("PSIGNN_U2D_KMAX")) s->u2d_kmax = (s->uvu && s->vec_u == 16) ? std::max(0, std::min(38, atoi(e))) : 0;
+  // (single solves only: the batched wrappers do not carry the folded form)
+  const bool fold_ok = s->uvu && s->size_hint == 0;
+  s->u2d_kmax = fold_ok ? 24 : 0;   // 96 KB of LDS per block at most; 20 ... 32 measure alike at K = 50, K = 20 needs >= 19
+  if (const char* e = getenv("PSIGNN_U2D_KMAX")) s->u2d_kmax = fold_ok ? std::max(0, std::min(38, atoi(e))) : 0;
   s->u2d_keep = s->u2d_kmax > 0 ? 16 : 0;
   if (const char* e = getenv("PSIGNN_U2D_KEEP")) s->u2d_keep = s->u2d_kmax > 0 ? std::max(0, std::min(s->u2d_kmax, atoi(e))) : 0;
   s->nn_cap = std::max<int>(std::max(s->nblk, s->nblk_ax), s->plan ? (int)s->plan->n_tiles : 0);
