@@ -174,4 +174,6 @@ struct BatchDesc {
   const float *h0p, *prbp;
   float* part2;                // three-sweep update: block partials of vT.dg, vT.g
   int32_t nblk_u, npart_u;     // its blocks / per-wave partials per stored pair
+  float* parta;                // folded sweep 3: per-wave partials of the next iteration's a, contiguous per stored pair
+  int32_t nblk4, pad_;         // its blocks (4 floats per lane)
 };

@@ -544,10 +544,10 @@ __global__ __launch_bounds__(TB) void k_sweep_u2(int64_t M, int k, const Status*
 #ifndef U2D_UNROLL
 #define U2D_UNROLL 8   // stored pairs whose loads are in flight together (one wave per SIMD has to keep the memory pipe busy alone)
 #endif
-__global__ __launch_bounds__(TB) void k_sweep_u2d(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
-                                                  float* __restrict__ upd, const float* __restrict__ dgv,
-                                                  const float* __restrict__ gv, const float* __restrict__ coef, int thr,
-                                                  float* __restrict__ part, int npart4, int64_t ld, int j_keep0) {
+__device__ __forceinline__ void sweep_u2d_body(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
+                                               float* __restrict__ upd, const float* __restrict__ dgv,
+                                               const float* __restrict__ gv, const float* __restrict__ coef, int thr,
+                                               float* __restrict__ part, int npart4, int64_t ld, int j_keep0) {
   // j_keep0: first stored pair that is kept (0 while k <= U2D_KMAX: all of them; later only the most recent ones -- the next
   // iteration's sweep 1 then covers the pairs before j_keep0 only)
   extern __shared__ __attribute__((aligned(16))) float4 keep[];   // keep[(j - j_keep0) * TB + tid] = this thread's 4 values of U_j
@@ -620,6 +620,12 @@ __global__ __launch_bounds__(TB) void k_sweep_u2d(int64_t M, int k, const Status
     sa = wave_sum(sa);
     if (lead) part[(int64_t)jj * npart4 + w] = sa;
   }
+}
+__global__ __launch_bounds__(TB) void k_sweep_u2d(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
+                                                  float* __restrict__ upd, const float* __restrict__ dgv,
+                                                  const float* __restrict__ gv, const float* __restrict__ coef, int thr,
+                                                  float* __restrict__ part, int npart4, int64_t ld, int j_keep0) {
+  sweep_u2d_body(M, k, st, U, upd, dgv, gv, coef, thr, part, npart4, ld, j_keep0);
 }
 
 // axpy pass.  Writes vT (NaN->0) to V[k], D1 to U[k] (unscaled), D2 to upd, partials of vT.dg, vT.g.
@@ -853,8 +859,7 @@ static int broyden_alloc(psignn_broyden* s) {
   }
   s->npart_u = s->nblk_u * (TB / 64);
   s->nblk4 = (int)cdiv(s->M, (int64_t)4 * TB);
-  // (single solves only: the batched wrappers do not carry the folded form)
-  const bool fold_ok = s->uvu && s->size_hint == 0;
+  const bool fold_ok = s->uvu != 0;
   s->u2d_kmax = fold_ok ? 24 : 0;   // 96 KB of LDS per block at most; 20 ... 32 measure alike at K = 50, K = 20 needs >= 19
   if (const char* e = getenv("PSIGNN_U2D_KMAX")) s->u2d_kmax = fold_ok ? std::max(0, std::min(38, atoi(e))) : 0;
   s->u2d_keep = s->u2d_kmax > 0 ? 16 : 0;
@@ -1219,11 +1224,17 @@ __global__ __launch_bounds__(TB) void kb_sweep_u1(const BatchDesc* __restrict__ 
   if ((int)blockIdx.x >= d.nblk_u) return;
   sweep_u1_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, d.part, d.npart_u, d.ld);
 }
-__global__ __launch_bounds__(TB) void kb_reduce_a_check(const BatchDesc* __restrict__ descs, int k, double eps) {
+__global__ __launch_bounds__(TB) void kb_reduce_a_check(const BatchDesc* __restrict__ descs, int k, double eps, int a_from) {
   __shared__ double sh[TB];
   const BatchDesc& d = descs[blockIdx.z];
   reduce_a_check_body(reinterpret_cast<Status*>(d.st), d.part, d.npart_u, d.thr, k, d.coef, d.nrm_part, d.n_tiles, d.rel_trace,
-                      d.abs_trace, eps, d.seq_len, d.keep_trace, sh);
+                      d.abs_trace, eps, d.seq_len, d.keep_trace, sh, d.parta, d.nblk4 * (TB / 64), a_from);
+}
+__global__ __launch_bounds__(TB) void kb_sweep_u2d(const BatchDesc* __restrict__ descs, int k, int j_keep0) {
+  const BatchDesc& d = descs[blockIdx.z];
+  if ((int)blockIdx.x >= d.nblk4) return;
+  sweep_u2d_body(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, d.dg, d.gx, d.coef, d.thr, d.parta, d.nblk4 * (TB / 64), d.ld,
+                 j_keep0);
 }
 template <int VEC>
 __global__ __launch_bounds__(TB) void kb_sweep_v(const BatchDesc* __restrict__ descs, int k) {
@@ -1264,11 +1275,12 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
   if (poll_every <= 0) poll_every = 8;
   // one vector width / split layout / threshold for the whole shard (meshes of one shard are of one size class)
   const psignn_broyden* s0 = sv[0];
-  int max_g = 0, max_ga = 0, max_gu = 0, max_G = 1, max_rows = 0, n_slots = 0;
+  int max_g = 0, max_ga = 0, max_gu = 0, max_g4 = 0, max_G = 1, max_rows = 0, n_slots = 0;
   for (int m = 0; m < n; ++m) {
     const psignn_broyden* s = sv[m];
     ARG_CHECK(s && s->plan && s->plan->tiled && !s->plan->mixed, "batched solve: tiled dirichlet plans only");
-    ARG_CHECK(s->vec == s0->vec && s->vec_ax == s0->vec_ax && s->uvu == s0->uvu && s->vec_u == s0->vec_u && s->thr == s0->thr,
+    ARG_CHECK(s->vec == s0->vec && s->vec_ax == s0->vec_ax && s->uvu == s0->uvu && s->vec_u == s0->vec_u && s->thr == s0->thr &&
+                  s->u2d_kmax == s0->u2d_kmax && s->u2d_keep == s0->u2d_keep,
               "batched solve: meshes of different size classes (vector width / threshold differ)");
     ARG_CHECK(h0[m] && prb[m], "NULL argument");
     max_g = std::max(max_g, s->nblk);
@@ -1299,6 +1311,8 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
     d.nrm_part = s->nrm_part; d.jpart = s->jpart; d.rel_trace = s->rel_trace; d.abs_trace = s->abs_trace;
     d.ctx = p->d_ctx; d.h0p = s->h0p; d.prbp = s->prbp;
     d.part2 = s->part2; d.nblk_u = s->nblk_u; d.npart_u = s->npart_u;
+    d.parta = s->parta; d.nblk4 = s->nblk4; d.pad_ = 0;
+    max_g4 = std::max(max_g4, s->nblk4);
     base += (int)p->n_tiles;
   }
   BatchDesc* d_descs = nullptr;
@@ -1323,6 +1337,8 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
   BT(hipMemcpyAsync(d_descs, hd.data(), sizeof(BatchDesc) * n, hipMemcpyHostToDevice, st));
   const int off_done = offsetof(Status, done) / 4;
   const int thr = s0->thr;
+  bool a_ready = false;
+  int a_from_next = 0;
   for (int it = 0; it < thr; ++it) {
     rc = psignn_f_tile_fused_batch(d_descs, n, n_slots, max_rows, W, off_done, sel_off_cur(), sel_off_nxt(), st);
     if (rc) { cleanup(); return rc; }
@@ -1330,11 +1346,26 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
     const int kd = k >= thr ? 0 : k;
     if (s0->uvu) {
       const dim3 gu((unsigned)max_gu, 1, (unsigned)n);
-      if (kd > 0) VLAUNCH("k_sweep_u1", st, s0->vec_u, kb_sweep_u1, (gu, TB, 0, st), d_descs, kd);
-      LAUNCH("k_reduce_check", st, (kb_reduce_a_check<<<dim3((unsigned)std::max(kd, 1), 2, (unsigned)n), TB, 0, st>>>(d_descs, kd, eps)));
+      // (all meshes of the shard carry the same number of stored pairs: one a_from / keep window for the launch)
+      const int a_from = a_ready ? a_from_next : kd;
+      if (std::min(a_from, kd) > 0) VLAUNCH("k_sweep_u1", st, s0->vec_u, kb_sweep_u1, (gu, TB, 0, st), d_descs, std::min(a_from, kd));
+      LAUNCH("k_reduce_check", st, (kb_reduce_a_check<<<dim3((unsigned)std::max(kd, 1), 2, (unsigned)n), TB, 0, st>>>(d_descs, kd, eps, a_from)));
+      a_ready = false;
       VLAUNCH("k_sweep_v", st, s0->vec_u, kb_sweep_v, (gu, TB, 0, st), d_descs, k);
       LAUNCH("k_reduce_cb", st, (kb_reduce_cb<<<dim3((unsigned)std::max(k, 1), 3, (unsigned)n), TB, 0, st>>>(d_descs, k)));
-      VLAUNCH("k_sweep_u2", st, s0->vec_u, kb_sweep_u2, (gu, TB, 0, st), d_descs, k);
+      const int keep0 = k <= s0->u2d_kmax ? 0 : k - s0->u2d_keep;
+      if (s0->u2d_kmax > 0 && (k <= s0->u2d_kmax || s0->u2d_keep > 0) && k + 1 < thr) {
+        const size_t lds = (size_t)std::max(k - keep0, 1) * TB * 16;
+        static const bool lds_ok = [] {
+          return hipFuncSetAttribute((const void*)kb_sweep_u2d, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        }();
+        (void)lds_ok;
+        LAUNCH("k_sweep_u2d", st, (kb_sweep_u2d<<<dim3((unsigned)max_g4, 1, (unsigned)n), TB, lds, st>>>(d_descs, k, keep0)));
+        a_ready = true;
+        a_from_next = keep0;
+      } else {
+        VLAUNCH("k_sweep_u2", st, s0->vec_u, kb_sweep_u2, (gu, TB, 0, st), d_descs, k);
+      }
     } else {
     if (kd > 0)
       VLAUNCH("k_dots", st, s0->vec, kb_dots, (dim3((unsigned)max_g, (unsigned)max_G, (unsigned)n), TB, 0, st), d_descs, kd);
