@@ -309,6 +309,12 @@ int psignn_broyden_solve_adjoint(psignn_broyden_t* s, const float* d_weights, in
                                  double* h_rel_trace, double* h_abs_trace, void* stream);
 /* Copy iterate i (0..n_iter) of the last solve to d_dst (needs keep_trace). */
 int psignn_broyden_get_iterate(const psignn_broyden_t* s, int i, float* d_dst, void* stream);
+/* Copy stored rank-one pair j (0 .. pairs stored - 1) of the last solve to d_dst: which = 0 -> U_j, 1 -> V_j; which = 2 -> the current
+ * `update` vector (solver.py:136,192; j ignored).  Caller's numbering.
+ * replaces: reading Us[..., j] / VTs[:, j] of broyden() (utilities/solver.py:134-135, written at :190-191); the reference keeps them
+ *           as locals of the solver call -- here they stay on the device between solves.  Used by the parity tests to check
+ *           the Broyden recurrences of every update form on the device's own state. */
+int psignn_broyden_get_pair(const psignn_broyden_t* s, int j, int which, float* d_dst, void* stream);
 
 /* Generic low-rank machinery for user-supplied f (Python callables): the solver-API drop-in
  * `broyden(f, x0, threshold, eps)` drives these from the host with one f call per iteration.

@@ -92,6 +92,7 @@ SIGNATURES = {
                                           C.POINTER(_P), C.POINTER(SolveInfo), C.POINTER(C.POINTER(C.c_double)),
                                           C.POINTER(C.POINTER(C.c_double)), _P]),
     "psignn_broyden_get_iterate": (_INT, [_P, _INT, _P, _P]),
+    "psignn_broyden_get_pair": (_INT, [_P, _INT, _INT, _P, _P]),
     "psignn_broyden_ext_begin": (_INT, [_P, _P, _P, _P]),
     "psignn_broyden_ext_next_x": (_INT, [_P, _P, _P]),
     "psignn_broyden_ext_trial_x": (_INT, [_P, C.c_double, _P, _P]),

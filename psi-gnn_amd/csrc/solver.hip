@@ -57,6 +57,7 @@ struct psignn_broyden {
   int vec_u = 0, nblk_u = 0, npart_u = 0;   // their vector width / blocks / per-wave partials per stored pair
   int u2d_kmax = 0, nblk4 = 0, a_ready = 0; // k_sweep_u2d: up to this many stored pairs are all kept; its blocks; a of the next iteration comes (partly) from it
   int u2d_keep = 0, a_from = 0;             // beyond u2d_kmax: the most recent u2d_keep pairs are kept; pairs before a_from still need sweep 1
+  int u2d_reg = 1;                          // kept values in registers (k_sweep_u2r<KB>, the default) or in per-thread LDS slots (k_sweep_u2d; PSIGNN_U2D_FORM=lds)
   float* parta = nullptr;                   // its per-wave partials of a, contiguous per stored pair: (u2d_kmax + 2, nblk4 * 4)
   int nn_cap = 0;
   float *h0p = nullptr, *prbp = nullptr, *nrmp = nullptr;  // plan-order copies of h_initial, prb_data, normals
@@ -628,6 +629,210 @@ __global__ __launch_bounds__(TB) void k_sweep_u2d(int64_t M, int k, const Status
   sweep_u2d_body(M, k, st, U, upd, dgv, gv, coef, thr, part, npart4, ld, j_keep0);
 }
 
+// The same folded sweep with the kept values in REGISTERS (round 3; the default).  The LDS form above pins ONE 256-thread block per
+// CU once 16 k bytes per thread exceed 80 KB (k > 19): one wave per SIMD then has to cover the HBM latency alone, and the
+// dominant kernel of the headline solve was its slowest sweep (0.58 - 0.61 of peak against 0.63 - 0.70 for k_sweep_v).  A fully
+// unrolled array of KB float4 (KB = 8 / 16 / 24: 32 / 64 / 96 VGPRs) is addressed by compile-time indices only, so it stays in
+// the register file: 8 / 5 / 4 waves per SIMD, no LDS, all KB loads of a thread in flight at once.  Pairs older than the kept
+// window (j < j_keep0) are streamed as in the LDS form.  Same arithmetic in the same order on every element and the same
+// partial-sum shapes as the LDS form => bit-identical iterates (tests/test_gpu_solver_forms.py).
+// straight-line tail of the fast path for exactly NK kept pairs: NK loads issued back to back, NK fma groups, the update's last
+// step, NK + 1 dot products.  Addresses are a wave-uniform row base (SGPR pair) plus ONE 32-bit lane offset shared by every load
+// (global_load ... v_off, s[base]): a 64-bit VGPR address per load would cost 2 VGPRs and a 64-bit add each.
+// scalar row base + 32-bit byte offset of the lane.  The empty asm pins the base in an SGPR pair and hides its provenance from the
+// address reassociation passes (which otherwise chain 64-bit VGPR adds from one row to the next: 2 VGPRs + one VALU add per load);
+// the explicit global address space keeps the access a global_load (an integer laundered through asm would become a flat access).
+typedef float f4g __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_so(const float* __restrict__ base, uint32_t boff) {
+  uint64_t rb = reinterpret_cast<uint64_t>(base);
+  asm("" : "+s"(rb));
+  const f4g t = *reinterpret_cast<const __attribute__((address_space(1))) f4g*>(rb + boff);
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void st4_so(float* __restrict__ base, uint32_t boff, float4 v) {
+  uint64_t rb = reinterpret_cast<uint64_t>(base);
+  asm("" : "+s"(rb));
+  f4g t = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<__attribute__((address_space(1))) f4g*>(rb + boff) = t;
+}
+__device__ __forceinline__ float rfl(float v) {   // wave-uniform value -> SGPR
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+template <int NK, bool FIRST>
+__device__ __forceinline__ void u2r_kept(float (&a1)[4], float (&a2)[4], int k, const Status* __restrict__ st, float* __restrict__ U,
+                                         float* __restrict__ upd, const float* __restrict__ dgv, const float* __restrict__ gv,
+                                         const float* __restrict__ coef, int thr, float* __restrict__ part,
+                                         int npart4, int64_t ld, int j_keep0, uint32_t off, int w, bool lead) {
+  // (instruction selection works per basic block: the 32-bit offset has to be (re)defined in the block of the accesses for
+  // `sgpr base + zext(vgpr32)` to be matched as the saddr addressing mode)
+  asm volatile("" : "+v"(off));
+  float4 kp[NK > 0 ? NK : 1];
+  const float* Ub = U + (int64_t)j_keep0 * ld;
+#pragma unroll
+  for (int q = 0; q < NK; ++q) kp[q] = ld4_so(Ub + (int64_t)q * ld, off);
+  if (FIRST) {   // all pairs are kept (j_keep0 = 0): the three state vectors are requested in the same burst as the NK rows of U
+    const float4 x = ld4_so(upd, off), dg = ld4_so(dgv, off), g = ld4_so(gv, off);
+    a1[0] = x.x + dg.x; a1[1] = x.y + dg.y; a1[2] = x.z + dg.z; a1[3] = x.w + dg.w;
+    a2[0] = g.x; a2[1] = g.y; a2[2] = g.z; a2[3] = g.w;
+  }
+  // The 2 NK coefficients: lane q of the wave loads the pair of stored pair q (ONE vector load each for c and b), v_readlane hands
+  // them to the fma's as scalars.  In the single-mesh kernel they could be scalar loads; in the batched kernel the coefficient
+  // table hangs off a descriptor in memory, the compiler cannot prove it read-only and loads every coefficient into a VGPR of
+  // its own -- 2 NK registers on top of the 4 NK kept ones.
+  const int lane = threadIdx.x & 63;
+  float ccv = 0.f, cbv = 0.f;
+  if (lane < NK) {
+    ccv = coef[thr + j_keep0 + lane];
+    cbv = coef[2 * thr + j_keep0 + lane];
+  }
+  const float sv = rfl((float)st->s), beta = rfl((float)st->beta);
+#pragma unroll
+  for (int q = 0; q < NK; ++q) {
+    const float cc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ccv), q));
+    const float cb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cbv), q));
+    a1[0] = fmaf(-cc, kp[q].x, a1[0]); a1[1] = fmaf(-cc, kp[q].y, a1[1]); a1[2] = fmaf(-cc, kp[q].z, a1[2]); a1[3] = fmaf(-cc, kp[q].w, a1[3]);
+    a2[0] = fmaf(-cb, kp[q].x, a2[0]); a2[1] = fmaf(-cb, kp[q].y, a2[1]); a2[2] = fmaf(-cb, kp[q].z, a2[2]); a2[3] = fmaf(-cb, kp[q].w, a2[3]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float q = a1[i] / sv;
+    q = (q != q) ? 0.f : q;
+    a1[i] = q;
+    a2[i] = fmaf(-q, beta, a2[i]);
+  }
+  st4_so(U + (int64_t)k * ld, off, make_float4(a1[0], a1[1], a1[2], a1[3]));
+  st4_so(upd, off, make_float4(a2[0], a2[1], a2[2], a2[3]));
+#pragma unroll
+  for (int q = 0; q < NK; ++q) {
+    float sa = fmaf(kp[q].x, a2[0], fmaf(kp[q].y, a2[1], fmaf(kp[q].z, a2[2], kp[q].w * a2[3])));
+    sa = wave_sum(sa);
+    if (lead) part[(int64_t)(j_keep0 + q) * npart4 + w] = sa;
+  }
+  float sa = fmaf(a1[0], a2[0], fmaf(a1[1], a2[1], fmaf(a1[2], a2[2], a1[3] * a2[3])));
+  sa = wave_sum(sa);
+  if (lead) part[(int64_t)k * npart4 + w] = sa;
+}
+
+template <int KB>
+__device__ __forceinline__ void sweep_u2r_body(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
+                                               float* __restrict__ upd, const float* __restrict__ dgv,
+                                               const float* __restrict__ gv, const float* __restrict__ coef, int thr,
+                                               float* __restrict__ part, int npart4, int64_t ld, int j_keep0) {
+  if (__builtin_amdgcn_readfirstlane(st->done)) return;   // (a vector load in the batched kernel: keep the branch scalar)
+  const int tid = threadIdx.x;
+  const int64_t e0 = elem0<4>();
+  const int w = blockIdx.x * (TB / 64) + (tid >> 6);
+  const bool lead = (tid & 63) == 0;
+  // wave-uniform: the whole span of this wave (256 floats) lies inside the vector -> no per-lane bounds anywhere on the hot path
+  const int64_t wave_e0 = ((int64_t)blockIdx.x * TB + (int64_t)__builtin_amdgcn_readfirstlane(tid & ~63)) * 4;
+  if (wave_e0 + 256 <= M) {
+    // byte offset of the lane, formed in 32-bit arithmetic (the host runs this form for M < 2^30 floats only): elem0<4>() * 4
+    uint32_t off = ((blockIdx.x * (uint32_t)TB + ((uint32_t)tid & ~63u)) * 4u + ((uint32_t)tid & 63u) * 4u) * 4u;
+    asm volatile("" : "+v"(off));   // opaque 32-bit VGPR: the accesses below are `global_load/store v_off, s[base]` (saddr form)
+    float a1[4], a2[4];
+#define U2R_CASE(n, first) case (n): u2r_kept<(n) < 0 ? 0 : (n), first>(a1, a2, k, st, U, upd, dgv, gv, coef, thr, part, npart4, ld, j_keep0, off, w, lead); break;
+    if (j_keep0 == 0) {   // every stored pair is kept: one burst of k + 3 loads per thread, no wait in front of it
+      switch (k) {
+        U2R_CASE(KB - 8, true) U2R_CASE(KB - 7, true) U2R_CASE(KB - 6, true) U2R_CASE(KB - 5, true) U2R_CASE(KB - 4, true)
+        U2R_CASE(KB - 3, true) U2R_CASE(KB - 2, true) U2R_CASE(KB - 1, true) U2R_CASE(KB, true)
+        default: break;   // (the host only launches KB - 8 < count <= KB; KB = 8 also takes count = 0)
+      }
+      return;
+    }
+    {
+      const float4 x = ld4_so(upd, off), dg = ld4_so(dgv, off), g = ld4_so(gv, off);
+      a1[0] = x.x + dg.x; a1[1] = x.y + dg.y; a1[2] = x.z + dg.z; a1[3] = x.w + dg.w;
+      a2[0] = g.x; a2[1] = g.y; a2[2] = g.z; a2[3] = g.w;
+    }
+    // pairs before the kept window: streamed, eight pairs' loads in flight
+    int j = 0;
+    for (; j + U2D_UNROLL <= j_keep0; j += U2D_UNROLL) {
+      float4 u[U2D_UNROLL];
+      const float* Uj = U + (int64_t)j * ld;
+      asm volatile("" : "+v"(off));
+#pragma unroll
+      for (int q = 0; q < U2D_UNROLL; ++q) u[q] = ld4_so(Uj + (int64_t)q * ld, off);
+#pragma unroll
+      for (int q = 0; q < U2D_UNROLL; ++q) {
+        const float cc = rfl(coef[thr + j + q]), cb = rfl(coef[2 * thr + j + q]);
+        a1[0] = fmaf(-cc, u[q].x, a1[0]); a1[1] = fmaf(-cc, u[q].y, a1[1]); a1[2] = fmaf(-cc, u[q].z, a1[2]); a1[3] = fmaf(-cc, u[q].w, a1[3]);
+        a2[0] = fmaf(-cb, u[q].x, a2[0]); a2[1] = fmaf(-cb, u[q].y, a2[1]); a2[2] = fmaf(-cb, u[q].z, a2[2]); a2[3] = fmaf(-cb, u[q].w, a2[3]);
+      }
+    }
+    for (; j < j_keep0; ++j) {
+      const float cc = rfl(coef[thr + j]), cb = rfl(coef[2 * thr + j]);
+      asm volatile("" : "+v"(off));
+      const float4 u = ld4_so(U + (int64_t)j * ld, off);
+      a1[0] = fmaf(-cc, u.x, a1[0]); a1[1] = fmaf(-cc, u.y, a1[1]); a1[2] = fmaf(-cc, u.z, a1[2]); a1[3] = fmaf(-cc, u.w, a1[3]);
+      a2[0] = fmaf(-cb, u.x, a2[0]); a2[1] = fmaf(-cb, u.y, a2[1]); a2[2] = fmaf(-cb, u.z, a2[2]); a2[3] = fmaf(-cb, u.w, a2[3]);
+    }
+    // the kept pairs: one straight-line instance per count (the count is a kernel argument: scalar jump)
+    switch (k - j_keep0) {
+      U2R_CASE(KB - 8, false) U2R_CASE(KB - 7, false) U2R_CASE(KB - 6, false) U2R_CASE(KB - 5, false) U2R_CASE(KB - 4, false)
+      U2R_CASE(KB - 3, false) U2R_CASE(KB - 2, false) U2R_CASE(KB - 1, false) U2R_CASE(KB, false)
+      default: break;
+    }
+#undef U2R_CASE
+    return;
+  }
+  // ---- the one ragged wave at the end of the vector (and lanes past it): per-lane bounds, kept pairs simply read twice --
+  // same operations in the same order on every element, so the same bits as the fast path would give
+  const bool in = e0 < M;
+  float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (in) {
+    float dg[4];
+    ldv<4>(upd, e0, M, a1);
+    ldv<4>(dgv, e0, M, dg);
+    ldv<4>(gv, e0, M, a2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a1[i] = a1[i] + dg[i];
+  }
+  for (int j = 0; j < k; ++j) {
+    float u[4] = {0.f, 0.f, 0.f, 0.f};
+    const float cc = coef[thr + j], cb = coef[2 * thr + j];
+    if (in) ldv<4>(U + (int64_t)j * ld, e0, M, u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a1[i] = fmaf(-cc, u[i], a1[i]);
+      a2[i] = fmaf(-cb, u[i], a2[i]);
+    }
+  }
+  if (in) {
+    const float sv = (float)st->s, beta = (float)st->beta;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float q = a1[i] / sv;
+      q = (q != q) ? 0.f : q;
+      a1[i] = q;
+      a2[i] = fmaf(-q, beta, a2[i]);
+    }
+    stv<4>(U + (int64_t)k * ld, e0, M, a1);
+    stv<4>(upd, e0, M, a2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (e0 + i >= M) a1[i] = a2[i] = 0.f;   // lanes past the end contribute nothing to the dot products
+  }
+  for (int jj = j_keep0; jj <= k; ++jj) {
+    float u[4] = {a1[0], a1[1], a1[2], a1[3]};
+    if (jj < k) {
+      u[0] = u[1] = u[2] = u[3] = 0.f;
+      if (in) ldv<4>(U + (int64_t)jj * ld, e0, M, u);
+    }
+    float sa = fmaf(u[0], a2[0], fmaf(u[1], a2[1], fmaf(u[2], a2[2], u[3] * a2[3])));
+    sa = wave_sum(sa);
+    if (lead) part[(int64_t)jj * npart4 + w] = sa;
+  }
+}
+// waves per SIMD the register budget of each instantiation allows (512 / (4 KB + working set), MI355X_MICROARCH register table)
+template <int KB> struct U2RWaves { static constexpr int value = KB <= 8 ? 8 : KB <= 16 ? 5 : 4; };
+template <int KB>
+__global__ __launch_bounds__(TB, U2RWaves<KB>::value) void k_sweep_u2r(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
+                                                                      float* __restrict__ upd, const float* __restrict__ dgv,
+                                                                      const float* __restrict__ gv, const float* __restrict__ coef, int thr,
+                                                                      float* __restrict__ part, int npart4, int64_t ld, int j_keep0) {
+  sweep_u2r_body<KB>(M, k, st, U, upd, dgv, gv, coef, thr, part, npart4, ld, j_keep0);
+}
+
 // axpy pass.  Writes vT (NaN->0) to V[k], D1 to U[k] (unscaled), D2 to upd, partials of vT.dg, vT.g.
 // gridDim.y == 1: the whole sum over j in one block column.  gridDim.y > 1 (short vectors): block row y sums its
 // j-range into jpart[y][3][M] and k_axpy_combine finishes -- fixed grouping, so still reproducible.
@@ -810,6 +1015,21 @@ int psignn_f_tile_fused(const psignn_plan* p, const float* W, int nl, float* xbu
                         int off_done, int off_cur, int off_nxt, const float* upd, float* gx, float* dg,
                         const float* h0, const float* prb, const float* nrm, float* part, hipStream_t st);
 
+#define U2R_KB_MAX 24
+__global__ __launch_bounds__(TB) void kb_sweep_u2d(const BatchDesc* __restrict__ descs, int k, int j_keep0);
+// LDS form of the folded sweep: up to 38 pairs x 16 B x 256 threads of dynamic LDS; asked for once per device
+static bool u2d_lds_attr(int dev) {
+  static int state[64] = {0};   // 0 unknown, 1 granted, -1 refused
+  if (dev < 0 || dev >= 64) return false;
+  if (state[dev] == 0) {
+    const bool ok = hipFuncSetAttribute((const void*)k_sweep_u2d, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                    hipFuncSetAttribute((const void*)kb_sweep_u2d, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    state[dev] = ok ? 1 : -1;
+  }
+  return state[dev] > 0;
+}
+
 static int broyden_alloc(psignn_broyden* s) {
   size_t M = (size_t)s->M, thr = (size_t)s->thr;
   // 16 floats per lane from 768 K elements up, 4 below (PSIGNN_VEC16_MIN overrides).  Re-tuned after the coalesced lane
@@ -860,10 +1080,27 @@ static int broyden_alloc(psignn_broyden* s) {
   s->npart_u = s->nblk_u * (TB / 64);
   s->nblk4 = (int)cdiv(s->M, (int64_t)4 * TB);
   const bool fold_ok = s->uvu != 0;
-  s->u2d_kmax = fold_ok ? 24 : 0;   // 96 KB of LDS per block at most; 20 ... 32 measure alike at K = 50, K = 20 needs >= 19
-  if (const char* e = getenv("PSIGNN_U2D_KMAX")) s->u2d_kmax = fold_ok ? std::max(0, std::min(38, atoi(e))) : 0;
+  // folded sweep 3: kept values in registers (default; at most U2R_KB_MAX pairs) or in LDS (PSIGNN_U2D_FORM=lds: the round-2 form, A/B and tests)
+  // Registers where the launch has several rounds of blocks (>= 2 048 blocks of 1 024 floats: 8 per CU); on shorter vectors every
+  // block is resident at once, all waves then load together and reduce together, and the LDS form's two rounds overlap better
+  // (100k nodes, K = 100: 56.5 vs 64.8 us per launch; profiles/r3_ab_u2d.txt).  M >= 2^30 floats: the register form's 32-bit lane
+  // offsets do not reach.
+  s->u2d_reg = cdiv(eff, (int64_t)4 * TB) >= 2048 && s->M < ((int64_t)1 << 30);
+  if (const char* e = getenv("PSIGNN_U2D_FORM")) s->u2d_reg = ((e[0] == 'l' || e[0] == 'L') ? 0 : 1) && s->M < ((int64_t)1 << 30);
+  const int kmax_cap = s->u2d_reg ? U2R_KB_MAX : 38;
+  s->u2d_kmax = fold_ok ? 24 : 0;   // LDS form: 96 KB per block at most; 20 ... 32 measure alike at K = 50, K = 20 needs >= 19
+  if (const char* e = getenv("PSIGNN_U2D_KMAX")) s->u2d_kmax = fold_ok ? std::max(0, std::min(kmax_cap, atoi(e))) : 0;
   s->u2d_keep = s->u2d_kmax > 0 ? 16 : 0;
   if (const char* e = getenv("PSIGNN_U2D_KEEP")) s->u2d_keep = s->u2d_kmax > 0 ? std::max(0, std::min(s->u2d_kmax, atoi(e))) : 0;
+  if (s->u2d_kmax > 0 && !s->u2d_reg) {
+    // more than 64 KB of dynamic LDS has to be asked for, per device (the attribute belongs to the device's code object)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!u2d_lds_attr(dev)) {   // not granted: stay within the default 64 KB (16 B x 256 threads x 16 pairs)
+      s->u2d_kmax = std::min(s->u2d_kmax, 16);
+      s->u2d_keep = std::min(s->u2d_keep, 16);
+    }
+  }
   s->nn_cap = std::max<int>(std::max(s->nblk, s->nblk_ax), s->plan ? (int)s->plan->n_tiles : 0);
   size_t nx = s->keep_trace ? thr + 2 : 3;
   s->ld = (s->M + 63) / 64 * 64;  // row pitch of U and V: every stored vector starts on a 256-byte boundary
@@ -1007,13 +1244,18 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
     LAUNCH("k_reduce_cb", st, (k_reduce_cb<<<dim3(std::max(k, 1), 3), TB, 0, st>>>(s->st, s->part, s->npart_u, s->thr, k, s->coef, s->part2, s->nblk_u)));
     const int keep0 = k <= s->u2d_kmax ? 0 : k - s->u2d_keep;      // few stored pairs: all kept; later the most recent ones
     if (s->u2d_kmax > 0 && (k <= s->u2d_kmax || s->u2d_keep > 0) && k + 1 < s->thr) {
-      const size_t lds = (size_t)std::max(k - keep0, 1) * TB * 16;
-      static const bool lds_ok = [] {   // more than 64 KB of dynamic LDS has to be asked for once
-        return hipFuncSetAttribute((const void*)k_sweep_u2d, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-      }();
-      (void)lds_ok;
-      LAUNCH("k_sweep_u2d", st, (k_sweep_u2d<<<(unsigned)s->nblk4, TB, lds, st>>>(s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->parta,
-                                                                                  np4, s->ld, keep0)));
+      const int nk = k - keep0;
+      if (s->u2d_reg) {
+#define U2R_ARGS s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->parta, np4, s->ld, keep0
+        if (nk <= 8) LAUNCH("k_sweep_u2d", st, (k_sweep_u2r<8><<<(unsigned)s->nblk4, TB, 0, st>>>(U2R_ARGS)));
+        else if (nk <= 16) LAUNCH("k_sweep_u2d", st, (k_sweep_u2r<16><<<(unsigned)s->nblk4, TB, 0, st>>>(U2R_ARGS)));
+        else LAUNCH("k_sweep_u2d", st, (k_sweep_u2r<24><<<(unsigned)s->nblk4, TB, 0, st>>>(U2R_ARGS)));
+#undef U2R_ARGS
+      } else {
+        const size_t lds = (size_t)std::max(nk, 1) * TB * 16;
+        LAUNCH("k_sweep_u2d", st, (k_sweep_u2d<<<(unsigned)s->nblk4, TB, lds, st>>>(s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->parta,
+                                                                                    np4, s->ld, keep0)));
+      }
       s->a_ready = 1;
       s->a_from = keep0;
     } else {
@@ -1236,6 +1478,13 @@ __global__ __launch_bounds__(TB) void kb_sweep_u2d(const BatchDesc* __restrict__
   sweep_u2d_body(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, d.dg, d.gx, d.coef, d.thr, d.parta, d.nblk4 * (TB / 64), d.ld,
                  j_keep0);
 }
+template <int KB>
+__global__ __launch_bounds__(TB, U2RWaves<KB>::value) void kb_sweep_u2r(const BatchDesc* __restrict__ descs, int k, int j_keep0) {
+  const BatchDesc& d = descs[blockIdx.z];
+  if ((int)blockIdx.x >= d.nblk4) return;
+  sweep_u2r_body<KB>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, d.dg, d.gx, d.coef, d.thr, d.parta, d.nblk4 * (TB / 64), d.ld,
+                     j_keep0);
+}
 template <int VEC>
 __global__ __launch_bounds__(TB) void kb_sweep_v(const BatchDesc* __restrict__ descs, int k) {
   const BatchDesc& d = descs[blockIdx.z];
@@ -1280,7 +1529,7 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
     const psignn_broyden* s = sv[m];
     ARG_CHECK(s && s->plan && s->plan->tiled && !s->plan->mixed, "batched solve: tiled dirichlet plans only");
     ARG_CHECK(s->vec == s0->vec && s->vec_ax == s0->vec_ax && s->uvu == s0->uvu && s->vec_u == s0->vec_u && s->thr == s0->thr &&
-                  s->u2d_kmax == s0->u2d_kmax && s->u2d_keep == s0->u2d_keep,
+                  s->u2d_kmax == s0->u2d_kmax && s->u2d_keep == s0->u2d_keep && s->u2d_reg == s0->u2d_reg,
               "batched solve: meshes of different size classes (vector width / threshold differ)");
     ARG_CHECK(h0[m] && prb[m], "NULL argument");
     max_g = std::max(max_g, s->nblk);
@@ -1355,12 +1604,16 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
       LAUNCH("k_reduce_cb", st, (kb_reduce_cb<<<dim3((unsigned)std::max(k, 1), 3, (unsigned)n), TB, 0, st>>>(d_descs, k)));
       const int keep0 = k <= s0->u2d_kmax ? 0 : k - s0->u2d_keep;
       if (s0->u2d_kmax > 0 && (k <= s0->u2d_kmax || s0->u2d_keep > 0) && k + 1 < thr) {
-        const size_t lds = (size_t)std::max(k - keep0, 1) * TB * 16;
-        static const bool lds_ok = [] {
-          return hipFuncSetAttribute((const void*)kb_sweep_u2d, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        }();
-        (void)lds_ok;
-        LAUNCH("k_sweep_u2d", st, (kb_sweep_u2d<<<dim3((unsigned)max_g4, 1, (unsigned)n), TB, lds, st>>>(d_descs, k, keep0)));
+        const int nk = k - keep0;
+        const dim3 g4((unsigned)max_g4, 1, (unsigned)n);
+        if (s0->u2d_reg) {
+          if (nk <= 8) LAUNCH("k_sweep_u2d", st, (kb_sweep_u2r<8><<<g4, TB, 0, st>>>(d_descs, k, keep0)));
+          else if (nk <= 16) LAUNCH("k_sweep_u2d", st, (kb_sweep_u2r<16><<<g4, TB, 0, st>>>(d_descs, k, keep0)));
+          else LAUNCH("k_sweep_u2d", st, (kb_sweep_u2r<24><<<g4, TB, 0, st>>>(d_descs, k, keep0)));
+        } else {
+          const size_t lds = (size_t)std::max(nk, 1) * TB * 16;
+          LAUNCH("k_sweep_u2d", st, (kb_sweep_u2d<<<g4, TB, lds, st>>>(d_descs, k, keep0)));
+        }
         a_ready = true;
         a_from_next = keep0;
       } else {
@@ -1477,6 +1730,22 @@ extern "C" int psignn_broyden_get_iterate(const psignn_broyden_t* s, int i, floa
   }
   VPLAIN(s->vec, k_copy_sel, ((unsigned)s->nblk, TB, 0, (hipStream_t)stream), s->M, s->xbuf, nullptr, i, d_dst);
   HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
+}
+
+// Stored rank-one pair j of the last solve: which = 0 -> U_j, 1 -> V_j (the reference's Us[..., j] / VTs[:, j], solver.py:134-135,190-191);
+// which = 2 -> the current `update` vector (solver.py:136,192; j ignored).  Caller's numbering.  Read-out for diagnostics and for the parity tests, which check the Broyden recurrences of every
+// update form on the device's own state (tests/test_gpu_solver_forms.py).
+extern "C" int psignn_broyden_get_pair(const psignn_broyden_t* s, int j, int which, float* d_dst, void* stream) {
+  ARG_CHECK(s && d_dst, "NULL argument");
+  ARG_CHECK(which >= 0 && which <= 2, "which: 0 = U_j, 1 = V_j, 2 = the current update vector");
+  ARG_CHECK(which == 2 || (j >= 0 && j < s->thr), "pair index out of range");
+  const float* row = which == 2 ? s->upd : (which ? s->V : s->U) + (int64_t)j * s->ld;
+  if (s->plan && s->plan_order) {
+    HIP_TRY(hipMemcpyAsync(s->fx, row, (size_t)s->M * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return psignn_plan_permute(s->plan, s->fx, D, d_dst, 0, stream);
+  }
+  HIP_TRY(hipMemcpyAsync(d_dst, row, (size_t)s->M * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return PSIGNN_OK;
 }
 

@@ -885,6 +885,15 @@ class DeviceBroyden:
                                                            nat.stream_ptr(self.device)), "psignn_broyden_get_iterate")
         return dst
 
+    def pair(self, j, like, which="U"):
+        """Stored rank-one pair j of the last solve (``U_j`` / ``V_j``; the reference's ``Us[..., j]`` / ``VTs[:, j]``,
+        utilities/solver.py:190-191) or, ``which="update"``, the current update vector (``j`` ignored); caller's numbering."""
+        dst = torch.empty_like(like)
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().psignn_broyden_get_pair(self.handle, int(j), {"U": 0, "V": 1, "update": 2}[which], nat.ptr(dst),
+                                                        nat.stream_ptr(self.device)), "psignn_broyden_get_pair")
+        return dst
+
     def _armijo_step(self, f, phi0, lib, sp, like):
         """Step length of the reference's line search (line_search / scalar_search_armijo, utilities/solver.py:20-94) for
         the current update direction: backtracking on phi(s) = |f(x + s u) - (x + s u)|^2 with phi'(0) taken as -phi(0),
