@@ -35,6 +35,10 @@ extern "C" {
 
 const char* psignn_last_error(void);
 int psignn_version(void);
+/* Re-read the PSIGNN_* environment knobs at their next use (they are cached after the first read).  The knobs select
+ * alternative forms of a kernel for A/B measurements and tests (MFMA stage 1, Hilbert tiling, gather kernels for the mixed
+ * family, ...); a normal run sets none of them.  No reference counterpart. */
+void psignn_reload_knobs(void);
 
 /* ------------------------------------------------------------------------------------------
  * Mesh plan: everything iteration-invariant, computed once per mesh on the device.
@@ -285,9 +289,10 @@ int psignn_broyden_solve(psignn_broyden_t* s, const float* d_weights, int n_laye
 /* Batched solve of n independent meshes (one GPU's share of a batch: BASELINE configs[3], 8 x 50k-node meshes): the meshes
  * iterate in lockstep and every per-iteration pass (fused f step, dots, reduce + stop tests, axpy, final) is ONE launch over
  * all of them; each mesh keeps its own status block, traces and stop test, and its result is bit-identical to
- * psignn_broyden_solve with the same solver on that mesh alone.  solvers[i] was created from mesh i's plan (tiled dirichlet plans, one
- * threshold and vector-size class for the shard; otherwise PSIGNN_EINVAL and the caller solves them one by one).
- * replaces: the reference's one-union-Batch-per-device DataParallel call (dirichlet/psignn/main.py:106,
+ * psignn_broyden_solve with the same solver on that mesh alone.  solvers[i] was created from mesh i's plan (tiled plans of ONE
+ * family -- all dirichlet or all mixed, d_normals then holds the unit normals, else NULL --, one threshold and vector-size class
+ * for the shard: psignn_broyden_batchable; otherwise PSIGNN_EINVAL).
+ * replaces: the reference's one-union-Batch-per-device DataParallel call (dirichlet/psignn/main.py:106, mixed/psignn/main.py:106,
  *           dirichlet/psignn/test/test_func.py:68-120) for independent per-mesh solves.
  * Arrays of n device / host pointers; h_rel_trace[i] / h_abs_trace[i]: `threshold` doubles each (arrays may be NULL). */
 /* Solver for mesh `plan` that will be used inside psignn_broyden_solve_batch together with others: shard_elems = sum of
@@ -296,9 +301,14 @@ int psignn_broyden_solve(psignn_broyden_t* s, const float* d_weights, int n_laye
 int psignn_broyden_create_for_batch(psignn_broyden_t** out, const psignn_plan_t* plan, int threshold, int keep_trace,
                                     int64_t shard_elems);
 int psignn_broyden_solve_batch(int n, psignn_broyden_t** solvers, const float* d_weights, int n_layers,
-                               const float* const* d_h_initial, const float* const* d_prb, double eps, int poll_every,
-                               float* const* d_results, psignn_solve_info_t* h_infos, double* const* h_rel_trace,
-                               double* const* h_abs_trace, void* stream);
+                               const float* const* d_h_initial, const float* const* d_prb, const float* const* d_normals,
+                               double eps, int poll_every, float* const* d_results, psignn_solve_info_t* h_infos,
+                               double* const* h_rel_trace, double* const* h_abs_trace, void* stream);
+/* 1 when psignn_broyden_solve_batch takes these solvers together (tiled plans of one boundary-condition family, one size class),
+ * else 0 -- asked on the host before a shard is handed over, so that "not batchable" is a decision and not an error code.
+ * replaces: nothing in the reference (its DataParallel call takes any list of graphs as one union batch,
+ *           dirichlet/psignn/main.py:106; mixed/psignn/main.py:106). */
+int psignn_broyden_batchable(int n, psignn_broyden_t* const* solvers);
 /* Adjoint fixed point y = J_f(h*)^T y + grad with the same Broyden machinery, the VJP kernel as the map, y_0 = 0.
  * replaces: the backward hook of DeepEquilibrium.forward (dirichlet/psignn/model.py:210-223), i.e.
  *           solver(lambda y: autograd.grad(new_H, H, y) + grad, zeros, bw_thres, bw_tol).

@@ -88,9 +88,10 @@ SIGNATURES = {
                                     C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
     "psignn_broyden_solve_adjoint": (_INT, [_P, _P, _INT, _P, _P, _P, _P, C.c_double, _INT, _P, C.POINTER(SolveInfo),
                                             C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
-    "psignn_broyden_solve_batch": (_INT, [_INT, C.POINTER(_P), _P, _INT, C.POINTER(_P), C.POINTER(_P), C.c_double, _INT,
+    "psignn_broyden_solve_batch": (_INT, [_INT, C.POINTER(_P), _P, _INT, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.c_double, _INT,
                                           C.POINTER(_P), C.POINTER(SolveInfo), C.POINTER(C.POINTER(C.c_double)),
                                           C.POINTER(C.POINTER(C.c_double)), _P]),
+    "psignn_broyden_batchable": (_INT, [_INT, C.POINTER(_P)]),
     "psignn_broyden_get_iterate": (_INT, [_P, _INT, _P, _P]),
     "psignn_broyden_get_pair": (_INT, [_P, _INT, _INT, _P, _P]),
     "psignn_broyden_ext_begin": (_INT, [_P, _P, _P, _P]),
@@ -122,6 +123,7 @@ SIGNATURES = {
     "psignn_gmres_history": (_INT, [_P, C.POINTER(C.c_double), _P]),
     "psignn_gmres_reorth_count": (_INT, [_P, C.POINTER(C.c_int), _P]),
     "psignn_prof_enable": (None, [_INT]),
+    "psignn_reload_knobs": (None, []),
     "psignn_prof_tile_stamps": (None, [_P]),
     "psignn_prof_collect": (_INT, []),
     "psignn_prof_get": (_INT, [_INT, C.c_char_p, _INT, C.POINTER(_I64), C.POINTER(C.c_double)]),

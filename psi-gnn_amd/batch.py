@@ -42,10 +42,10 @@ def solve_shard_batched(model, meshes, device, indices=None, group=8):
     batched device solve (``engine.broyden_solve_batch``: every per-iteration pass is one launch over all of them, own stop
     test per mesh).  Each mesh's result is bit-identical to its own solve with a solver of the same configuration
     (``DeviceBroyden(..., shard_elems=...)``: the sweeps' reduction shapes are sized for the shard) and agrees with the plain
-    ``solve_shard`` path to solver tolerance; meshes the batched solver cannot take together (mixed family, untiled plans,
-    different size classes) fall back to one solve each."""
+    ``solve_shard`` path to solver tolerance; both families (a shard is all dirichlet or all mixed, as every dataset of the
+    reference is).  Meshes the batched solver cannot take together (untiled plans, different size classes, multi-layer blocks)
+    are solved one by one -- decided on the host before anything is allocated or launched; errors of the batched solve raise."""
     import importlib
-    from . import _native as nat
     eng = importlib.import_module(__package__ + ".engine")
     slv = importlib.import_module(__package__ + ".utilities.solver")
     net = getattr(model, "module", model)
@@ -59,16 +59,19 @@ def solve_shard_batched(model, meshes, device, indices=None, group=8):
             h0s = [net.autoencoder.encoder(md.x) for md in mds]
             fmaps = [net.deqdss.f.bind(h0, md) for h0, md in zip(h0s, mds)]
             solved = None
-            if cfg["solver"] is slv.broyden and len(ids) > 1:
+            # batchable? decided on the host BEFORE any solver state is allocated: tiled plans of one family, single-layer
+            # block; then (solvers exist, nothing solved yet) one size class.  Anything the batched solve raises is a real error.
+            if (cfg["solver"] is slv.broyden and len(ids) > 1 and all(f.plan.tiled for f in fmaps)
+                    and len({f.plan.mixed for f in fmaps}) == 1 and fmaps[0].weights.n_layers == 1):
                 total = sum(f.plan.N for f in fmaps) * eng.D
                 solvers = [eng.DeviceBroyden(plan=f.plan, threshold=cfg["fw_thres"], keep_trace=False, shard_elems=total)
                            for f in fmaps]
                 try:
-                    solved = eng.broyden_solve_batch(solvers, fmaps, cfg["fw_tol"])
-                except nat.NativeError:
-                    solved = None          # not one size class / not tiled dirichlet: one solve per mesh below
-                for sv in solvers:
-                    sv.close()
+                    if eng.shard_batchable(solvers):
+                        solved = eng.broyden_solve_batch(solvers, fmaps, cfg["fw_tol"])
+                finally:
+                    for sv in solvers:
+                        sv.close()
             for k, i in enumerate(ids):
                 if solved is not None:
                     h_final, nstep = solved[k]["result"], solved[k]["nstep"]

@@ -10,6 +10,17 @@
 
 void psignn_set_error(const char* fmt, ...);
 
+// Run-time knobs (PSIGNN_* environment variables; A/B scaffolding and test selectors, never needed for a normal run) are read
+// once and cached; psignn_reload_knobs() bumps the epoch so that the next use re-reads them (tests switch forms in-process).
+extern int g_knob_epoch;
+#define KNOB_INT(var, expr)                   \
+  static int var##_epoch = -1;                \
+  static int var = 0;                         \
+  if (var##_epoch != g_knob_epoch) {          \
+    var = (expr);                             \
+    var##_epoch = g_knob_epoch;               \
+  }
+
 #define HIP_TRY(expr)                                                                   \
   do {                                                                                  \
     hipError_t _e = (expr);                                                             \
@@ -176,4 +187,5 @@ struct BatchDesc {
   int32_t nblk_u, npart_u;     // its blocks / per-wave partials per stored pair
   float* parta;                // folded sweep 3: per-wave partials of the next iteration's a, contiguous per stored pair
   int32_t nblk4, pad_;         // its blocks (4 floats per lane)
+  const float* nrmp;           // mixed family: unit normals in plan order (NULL for dirichlet plans)
 };

@@ -450,7 +450,7 @@ extern "C" int psignn_f_jvp(const psignn_plan_t* p, const float* W, int nl, cons
   ARG_CHECK(v != nullptr && out != v, "v is NULL or aliases out");
   ARG_CHECK(p->mixed || nl == 1, "JVP of a multi-layer dirichlet block is not implemented");
   hipStream_t st = (hipStream_t)stream;
-  static const bool mixed_tiled = [] { const char* e = getenv("PSIGNN_MIXED_JVP"); return !(e && strcmp(e, "gather") == 0); }();
+  KNOB_INT(mixed_tiled, [] { const char* e = getenv("PSIGNN_MIXED_JVP"); return (int)!(e && strcmp(e, "gather") == 0); }());
   if (p->tiled && (p->mixed ? mixed_tiled : nl == 1)) {  // caller numbering -> plan order -> tiled kernel -> caller numbering
     const int64_t N = p->N;
     const int P = p->mixed ? 3 : 2;

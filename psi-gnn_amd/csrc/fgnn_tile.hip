@@ -85,10 +85,10 @@ __device__ __forceinline__ void lds_load10at(const float* __restrict__ p, float*
 // nodes run with 80-byte LDS rows (launch_mixed).  Before the barriers the VALU form spilled ~200 SGPRs and lost: 68.2 vs
 // 66.3 us.  The MFMA form stays selectable (PSIGNN_STAGE1=mfma) for A/B runs.
 static int stage1_mfma(bool fused, bool mixed) {
-  static int forced = [] {
+  KNOB_INT(forced, [] {
     const char* e = getenv("PSIGNN_STAGE1");
     return !e ? -1 : (strcmp(e, "mfma") == 0 ? 1 : 0);
-  }();
+  }());
   if (forced >= 0) return forced;
   (void)fused;
   (void)mixed;
@@ -695,10 +695,10 @@ static unsigned tile_grid(int chunk);
 #else
 #define BATCH_WPE_ATTR
 #endif
-template <int P>
+template <int P, bool MIXED>
 __global__ __launch_bounds__(TILE_THREADS) BATCH_WPE_ATTR void k_f_tile_batch(const BatchDesc* __restrict__ descs, int n_mesh, int n_slots, int chunk,
                                                               int off_done, int off_cur, int off_nxt,
-                                                              const float* __restrict__ W, int lofs, int tofs) {
+                                                              const float* __restrict__ W, int lofs, int tofs, int tnofs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int slot = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (slot >= n_slots) return;
@@ -707,17 +707,26 @@ __global__ __launch_bounds__(TILE_THREADS) BATCH_WPE_ATTR void k_f_tile_batch(co
   const BatchDesc& d = descs[m];
   if (d.st[off_done]) return;
   FuseArgs fa{d.upd, d.gx, d.dg, d.xbuf, d.st, off_done, off_cur, off_nxt, d.M, d.nrm_part, d.n_tiles, nullptr};
-  f_tile_body<P, false, true, false>(fa, slot - d.tile_base, nullptr, d.ctx, W, lofs, tofs, 0, 1, d.xbuf, nullptr, 0, d.h0p, d.prbp,
-                                     nullptr, nullptr, lds);
+  f_tile_body<P, MIXED, true, false>(fa, slot - d.tile_base, nullptr, d.ctx, W, lofs, tofs, tnofs, 1, d.xbuf, nullptr, 0, d.h0p, d.prbp,
+                                     d.nrmp, nullptr, lds);
 }
 
 // descs: device array of n_mesh descriptors; max_rows: largest tile + halo row count over the meshes (LDS size).
-int psignn_f_tile_fused_batch(const BatchDesc* d_descs, int n_mesh, int n_slots, int max_rows, const float* W,
+// mixed shards: every tile runs the full kernel (128-byte LDS rows, Neumann branch for the lanes that need it) in tile order --
+// what the single-mesh fused step does below 2 048 plain tiles, and bit-identical to its two-group launch above that
+// (tests/test_gpu_configs.py::test_mixed_two_group_launch_at_natural_size).
+int psignn_f_tile_fused_batch(const BatchDesc* d_descs, int n_mesh, int n_slots, int max_rows, const float* W, int mixed,
                               int off_done, int off_cur, int off_nxt, hipStream_t st) {
-  using L = WLayout<2>;
   const int chunk = (int)cdiv(n_slots, 8);
-  LAUNCH("k_f_tile_fused", st, (k_f_tile_batch<2><<<tile_grid(chunk), TILE_THREADS, (size_t)max_rows * TileRow<false>::RS * 4, st>>>(
-      d_descs, n_mesh, n_slots, chunk, off_done, off_cur, off_nxt, W, L::layer(0), L::tp_layer(1, false, 0))));
+  if (mixed) {
+    using L = WLayout<3>;
+    LAUNCH("k_f_tile_fused", st, (k_f_tile_batch<3, true><<<tile_grid(chunk), TILE_THREADS, (size_t)max_rows * TileRow<true>::RS * 4, st>>>(
+        d_descs, n_mesh, n_slots, chunk, off_done, off_cur, off_nxt, W, L::layer(0), L::tp_layer(1, true, 0), L::tp_neu(1))));
+  } else {
+    using L = WLayout<2>;
+    LAUNCH("k_f_tile_fused", st, (k_f_tile_batch<2, false><<<tile_grid(chunk), TILE_THREADS, (size_t)max_rows * TileRow<false>::RS * 4, st>>>(
+        d_descs, n_mesh, n_slots, chunk, off_done, off_cur, off_nxt, W, L::layer(0), L::tp_layer(1, false, 0), 0)));
+  }
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }

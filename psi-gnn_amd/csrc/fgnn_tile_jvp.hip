@@ -523,10 +523,10 @@ int psignn_f_tile_jvp(const psignn_plan* p, const float* W, int nl, const float*
   const size_t lds = (size_t)p->max_rows * 40 * 4;
   ARG_CHECK(lds <= 160 * 1024, "tile + halo rows exceed the LDS budget of the tiled JVP");
   // stage-1 form: PSIGNN_JVP_STAGE1 = mfma | valu (default: see the A/B in DESIGN.md)
-  static const int use_mfma = [] {
+  KNOB_INT(use_mfma, [] {
     const char* e = getenv("PSIGNN_JVP_STAGE1");
-    return e ? (strcmp(e, "mfma") == 0) : JVP_STAGE1_DEFAULT_MFMA;
-  }();
+    return e ? (int)(strcmp(e, "mfma") == 0) : (int)JVP_STAGE1_DEFAULT_MFMA;
+  }());
   if (use_mfma)
     LAUNCH("k_jvp_tile", st, (k_jvp_tile<2, false, true><<<(unsigned)(chunk * 8), TILE_THREADS, lds, st>>>(
         (int)p->n_tiles, chunk, nullptr, JVP_TILE_ARGS, W, L::layer(0), L::tp_layer(nl, false, 0), 0, h, prb, nrm, v, out)));

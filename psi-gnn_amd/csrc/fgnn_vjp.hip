@@ -601,7 +601,7 @@ extern "C" int psignn_f_vjp(const psignn_plan_t* p, const float* W, int nl, cons
   ARG_CHECK(!p->mixed || nrm, "mixed plan needs unit normals");
   ARG_CHECK(out != w && out != h, "out must not alias its inputs");
   hipStream_t st = (hipStream_t)stream;
-  static const bool mixed_tiled = [] { const char* e = getenv("PSIGNN_MIXED_VJP"); return !(e && strcmp(e, "gather") == 0); }();
+  KNOB_INT(mixed_tiled, [] { const char* e = getenv("PSIGNN_MIXED_VJP"); return (int)!(e && strcmp(e, "gather") == 0); }());
   if (p->tiled && (p->mixed ? mixed_tiled : nl == 1)) {
     // caller numbering -> plan order -> tiled kernels -> caller numbering
     const int64_t N = p->N;

@@ -263,7 +263,13 @@ __global__ __launch_bounds__(TB) void k_and_check(FpStatus* st, const float* __r
                                                   double* __restrict__ rel_trace, double* __restrict__ abs_trace,
                                                   int32_t* __restrict__ low_idx, double eps, int thr, int k) {
   __shared__ double sh[TB];
-  if (st->done) return;
+  if (st->done) {
+    // The host runs ahead of the stop by up to poll_every - 1 steps.  The stopping step left new_low = 1 (a tolerance stop is
+    // always a new lowest objective): without this reset every later psignn_anderson_update would copy its stale X[slot] over
+    // the lowest iterate, and the solve would return iterate k* - r instead of k*.
+    if (threadIdx.x == 0) st->new_low = 0;
+    return;
+  }
   const double sg = block_sum_partials(part, npart, sh);
   const double sf = block_sum_partials(part + npart, npart, sh);
   if (threadIdx.x != 0) return;

@@ -407,7 +407,7 @@ extern "C" int psignn_gmres_step(psignn_gmres_t* s, int j, double shift, double 
   hipStream_t st = (hipStream_t)stream;
   const unsigned g = (unsigned)s->nblk;
   float* w = s->V + (size_t)(j + 1) * s->ld;
-  static const int always = [] { const char* e = getenv("PSIGNN_GMRES_REORTH"); return e && strcmp(e, "always") == 0 ? 1 : 0; }();
+  KNOB_INT(always, [] { const char* e = getenv("PSIGNN_GMRES_REORTH"); return e && strcmp(e, "always") == 0 ? 1 : 0; }());
   for (int pass = 0; pass < 2; ++pass) {
     VLAUNCH("k_gm_dots", st, s->vec, k_gm_dots, (g, TB, 0, st), s->M, s->ld, j, 0.f, s->st, s->V, w, s->part, s->npart, pass);
     LAUNCH("k_gm_reduce", st, (k_gm_reduce<<<(unsigned)(j + 1 + (pass == 0)), TB, 0, st>>>(s->st, s->part, s->npart, s->coef, s->hcol, pass, j + 1)));

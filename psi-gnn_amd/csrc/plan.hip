@@ -22,6 +22,8 @@ void psignn_set_error(const char* fmt, ...) {
 }
 extern "C" const char* psignn_last_error(void) { return g_err.c_str(); }
 extern "C" int psignn_version(void) { return 100; }
+int g_knob_epoch = 0;
+extern "C" void psignn_reload_knobs(void) { ++g_knob_epoch; }
 
 // ------------------------------------------------------------------ event profiler
 #include <map>

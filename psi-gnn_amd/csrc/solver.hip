@@ -1035,7 +1035,7 @@ static int broyden_alloc(psignn_broyden* s) {
   // 16 floats per lane from 768 K elements up, 4 below (PSIGNN_VEC16_MIN overrides).  Re-tuned after the coalesced lane
   // mapping, Broyden iterations/s with 4 vs 16 (dirichlet meshes, K = 100): 27 k nodes 12 790 / 10 156, 50 k 8 283 /
   // 7 826, 100 k 4 578 / 4 972, 200 k 2 608 / 2 806, 400 k 1 416 / 1 551 (the old switch point was 4 M elements)
-  static const int64_t vec16_min = [] {
+  const int64_t vec16_min = [] {
     const char* e = getenv("PSIGNN_VEC16_MIN");
     return e ? (int64_t)atoll(e) : (int64_t)3 << 18;
   }();
@@ -1349,7 +1349,7 @@ extern "C" int psignn_broyden_solve(psignn_broyden_t* s, const float* W, int nl,
   VPLAIN(s->vec, k_begin, (g, TB, 0, st), s->M, s->h0p, s->fx, s->xbuf, s->gx, s->upd);
   const bool fused = p->tiled && (nl == 1 || p->mixed);
   const int32_t* st_words = reinterpret_cast<const int32_t*>(s->st);
-  static const bool use_graph = [] { const char* e = getenv("PSIGNN_GRAPH"); return e && atoi(e) != 0; }();
+  KNOB_INT(use_graph, [] { const char* e = getenv("PSIGNN_GRAPH"); return (int)(e && atoi(e) != 0); }());
   if (use_graph && fused && !g_prof_on) {
     // one graph per chunk of poll_every iterations (the iteration index is a kernel argument); every kernel returns at once
     // when the device-side done flag is set, so a chunk that overshoots the stop is harmless
@@ -1512,12 +1512,29 @@ __global__ void kb_all_done(const BatchDesc* __restrict__ descs, int n, int off_
   }
 }
 
-int psignn_f_tile_fused_batch(const BatchDesc* d_descs, int n_mesh, int n_slots, int max_rows, const float* W,
+int psignn_f_tile_fused_batch(const BatchDesc* d_descs, int n_mesh, int n_slots, int max_rows, const float* W, int mixed,
                               int off_done, int off_cur, int off_nxt, hipStream_t st);
 
+// 1 when psignn_broyden_solve_batch takes these solvers together: tiled plans of ONE boundary-condition family and one size
+// class (the vector width / split layout / threshold / fold limits that broyden_alloc derives from the shard size) -- a host-side
+// question, asked before the solve so that a shard the batched solver cannot take is not an error path.
+extern "C" int psignn_broyden_batchable(int n, psignn_broyden_t* const* sv) {
+  if (n <= 0 || !sv || !sv[0] || !sv[0]->plan) return 0;
+  const psignn_broyden* s0 = sv[0];
+  for (int m = 0; m < n; ++m) {
+    const psignn_broyden* s = sv[m];
+    if (!s || !s->plan || !s->plan->tiled || s->plan->mixed != s0->plan->mixed) return 0;
+    if (!(s->vec == s0->vec && s->vec_ax == s0->vec_ax && s->uvu == s0->uvu && s->vec_u == s0->vec_u && s->thr == s0->thr &&
+          s->u2d_kmax == s0->u2d_kmax && s->u2d_keep == s0->u2d_keep && s->u2d_reg == s0->u2d_reg))
+      return 0;
+  }
+  return 1;
+}
+
 extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const float* W, int nl, const float* const* h0,
-                                          const float* const* prb, double eps, int poll_every, float* const* d_results,
-                                          psignn_solve_info_t* infos, double* const* h_rel, double* const* h_abs, void* stream) {
+                                          const float* const* prb, const float* const* nrm, double eps, int poll_every,
+                                          float* const* d_results, psignn_solve_info_t* infos, double* const* h_rel,
+                                          double* const* h_abs, void* stream) {
   ARG_CHECK(n > 0 && sv && W && h0 && prb, "bad arguments");
   ARG_CHECK(nl == 1, "the batched solver runs single-layer blocks");
   hipStream_t st = (hipStream_t)stream;
@@ -1527,11 +1544,13 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
   int max_g = 0, max_ga = 0, max_gu = 0, max_g4 = 0, max_G = 1, max_rows = 0, n_slots = 0;
   for (int m = 0; m < n; ++m) {
     const psignn_broyden* s = sv[m];
-    ARG_CHECK(s && s->plan && s->plan->tiled && !s->plan->mixed, "batched solve: tiled dirichlet plans only");
+    ARG_CHECK(s && s->plan && s->plan->tiled, "batched solve: tiled plans only");
+    ARG_CHECK(s->plan->mixed == s0->plan->mixed, "batched solve: one boundary-condition family per shard");
     ARG_CHECK(s->vec == s0->vec && s->vec_ax == s0->vec_ax && s->uvu == s0->uvu && s->vec_u == s0->vec_u && s->thr == s0->thr &&
                   s->u2d_kmax == s0->u2d_kmax && s->u2d_keep == s0->u2d_keep && s->u2d_reg == s0->u2d_reg,
               "batched solve: meshes of different size classes (vector width / threshold differ)");
     ARG_CHECK(h0[m] && prb[m], "NULL argument");
+    ARG_CHECK(!s->plan->mixed || (nrm && nrm[m]), "mixed plans need unit normals");
     max_g = std::max(max_g, s->nblk);
     max_ga = std::max(max_ga, s->nblk_ax);
     max_gu = std::max(max_gu, s->nblk_u);
@@ -1549,8 +1568,10 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
     s->plan_order = 1;
     k_init_status<<<4, TB, 0, st>>>(s->st, s->rel_trace, s->abs_trace, s->thr, s->stop_abs);
     if ((rc = psignn_plan_permute(p, h0[m], D, s->h0p, 1, st))) return rc;
-    if ((rc = psignn_plan_permute(p, prb[m], 2, s->prbp, 1, st))) return rc;
-    if ((rc = psignn_f_eval_p(p, W, nl, s->h0p, nullptr, 0, s->h0p, s->prbp, nullptr, s->fx, s->fwork, st))) return rc;
+    if ((rc = psignn_plan_permute(p, prb[m], p->mixed ? 3 : 2, s->prbp, 1, st))) return rc;
+    if (p->mixed && (rc = psignn_plan_permute(p, nrm[m], 2, s->nrmp, 1, st))) return rc;
+    const float* nrmp = p->mixed ? s->nrmp : nullptr;
+    if ((rc = psignn_f_eval_p(p, W, nl, s->h0p, nullptr, 0, s->h0p, s->prbp, nrmp, s->fx, s->fwork, st))) return rc;
     VPLAIN(s->vec, k_begin, ((unsigned)s->nblk, TB, 0, st), s->M, s->h0p, s->fx, s->xbuf, s->gx, s->upd);
     BatchDesc& d = hd[m];
     d.M = s->M; d.ld = s->ld; d.nblk = s->nblk; d.npart = s->npart; d.nblk_ax = s->nblk_ax; d.jgroups = s->jgroups;
@@ -1560,7 +1581,7 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
     d.nrm_part = s->nrm_part; d.jpart = s->jpart; d.rel_trace = s->rel_trace; d.abs_trace = s->abs_trace;
     d.ctx = p->d_ctx; d.h0p = s->h0p; d.prbp = s->prbp;
     d.part2 = s->part2; d.nblk_u = s->nblk_u; d.npart_u = s->npart_u;
-    d.parta = s->parta; d.nblk4 = s->nblk4; d.pad_ = 0;
+    d.parta = s->parta; d.nblk4 = s->nblk4; d.pad_ = 0; d.nrmp = nrmp;
     max_g4 = std::max(max_g4, s->nblk4);
     base += (int)p->n_tiles;
   }
@@ -1589,7 +1610,7 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
   bool a_ready = false;
   int a_from_next = 0;
   for (int it = 0; it < thr; ++it) {
-    rc = psignn_f_tile_fused_batch(d_descs, n, n_slots, max_rows, W, off_done, sel_off_cur(), sel_off_nxt(), st);
+    rc = psignn_f_tile_fused_batch(d_descs, n, n_slots, max_rows, W, s0->plan->mixed, off_done, sel_off_cur(), sel_off_nxt(), st);
     if (rc) { cleanup(); return rc; }
     const int k = it;
     const int kd = k >= thr ? 0 : k;

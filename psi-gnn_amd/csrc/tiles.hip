@@ -549,10 +549,10 @@ done:
 // Tile structures: strips first, the Hilbert order where strips exceed a structure limit (halo > 512: graded meshes whose
 // strips degenerate into long thin tiles), untiled where that fails too.  PSIGNN_TILING = strips | hilbert forces one.
 int psignn_tiles_build(psignn_plan* p, const float* d_pos, int tile_target, hipStream_t st) {
-  static const int forced = [] {
+  KNOB_INT(forced, [] {
     const char* e = getenv("PSIGNN_TILING");
     return !e ? -1 : (strcmp(e, "hilbert") == 0 ? 1 : 0);
-  }();
+  }());
   if (!d_pos || forced >= 0) return tiles_build_mode(p, d_pos, tile_target, st, forced > 0 ? 1 : 0);
   int rc = tiles_build_mode(p, d_pos, tile_target, st, 0);
   if (rc == 0 && !p->tiled) rc = tiles_build_mode(p, d_pos, tile_target, st, 1);

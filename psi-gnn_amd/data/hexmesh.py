@@ -223,18 +223,22 @@ def vertex_normals(pos, tri):
 
 def make_hex_problem(n: int, seed: int = 0, mixed: bool = False, warp: float = 0.15,
                      phase: float | None = None, compute_sol: bool = True,
-                     dtype=torch.float32) -> MeshData:
+                     dtype=torch.float32, hsize: float = HSIZE, radius: float | None = None) -> MeshData:
     """One synthetic Poisson problem on the warped hexagon with ``3n^2+3n+1`` nodes.
 
     dirichlet: whole boundary ring is Dirichlet.  mixed: the six sides alternate
     Dirichlet / Neumann (corner nodes Dirichlet), homogeneous Neumann.
+    ``hsize``: triangle side (default 0.08, the dirichlet dataset's ``hsize``, dirichlet/dataset/generate_data.py:37; the mixed
+    training set's mean edge length is 0.068 by its normalisation constants, mixed/psignn/utilities/reader.py:77).
+    ``radius``: what the coordinates are divided by inside the problem's f and g (default: the hexagon's side n * hsize).
     """
     if phase is None:
         phase = 0.0
-    pos, tri, q, r = hex_lattice(n, HSIZE, warp, phase)
+    pos, tri, q, r = hex_lattice(n, hsize, warp, phase)
     s = -q - r
     ring = np.maximum(np.maximum(np.abs(q), np.abs(r)), np.abs(s)) == n
-    radius = n * HSIZE
+    if radius is None:   # the (f, g) fields are functions of pos / radius (extract_data.py:19-32; the reference passes its nominal domain radius 1.0)
+        radius = n * hsize
     if not mixed:
         return make_from_triangulation(pos, tri, ring, seed=seed, radius=radius, mixed=False,
                                        compute_sol=compute_sol, dtype=dtype)

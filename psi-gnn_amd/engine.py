@@ -979,10 +979,20 @@ class DeviceBroyden:
         return out
 
 
+def shard_batchable(solvers) -> bool:
+    """Whether ``broyden_solve_batch`` takes these solvers together: tiled plans of one family (all dirichlet or all mixed) and one
+    size class (``psignn_broyden_batchable``).  A host-side decision -- real errors of the batched solve still raise."""
+    n = len(solvers)
+    if n == 0:
+        return False
+    arr = (C.c_void_p * n)(*[s.handle.value for s in solvers])
+    return bool(nat.lib().psignn_broyden_batchable(n, arr))
+
+
 def broyden_solve_batch(solvers, fmaps, eps, poll_every=8):
     """One lockstep device solve of several independent meshes (``psignn_broyden_solve_batch``): ``solvers[i]`` is a
-    ``DeviceBroyden`` of ``fmaps[i].plan``.  Returns the list of per-mesh result dicts of ``DeviceBroyden.solve`` -- each
-    bit-identical to solving that mesh alone."""
+    ``DeviceBroyden`` of ``fmaps[i].plan``; all dirichlet or all mixed.  Returns the list of per-mesh result dicts of
+    ``DeviceBroyden.solve`` -- each bit-identical to solving that mesh alone."""
     n = len(solvers)
     if n == 0:
         return []
@@ -1005,7 +1015,8 @@ def broyden_solve_batch(solvers, fmaps, eps, poll_every=8):
     with torch.cuda.device(dev):
         nat.check(nat.lib().psignn_broyden_solve_batch(
             n, arr([s.handle.value for s in solvers]), nat.ptr(w0.flat), w0.n_layers, arr([nat.ptr(f.h0) for f in fmaps]),
-            arr([nat.ptr(f.prb) for f in fmaps]), float(eps), int(poll_every), arr([nat.ptr(r) for r in results]), infos,
+            arr([nat.ptr(f.prb) for f in fmaps]), arr([nat.ptr(f.nrm) for f in fmaps]) if w0.mixed else None,
+            float(eps), int(poll_every), arr([nat.ptr(r) for r in results]), infos,
             dpp(rel), dpp(abs_), nat.stream_ptr(dev)), "psignn_broyden_solve_batch")
     outs = []
     for i, s in enumerate(solvers):

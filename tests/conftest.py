@@ -65,3 +65,21 @@ def load_circlelarge():
                                       coeffs=(z["param_f"], z["param_g"]))
     band = json.load(open(os.path.join(GOLDEN, "circlelarge_band.json")))
     return mesh, band
+
+
+@pytest.fixture
+def knobs(monkeypatch):
+    """``knobs(PSIGNN_X="...")``: set PSIGNN_* run-time knobs of libpsignn_hip.so for this test (alternative kernel forms: MFMA
+    stage 1, Hilbert tiling, ...) and make the library re-read them; everything is restored, and re-read, afterwards."""
+    nat = pkg("_native")
+
+    def apply(**env):
+        for k, v in env.items():
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, str(v))
+        nat.lib().psignn_reload_knobs()
+    yield apply
+    monkeypatch.undo()
+    nat.lib().psignn_reload_knobs()

@@ -93,10 +93,26 @@ def test_plan_degenerate_graphs(dev):
 
 
 # ------------------------------------------------------------------------------------------ f
+FORMS_F = {"default": {}, "stage1_mfma": {"PSIGNN_STAGE1": "mfma"}, "stage1_valu": {"PSIGNN_STAGE1": "valu"},
+           "hilbert": {"PSIGNN_TILING": "hilbert"}}
+
+
+@pytest.mark.parametrize("form", list(FORMS_F))
 @pytest.mark.parametrize("name", list(CASES))
-def test_single_f_parity(name, dev):
+def test_single_f_parity(name, form, dev, knobs):
+    """One f application against the goldens and the oracle -- in the default form and in every selectable form of the tile
+    kernel (stage 1 on the matrix cores, ``v_mfma_f32_16x16x4_f32``, or on packed VALU; Hilbert instead of strip tiling):
+    the forms order every sum the same way, so their outputs are bit-identical to the default's."""
     g, mesh, md, sd, fmap = bind(name, dev)
     h0 = torch.from_numpy(g["h0"]).to(dev)
+    if form != "default":
+        base = fmap(h0)
+        knobs(**FORMS_F[form])
+        md2 = mesh.to(dev)                                   # (a fresh batch object: the tiling is chosen when the plan is built)
+        eng = pkg("engine")
+        fmap = eng.FixedPointMap(eng.MeshPlan(md2), fmap.weights, h0, md2.prb_data, getattr(md2, "unit_normal_vector", None))
+        assert fmap.plan.tiled
+        assert torch.equal(fmap(h0), base), form
     f1 = fmap(h0)
     f2 = fmap(f1)
     assert rel_l2(f1, g["f1"]) < 2e-6, rel_l2(f1, g["f1"])
@@ -189,11 +205,24 @@ def test_mixed_multi_layer_quirk(dev):
 
 
 # ------------------------------------------------------------------------------------------ JVP
+FORMS_JVP = {"default": {}, "stage1_mfma": {"PSIGNN_JVP_STAGE1": "mfma"}, "stage1_valu": {"PSIGNN_JVP_STAGE1": "valu"},
+             "hilbert": {"PSIGNN_TILING": "hilbert"}}
+
+
+@pytest.mark.parametrize("form", list(FORMS_JVP))
 @pytest.mark.parametrize("name", ["original_dirichlet_s0", "hex13_dirichlet_s0", "hex13_mixed_s1"])
-def test_jvp_parity(name, dev):
+def test_jvp_parity(name, form, dev, knobs):
+    """Analytic J_f v against float64 autograd, in every selectable form of the tiled JVP kernel (bit-identical outputs)."""
     g, mesh, md, sd, fmap = bind(name, dev)
     hp = torch.from_numpy(g["jv_point"]).float().to(dev)
     v = torch.from_numpy(g["jv_dir"]).float().to(dev)
+    if form != "default":
+        base = fmap.jvp(hp, v)
+        knobs(**FORMS_JVP[form])
+        md2 = mesh.to(dev)
+        eng = pkg("engine")
+        fmap = eng.FixedPointMap(eng.MeshPlan(md2), fmap.weights, fmap.h0, md2.prb_data, getattr(md2, "unit_normal_vector", None))
+        assert torch.equal(fmap.jvp(hp, v), base), form
     jv = fmap.jvp(hp, v)
     assert rel_l2(jv, g["jvp64"]) < 1e-5, rel_l2(jv, g["jvp64"])
     # linearity and consistency with a central finite difference of the HIP f itself
@@ -728,6 +757,15 @@ def test_forward_iteration_anderson_newton(dev):
     assert abs(out["nstep"] - int(g["anderson_nstep"])) <= 3
     np.testing.assert_allclose(out["rel_trace"][:5], g["anderson_rel_trace"][:5], rtol=1e-2)
     assert rel_l2(out["result"], g["anderson_result"]) < 1e-3
+    # the host runs ahead of a tolerance stop by up to poll_every - 1 steps: the result must be the STOPPING step's iterate
+    # (= the lowest, solver.py:270-283) whatever the poll interval -- bitwise, and equal to the last entry of xest_trace
+    runs = {pe: solver.anderson(fmap, fmap.h0, threshold=80, eps=1e-5, poll_every=pe, keep_trace=True) for pe in (1, 8, 5)}
+    a = runs[1]
+    assert a["nstep"] < 79 and a["lowest"] < 1e-5                       # a tolerance stop, not the threshold
+    for pe, o in runs.items():
+        assert o["nstep"] == a["nstep"] and o["rel_trace"] == a["rel_trace"], pe
+        assert torch.equal(o["result"], a["result"]), pe
+        assert torch.equal(o["result"], o["xest_trace"][len(o["xest_trace"]) - 1]), pe
     # block-diagonal Newton: the analytic blocks equal autograd's blocks on a tiny mesh
     data, eng = pkg("data"), pkg("engine")
     small = data.make_hex_problem(2, seed=0)
