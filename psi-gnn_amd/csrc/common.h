@@ -188,4 +188,5 @@ struct BatchDesc {
   float* parta;                // folded sweep 3: per-wave partials of the next iteration's a, contiguous per stored pair
   int32_t nblk4, pad_;         // its blocks (4 floats per lane)
   const float* nrmp;           // mixed family: unit normals in plan order (NULL for dirichlet plans)
+  int64_t pstride;             // plane stride of the dot partials (solver.hip: part = 3 planes of (blocks, ldp))
 };

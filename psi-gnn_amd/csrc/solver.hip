@@ -37,6 +37,57 @@ struct Status {
   double s, beta;       // vT.dg, vT.g
 };
 
+// ---- dot-product partials: one value per BLOCK and stored pair, written as coalesced rows -------------------------------------
+// Round 2 had the lead lane of every wave store its wave sum of every pair straight to memory: one 4-byte store instruction per
+// wave and pair, ~1 M scattered partial-line writes per sweep at 1M nodes.  Measured in isolation (scripts/ubench_sweep2.hip,
+// profiles/r3_ubench_sweep2.txt): a sweep that streams at 0.78 of the HBM peak without them runs at 0.65 (4 floats per lane) /
+// 0.71 (16 floats per lane) with them -- the wave reductions themselves cost nothing.  Now the lead lanes stash their wave sums
+// in LDS, and after every 64 pairs (and after the last one) the block's first 64 threads add the four waves' values in a fixed
+// order and store ONE contiguous row segment: part[plane][block * ldp + j].  Same bench: 0.76.  The reduce kernels read a
+// column of that (blocks x pairs) matrix per pair -- 64-byte sectors from L2, a quarter as many elements as before.
+#define PARTA_LD 32            // row pitch of the folded sweep's partials: at most U2R_KB_MAX + 1 = 25 kept pairs
+template <int NV>
+struct PairStash {
+  float v[NV][TB / 64][64];
+};
+// every thread of the block calls this with the same j, cnt (1..64 pairs stashed at slots 0..cnt-1) -- it contains barriers
+template <int NV>
+__device__ __forceinline__ void stash_flush(PairStash<NV>& sh, int cnt, float* const (&row)[NV]) {
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < cnt) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) row[q][t] = (sh.v[q][0][t] + sh.v[q][1][t]) + (sh.v[q][2][t] + sh.v[q][3][t]);
+  }
+  __syncthreads();
+}
+// sum of n values p[b * stride], b = 0 .. n-1 (one column of a partials plane; stride 1: a contiguous list), fixed shape for a
+// given block size: thread-strided, 4 loads in flight, tree.  (RB = 1 024 threads per reduce block was tried for the column reads:
+// k_reduce_cb 9.7 vs 8.3 us, k_reduce_a_check unchanged -- a block's time is the 64-byte sectors it pulls through ONE CU, not
+// its load rounds; what helps is more blocks per column, RA below.)
+#define RB 256
+#define RA 8     // row chunks per column of the a-reduction: coef_a arrives as RA partial sums that sweep 2 adds up itself
+__device__ inline double block_sum_col(const float* __restrict__ p, int n, int64_t stride, double* sh) {
+  const int T = blockDim.x;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * T < n; i += 4 * T) {
+    const float a = p[(int64_t)i * stride], b = p[(int64_t)(i + T) * stride], c = p[(int64_t)(i + 2 * T) * stride],
+                d = p[(int64_t)(i + 3 * T) * stride];
+    s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
+  }
+  for (; i < n; i += T) s0 += (double)p[(int64_t)i * stride];
+  sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  for (int o = T / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
 struct psignn_broyden {
   const psignn_plan* plan = nullptr;
   int64_t M = 0;
@@ -58,11 +109,14 @@ struct psignn_broyden {
   int u2d_kmax = 0, nblk4 = 0, a_ready = 0; // k_sweep_u2d: up to this many stored pairs are all kept; its blocks; a of the next iteration comes (partly) from it
   int u2d_keep = 0, a_from = 0;             // beyond u2d_kmax: the most recent u2d_keep pairs are kept; pairs before a_from still need sweep 1
   int u2d_reg = 1;                          // kept values in registers (k_sweep_u2r<KB>, the default) or in per-thread LDS slots (k_sweep_u2d; PSIGNN_U2D_FORM=lds)
-  float* parta = nullptr;                   // its per-wave partials of a, contiguous per stored pair: (u2d_kmax + 2, nblk4 * 4)
+  float* parta = nullptr;                   // its per-block partials of a: (nblk4, PARTA_LD) -- entry q of a row = pair j_keep0 + q
   int nn_cap = 0;
   float *h0p = nullptr, *prbp = nullptr, *nrmp = nullptr;  // plan-order copies of h_initial, prb_data, normals
-  float* part = nullptr;    // (3, thr, npart) dot partials; reused for the norm / s,beta partials
-  float* coef = nullptr;    // (3, thr)
+  float* part = nullptr;    // dot partials: 3 planes (a, c, b) of (blocks, ldp) -- one value per BLOCK and stored pair, pairs contiguous
+                            // (pair_rows below); its head is reused for the axpy pass's s, beta partials
+  int ldp = 0;              // row pitch of a plane: thr rounded up to 64
+  int64_t pstride = 0;      // plane stride (floats): max blocks of any sweep form x ldp
+  float* coef = nullptr;    // (3 + RA, thr): a, c, b; then the RA row-chunk sums of a (three-sweep forms: what sweep 2 reads)
   Status* st = nullptr;     // device
   double *rel_trace = nullptr, *abs_trace = nullptr;  // device, thr entries
   Status* h_st = nullptr;   // pinned host mirror
@@ -178,8 +232,8 @@ __global__ __launch_bounds__(TB) void k_resid(int64_t M, const Status* __restric
 __device__ void check_block(Status* st, const float* __restrict__ part, int npart, double* __restrict__ rel_trace,
                             double* __restrict__ abs_trace, double eps, int thr, int seq_len, int keep_trace, double* sh) {
   if (st->done) return;
-  double sg = block_sum_partials(part, npart, sh);
-  double sf = block_sum_partials(part + npart, npart, sh);
+  double sg = block_sum_col(part, npart, 1, sh);
+  double sf = block_sum_col(part + npart, npart, 1, sh);
   if (threadIdx.x != 0) return;
   // torch.norm(...) is an fp32 value read back with .item(); the division is done in Python doubles
   double abs_diff = (double)(float)sqrt(sg);
@@ -243,17 +297,16 @@ __device__ void check_block(Status* st, const float* __restrict__ part, int npar
   }
 }
 
-#ifndef DOTS_PART4
-#define DOTS_PART4 1   // layout of the dots partials (A/B in profiles/r2_batch_sweep_ab.txt)
-#endif
-// dots pass: per-wave partials of a_j = dx.U_j, c_j = V_j.dg, b_j = V_j.g   for j < k
+#define DOTS_PART4 1   // (historic switch of the partials layout; the three-sweep forms below assume the current one)
+// dots pass: per-block partials of a_j = dx.U_j, c_j = V_j.dg, b_j = V_j.g   for j < k
 template <int VEC>
 __device__ __forceinline__ void dots_body(int64_t M, int k, const Status* __restrict__ st,
                                              const float* __restrict__ U, const float* __restrict__ V,
                                              const float* __restrict__ dxv, const float* __restrict__ dgv,
-                                             const float* __restrict__ gv, float* __restrict__ part, int npart, int thr,
+                                             const float* __restrict__ gv, float* __restrict__ part, int64_t pstride, int ldp,
                                              int jstride, int64_t ld) {
-  if (st->done) return;
+  __shared__ PairStash<3> sh;
+  if (__builtin_amdgcn_readfirstlane(st->done)) return;
   // blockIdx.y owns the stored pairs [j0, j1): short vectors (small meshes) give few blocks along x, so the
   // sweep is also split over j to cover the 256 CUs (each j still belongs to exactly one block row)
   const int j0 = blockIdx.y * jstride, j1 = min(k, j0 + jstride);
@@ -269,8 +322,9 @@ __device__ __forceinline__ void dots_body(int64_t M, int k, const Status* __rest
 #pragma unroll
     for (int i = 0; i < VEC; ++i) dx[i] = dg[i] = g[i] = 0.f;
   }
-  int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
-  bool lead = (threadIdx.x & 63) == 0;
+  const int wv = threadIdx.x >> 6;
+  const bool lead = (threadIdx.x & 63) == 0;
+  float* rowb = part + (int64_t)blockIdx.x * ldp;
   for (int j = j0; j < j1; ++j) {
     float u[VEC], v[VEC];
     float sa = 0.f, sc = 0.f, sb = 0.f;
@@ -287,14 +341,15 @@ __device__ __forceinline__ void dots_body(int64_t M, int k, const Status* __rest
     sa = wave_sum(sa);
     sc = wave_sum(sc);
     sb = wave_sum(sb);
+    const int q = (j - j0) & 63;
     if (lead) {
-#if DOTS_PART4   // one 16-byte store per wave and stored pair: {a, c, b, -} of wave w at part[(j * npart + w) * 4]
-      *reinterpret_cast<float4*>(part + ((int64_t)j * npart + w) * 4) = make_float4(sa, sc, sb, 0.f);
-#else
-      part[((int64_t)0 * thr + j) * npart + w] = sa;
-      part[((int64_t)1 * thr + j) * npart + w] = sc;
-      part[((int64_t)2 * thr + j) * npart + w] = sb;
-#endif
+      sh.v[0][wv][q] = sa;
+      sh.v[1][wv][q] = sc;
+      sh.v[2][wv][q] = sb;
+    }
+    if (q == 63 || j == j1 - 1) {
+      float* const rows[3] = {rowb + (j - q), rowb + pstride + (j - q), rowb + 2 * pstride + (j - q)};
+      stash_flush<3>(sh, q + 1, rows);
     }
   }
 }
@@ -302,9 +357,9 @@ template <int VEC>
 __global__ __launch_bounds__(TB) void k_dots(int64_t M, int k, const Status* __restrict__ st,
                                              const float* __restrict__ U, const float* __restrict__ V,
                                              const float* __restrict__ dxv, const float* __restrict__ dgv,
-                                             const float* __restrict__ gv, float* __restrict__ part, int npart, int thr,
+                                             const float* __restrict__ gv, float* __restrict__ part, int64_t pstride, int ldp,
                                              int jstride, int64_t ld) {
-  dots_body<VEC>(M, k, st, U, V, dxv, dgv, gv, part, npart, thr, jstride, ld);
+  dots_body<VEC>(M, k, st, U, V, dxv, dgv, gv, part, pstride, ldp, jstride, ld);
 }
 
 // One launch after the dots pass, grid = (max(k, 1), 4):
@@ -312,7 +367,7 @@ __global__ __launch_bounds__(TB) void k_dots(int64_t M, int k, const Status* __r
 //   block (0, 3): the iteration's bookkeeping (check_block) from the norm partials of the f / residual kernel.
 // The check used to be its own launch before the dots pass; running it here saves a launch per iteration.  The dots
 // pass of the final iteration then runs once more than needed (its results are ignored: every later kernel sees done).
-__device__ __forceinline__ void reduce_check_body(Status* st, const float* __restrict__ part, int npart, int thr, int k,
+__device__ __forceinline__ void reduce_check_body(Status* st, const float* __restrict__ part, int nrows, int64_t pstride, int ldp, int thr, int k,
                                                      float* __restrict__ coef, const float* __restrict__ nrm_part, int nn,
                                                      double* __restrict__ rel_trace, double* __restrict__ abs_trace,
                                                      double eps, int seq_len, int keep_trace, double* sh) {
@@ -323,19 +378,25 @@ __device__ __forceinline__ void reduce_check_body(Status* st, const float* __res
   if (st->done) return;
   int j = blockIdx.x, c = blockIdx.y;
   if (j >= k) return;
-#if DOTS_PART4
-  double s = block_sum_partials<4>(part + (int64_t)j * npart * 4 + c, npart, sh);
-#else
-  double s = block_sum_partials(part + ((int64_t)c * thr + j) * npart, npart, sh);
-#endif
+  const float* col = part + (int64_t)c * pstride + j;   // column j of plane c: one value per block of the dots pass
+  double s;
+  if (c == 0) {   // a: summed as the three-sweep forms sum it -- RA row chunks, each rounded to float, added in order (k_reduce_a_check
+    s = 0.0;      // + sweep 2) -- so that the two forms of the update stay bit-identical
+    for (int r = 0; r < RA; ++r) {
+      const int lo = (int)((int64_t)nrows * r / RA), hi = (int)((int64_t)nrows * (r + 1) / RA);
+      s += (double)(float)block_sum_col(col + (int64_t)lo * ldp, hi - lo, ldp, sh);
+    }
+  } else {
+    s = block_sum_col(col, nrows, ldp, sh);
+  }
   if (threadIdx.x == 0) coef[c * thr + j] = (float)s;
 }
-__global__ __launch_bounds__(TB) void k_reduce_check(Status* st, const float* __restrict__ part, int npart, int thr, int k,
+__global__ __launch_bounds__(RB) void k_reduce_check(Status* st, const float* __restrict__ part, int nrows, int64_t pstride, int ldp, int thr, int k,
                                                      float* __restrict__ coef, const float* __restrict__ nrm_part, int nn,
                                                      double* __restrict__ rel_trace, double* __restrict__ abs_trace,
                                                      double eps, int seq_len, int keep_trace) {
-  __shared__ double sh[TB];
-  reduce_check_body(st, part, npart, thr, k, coef, nrm_part, nn, rel_trace, abs_trace, eps, seq_len, keep_trace, sh);
+  __shared__ double sh[RB];
+  reduce_check_body(st, part, nrows, pstride, ldp, thr, k, coef, nrm_part, nn, rel_trace, abs_trace, eps, seq_len, keep_trace, sh);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -346,8 +407,9 @@ __global__ __launch_bounds__(TB) void k_reduce_check(Status* st, const float* __
 // (results bit-identical to the two-pass form; tests/test_gpu_parity.py::test_three_sweep_update_is_bitwise_identical).
 template <int VEC>
 __device__ __forceinline__ void sweep_u1_body(int64_t M, int k, const Status* __restrict__ st, const float* __restrict__ U,
-                                              const float* __restrict__ dxv, float* __restrict__ part, int npart, int64_t ld) {
-  if (st->done) return;
+                                              const float* __restrict__ dxv, float* __restrict__ part, int ldp, int64_t ld) {
+  __shared__ PairStash<1> sh;
+  if (__builtin_amdgcn_readfirstlane(st->done)) return;
   int64_t e0 = elem0<VEC>();
   float dx[VEC];
   const bool act = e0 < M;
@@ -357,8 +419,9 @@ __device__ __forceinline__ void sweep_u1_body(int64_t M, int k, const Status* __
 #pragma unroll
     for (int i = 0; i < VEC; ++i) dx[i] = 0.f;
   }
-  const int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+  const int wv = threadIdx.x >> 6;
   const bool lead = (threadIdx.x & 63) == 0;
+  float* rowb = part + (int64_t)blockIdx.x * ldp;      // plane 0 (a)
   for (int j = 0; j < k; ++j) {
     float u[VEC];
     float sa = 0.f;
@@ -368,41 +431,51 @@ __device__ __forceinline__ void sweep_u1_body(int64_t M, int k, const Status* __
       for (int i = 0; i < VEC; ++i) sa = fmaf(dx[i], u[i], sa);
     }
     sa = wave_sum(sa);
-    if (lead) part[((int64_t)j * npart + w) * 4] = sa;
+    const int q = j & 63;
+    if (lead) sh.v[0][wv][q] = sa;
+    if (q == 63 || j == k - 1) {
+      float* const rows[1] = {rowb + (j - q)};
+      stash_flush<1>(sh, q + 1, rows);
+    }
   }
 }
 
 template <int VEC>
 __global__ __launch_bounds__(TB) void k_sweep_u1(int64_t M, int k, const Status* __restrict__ st, const float* __restrict__ U,
-                                                 const float* __restrict__ dxv, float* __restrict__ part, int npart, int64_t ld) {
-  sweep_u1_body<VEC>(M, k, st, U, dxv, part, npart, ld);
+                                                 const float* __restrict__ dxv, float* __restrict__ part, int ldp, int64_t ld) {
+  sweep_u1_body<VEC>(M, k, st, U, dxv, part, ldp, ld);
 }
 
-// grid (max(k, 1), 2): blocks (j, 0): coef_a[j]; block (0, 1): the iteration's bookkeeping (as k_reduce_check's)
-__device__ __forceinline__ void reduce_a_check_body(Status* st, const float* __restrict__ part, int npart, int thr, int k,
+// grid (max(k, 1), RA + 1): blocks (j, r < RA): row chunk r of column j of the a partials; block (0, RA): the iteration's bookkeeping (as k_reduce_check's)
+__device__ __forceinline__ void reduce_a_check_body(Status* st, const float* __restrict__ part, int nrows, int ldp, int thr, int k,
                                                     float* __restrict__ coef, const float* __restrict__ nrm_part, int nn,
                                                     double* __restrict__ rel_trace, double* __restrict__ abs_trace,
                                                     double eps, int seq_len, int keep_trace, double* sh,
-                                                    const float* __restrict__ parta = nullptr, int npart4 = 0, int a_from = 1 << 30) {
-  if (blockIdx.y == 1) {
+                                                    const float* __restrict__ parta = nullptr, int nrows4 = 0, int a_from = 1 << 30) {
+  if (blockIdx.y == RA) {
     if (blockIdx.x == 0) check_block(st, nrm_part, nn, rel_trace, abs_trace, eps, thr, seq_len, keep_trace, sh);
     return;
   }
   if (st->done) return;
-  const int j = blockIdx.x;
+  const int j = blockIdx.x, r = blockIdx.y;
   if (j >= k) return;
-  // pairs from a_from on: partials of the folded sweep 3 of the last iteration (contiguous); before: sweep 1's (slot 0 of quads)
-  const double s = j >= a_from ? block_sum_contig(parta + (int64_t)j * npart4, npart4, sh)
-                               : block_sum_partials<4>(part + (int64_t)j * npart * 4, npart, sh);
-  if (threadIdx.x == 0) coef[j] = (float)s;
+  // pairs from a_from on: per-block partials of the folded sweep 3 of the last iteration (entry j - a_from of its rows); the older
+  // pairs: sweep 1's (column j of plane 0).  A column of the folded sweep has one row per 1 024 vector elements (9 771 at 1M
+  // nodes), every element a 64-byte sector of its own: RA blocks share it, sweep 2 adds their RA sums (coef + 3 thr + r thr + j).
+  const float* col = j >= a_from ? parta + (j - a_from) : part + j;
+  const int n = j >= a_from ? nrows4 : nrows;
+  const int64_t stride = j >= a_from ? PARTA_LD : ldp;
+  const int lo = (int)((int64_t)n * r / RA), hi = (int)((int64_t)n * (r + 1) / RA);
+  const double s = block_sum_col(col + (int64_t)lo * stride, hi - lo, stride, sh);
+  if (threadIdx.x == 0) coef[(3 + r) * thr + j] = (float)s;
 }
-__global__ __launch_bounds__(TB) void k_reduce_a_check(Status* st, const float* __restrict__ part, int npart, int thr, int k,
+__global__ __launch_bounds__(RB) void k_reduce_a_check(Status* st, const float* __restrict__ part, int nrows, int ldp, int thr, int k,
                                                        float* __restrict__ coef, const float* __restrict__ nrm_part, int nn,
                                                        double* __restrict__ rel_trace, double* __restrict__ abs_trace,
                                                        double eps, int seq_len, int keep_trace, const float* __restrict__ parta,
-                                                       int npart4, int a_from) {
-  __shared__ double sh[TB];
-  reduce_a_check_body(st, part, npart, thr, k, coef, nrm_part, nn, rel_trace, abs_trace, eps, seq_len, keep_trace, sh, parta, npart4, a_from);
+                                                       int nrows4, int a_from) {
+  __shared__ double sh[RB];
+  reduce_a_check_body(st, part, nrows, ldp, thr, k, coef, nrm_part, nn, rel_trace, abs_trace, eps, seq_len, keep_trace, sh, parta, nrows4, a_from);
 }
 
 // sweep 2: reads V once: partials of c_j = V_j.dg, b_j = V_j.g AND vT = -dx + sum_j a_j V_j; then vT's part of axpy_finish
@@ -411,8 +484,10 @@ template <int VEC>
 __device__ __forceinline__ void sweep_v_body(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ V,
                                              const float* __restrict__ dxv, const float* __restrict__ dgv,
                                              const float* __restrict__ gv, const float* __restrict__ coef,
-                                             float* __restrict__ part, int npart, float* __restrict__ part2, int nblk, int64_t ld) {
-  if (st->done) return;
+                                             float* __restrict__ part, int64_t pstride, int ldp, float* __restrict__ part2, int nblk, int64_t ld,
+                                             int thr) {
+  __shared__ PairStash<2> sh;
+  if (__builtin_amdgcn_readfirstlane(st->done)) return;
   int64_t e0 = elem0<VEC>();
   float dg[VEC], g[VEC], av[VEC];
   const bool act = e0 < M;
@@ -426,12 +501,26 @@ __device__ __forceinline__ void sweep_v_body(int64_t M, int k, const Status* __r
 #pragma unroll
     for (int i = 0; i < VEC; ++i) dg[i] = g[i] = av[i] = 0.f;
   }
-  const int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
-  const bool lead = (threadIdx.x & 63) == 0;
+  const int wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const bool lead = lane == 0;
+  float* rowb = part + (int64_t)blockIdx.x * ldp;      // planes 1 (c) and 2 (b)
+  float cw = 0.f;                                       // coef_a of the current chunk of 64 pairs: lane q holds a_{jc + q}
   for (int j = 0; j < k; ++j) {
+    const int q = j & 63;
+    // one vector load of 64 coefficients per chunk, handed out by v_readlane: in the batched kernels the table hangs off a
+    // descriptor in memory, where a scalar per-pair read is a vector load with its full latency inside the loop
+    if (q == 0) {
+      double acc = 0.0;
+      if (j + lane < k) {
+#pragma unroll
+        for (int r = 0; r < RA; ++r) acc += (double)coef[(3 + r) * thr + j + lane];   // the RA row-chunk sums of k_reduce_a_check, fixed order
+      }
+      cw = (float)acc;
+    }
     float v[VEC];
     float sc = 0.f, sb = 0.f;
-    const float ca = coef[j];
+    const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cw), q));
     if (act) {
       ldv_stream<VEC>(V + (int64_t)j * ld, e0, M, v);
 #pragma unroll
@@ -443,7 +532,14 @@ __device__ __forceinline__ void sweep_v_body(int64_t M, int k, const Status* __r
     }
     sc = wave_sum(sc);
     sb = wave_sum(sb);
-    if (lead) *reinterpret_cast<float2*>(part + ((int64_t)j * npart + w) * 4 + 1) = make_float2(sc, sb);
+    if (lead) {
+      sh.v[0][wv][q] = sc;
+      sh.v[1][wv][q] = sb;
+    }
+    if (q == 63 || j == k - 1) {
+      float* const rows[2] = {rowb + pstride + (j - q), rowb + 2 * pstride + (j - q)};
+      stash_flush<2>(sh, q + 1, rows);
+    }
   }
   float p1 = 0.f, p2 = 0.f;
   if (act) {
@@ -461,20 +557,20 @@ template <int VEC>
 __global__ __launch_bounds__(TB) void k_sweep_v(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ V,
                                                 const float* __restrict__ dxv, const float* __restrict__ dgv,
                                                 const float* __restrict__ gv, const float* __restrict__ coef,
-                                                float* __restrict__ part, int npart, float* __restrict__ part2, int nblk,
-                                                int64_t ld) {
-  sweep_v_body<VEC>(M, k, st, V, dxv, dgv, gv, coef, part, npart, part2, nblk, ld);
+                                                float* __restrict__ part, int64_t pstride, int ldp, float* __restrict__ part2, int nblk,
+                                                int64_t ld, int thr) {
+  sweep_v_body<VEC>(M, k, st, V, dxv, dgv, gv, coef, part, pstride, ldp, part2, nblk, ld, thr);
 }
 
 // grid (max(k, 1), 3): blocks (j, 0 | 1): coef_c[j], coef_b[j]; block (0, 2): s = vT.dg, beta = vT.g from sweep 2's block partials
 // (fixed order, fp64, rounded to fp32 like the reference's .item() values -- what every block of k_final used to repeat)
-__device__ __forceinline__ void reduce_cb_body(Status* __restrict__ st, const float* __restrict__ part, int npart, int thr, int k,
+__device__ __forceinline__ void reduce_cb_body(Status* __restrict__ st, const float* __restrict__ part, int nrows, int64_t pstride, int ldp, int thr, int k,
                                                float* __restrict__ coef, const float* __restrict__ part2, int nblk, double* sh) {
   if (st->done) return;
   if (blockIdx.y == 2) {
     if (blockIdx.x != 0) return;
-    const float sv = (float)block_sum_partials(part2, nblk, sh);
-    const float beta = (float)block_sum_partials(part2 + nblk, nblk, sh);
+    const float sv = (float)block_sum_col(part2, nblk, 1, sh);
+    const float beta = (float)block_sum_col(part2 + nblk, nblk, 1, sh);
     if (threadIdx.x == 0) {
       st->s = (double)sv;
       st->beta = (double)beta;
@@ -483,13 +579,13 @@ __device__ __forceinline__ void reduce_cb_body(Status* __restrict__ st, const fl
   }
   const int j = blockIdx.x, c = 1 + blockIdx.y;
   if (j >= k) return;
-  const double s = block_sum_partials<4>(part + (int64_t)j * npart * 4 + c, npart, sh);
+  const double s = block_sum_col(part + (int64_t)c * pstride + j, nrows, ldp, sh);
   if (threadIdx.x == 0) coef[c * thr + j] = (float)s;
 }
-__global__ __launch_bounds__(TB) void k_reduce_cb(Status* __restrict__ st, const float* __restrict__ part, int npart, int thr, int k,
+__global__ __launch_bounds__(RB) void k_reduce_cb(Status* __restrict__ st, const float* __restrict__ part, int nrows, int64_t pstride, int ldp, int thr, int k,
                                                   float* __restrict__ coef, const float* __restrict__ part2, int nblk) {
-  __shared__ double sh[TB];
-  reduce_cb_body(st, part, npart, thr, k, coef, part2, nblk, sh);
+  __shared__ double sh[RB];
+  reduce_cb_body(st, part, nrows, pstride, ldp, thr, k, coef, part2, nblk, sh);
 }
 
 // sweep 3: reads U once: D1 = dx + dg - sum_j c_j U_j, D2 = g - sum_j b_j U_j, and -- s and beta being known by now -- the
@@ -541,14 +637,14 @@ __global__ __launch_bounds__(TB) void k_sweep_u2(int64_t M, int k, const Status*
 // another name, no sharing, no barrier) and take the dot products from there once its piece of update_new is finished:
 // the following iteration then needs no sweep over U for a (V and U read once each while k is small -- all of a K = 20
 // solve).  Direct dot products, exact; other partial-sum shapes than k_sweep_u1 (4 floats per lane here), so the last bits of
-// a differ from the three-sweep form's.  Writes the per-wave partials of a_0 .. a_k contiguously: part[j * npart4 + wave].
+// a differ from the three-sweep form's.  Writes one row of per-block partials: part[block * PARTA_LD + (j - j_keep0)].
 #ifndef U2D_UNROLL
 #define U2D_UNROLL 8   // stored pairs whose loads are in flight together (one wave per SIMD has to keep the memory pipe busy alone)
 #endif
 __device__ __forceinline__ void sweep_u2d_body(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
                                                float* __restrict__ upd, const float* __restrict__ dgv,
                                                const float* __restrict__ gv, const float* __restrict__ coef, int thr,
-                                               float* __restrict__ part, int npart4, int64_t ld, int j_keep0) {
+                                               float* __restrict__ part, int64_t ld, int j_keep0) {
   // j_keep0: first stored pair that is kept (0 while k <= U2D_KMAX: all of them; later only the most recent ones -- the next
   // iteration's sweep 1 then covers the pairs before j_keep0 only)
   extern __shared__ __attribute__((aligned(16))) float4 keep[];   // keep[(j - j_keep0) * TB + tid] = this thread's 4 values of U_j
@@ -612,21 +708,23 @@ __device__ __forceinline__ void sweep_u2d_body(int64_t M, int k, const Status* _
         if (e0 + i >= M) a1[i] = a2[i] = 0.f;
     }
   }
-  // a_j(next) = U_j . update_new for j <= k (U_k = a1, update_new = a2)
-  const int w = blockIdx.x * (TB / 64) + (tid >> 6);
+  // a_j(next) = U_j . update_new for j <= k (U_k = a1, update_new = a2): wave sums stashed, one row of per-block values stored
+  __shared__ float ua[TB / 64][PARTA_LD];
   const bool lead = (tid & 63) == 0;
   for (int jj = j_keep0; jj <= k; ++jj) {
     float4 u = jj < k ? keep[(jj - j_keep0) * TB + tid] : make_float4(a1[0], a1[1], a1[2], a1[3]);
     float sa = fmaf(u.x, a2[0], fmaf(u.y, a2[1], fmaf(u.z, a2[2], u.w * a2[3])));
     sa = wave_sum(sa);
-    if (lead) part[(int64_t)jj * npart4 + w] = sa;
+    if (lead && jj - j_keep0 < PARTA_LD) ua[tid >> 6][jj - j_keep0] = sa;
   }
+  __syncthreads();
+  if (tid <= k - j_keep0 && tid < PARTA_LD) part[(int64_t)blockIdx.x * PARTA_LD + tid] = (ua[0][tid] + ua[1][tid]) + (ua[2][tid] + ua[3][tid]);
 }
 __global__ __launch_bounds__(TB) void k_sweep_u2d(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
                                                   float* __restrict__ upd, const float* __restrict__ dgv,
                                                   const float* __restrict__ gv, const float* __restrict__ coef, int thr,
-                                                  float* __restrict__ part, int npart4, int64_t ld, int j_keep0) {
-  sweep_u2d_body(M, k, st, U, upd, dgv, gv, coef, thr, part, npart4, ld, j_keep0);
+                                                  float* __restrict__ part, int64_t ld, int j_keep0) {
+  sweep_u2d_body(M, k, st, U, upd, dgv, gv, coef, thr, part, ld, j_keep0);
 }
 
 // The same folded sweep with the kept values in REGISTERS (round 3; the default).  The LDS form above pins ONE 256-thread block per
@@ -661,8 +759,8 @@ __device__ __forceinline__ float rfl(float v) {   // wave-uniform value -> SGPR
 template <int NK, bool FIRST>
 __device__ __forceinline__ void u2r_kept(float (&a1)[4], float (&a2)[4], int k, const Status* __restrict__ st, float* __restrict__ U,
                                          float* __restrict__ upd, const float* __restrict__ dgv, const float* __restrict__ gv,
-                                         const float* __restrict__ coef, int thr, float* __restrict__ part,
-                                         int npart4, int64_t ld, int j_keep0, uint32_t off, int w, bool lead) {
+                                         const float* __restrict__ coef, int thr, float* __restrict__ ua /* this wave's stash row (LDS) */,
+                                         int64_t ld, int j_keep0, uint32_t off, bool lead) {
   // (instruction selection works per basic block: the 32-bit offset has to be (re)defined in the block of the accesses for
   // `sgpr base + zext(vgpr32)` to be matched as the saddr addressing mode)
   asm volatile("" : "+v"(off));
@@ -706,22 +804,23 @@ __device__ __forceinline__ void u2r_kept(float (&a1)[4], float (&a2)[4], int k, 
   for (int q = 0; q < NK; ++q) {
     float sa = fmaf(kp[q].x, a2[0], fmaf(kp[q].y, a2[1], fmaf(kp[q].z, a2[2], kp[q].w * a2[3])));
     sa = wave_sum(sa);
-    if (lead) part[(int64_t)(j_keep0 + q) * npart4 + w] = sa;
+    if (lead) ua[q] = sa;
   }
   float sa = fmaf(a1[0], a2[0], fmaf(a1[1], a2[1], fmaf(a1[2], a2[2], a1[3] * a2[3])));
   sa = wave_sum(sa);
-  if (lead) part[(int64_t)k * npart4 + w] = sa;
+  if (lead) ua[NK] = sa;
 }
 
 template <int KB>
 __device__ __forceinline__ void sweep_u2r_body(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
                                                float* __restrict__ upd, const float* __restrict__ dgv,
                                                const float* __restrict__ gv, const float* __restrict__ coef, int thr,
-                                               float* __restrict__ part, int npart4, int64_t ld, int j_keep0) {
+                                               float* __restrict__ part, int64_t ld, int j_keep0) {
+  __shared__ float ua[TB / 64][PARTA_LD];   // wave sums of a_j(next), j = j_keep0 + q: combined per block at the end
   if (__builtin_amdgcn_readfirstlane(st->done)) return;   // (a vector load in the batched kernel: keep the branch scalar)
   const int tid = threadIdx.x;
   const int64_t e0 = elem0<4>();
-  const int w = blockIdx.x * (TB / 64) + (tid >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool lead = (tid & 63) == 0;
   // wave-uniform: the whole span of this wave (256 floats) lies inside the vector -> no per-lane bounds anywhere on the hot path
   const int64_t wave_e0 = ((int64_t)blockIdx.x * TB + (int64_t)__builtin_amdgcn_readfirstlane(tid & ~63)) * 4;
@@ -730,98 +829,101 @@ __device__ __forceinline__ void sweep_u2r_body(int64_t M, int k, const Status* _
     uint32_t off = ((blockIdx.x * (uint32_t)TB + ((uint32_t)tid & ~63u)) * 4u + ((uint32_t)tid & 63u) * 4u) * 4u;
     asm volatile("" : "+v"(off));   // opaque 32-bit VGPR: the accesses below are `global_load/store v_off, s[base]` (saddr form)
     float a1[4], a2[4];
-#define U2R_CASE(n, first) case (n): u2r_kept<(n) < 0 ? 0 : (n), first>(a1, a2, k, st, U, upd, dgv, gv, coef, thr, part, npart4, ld, j_keep0, off, w, lead); break;
+#define U2R_CASE(n, first) case (n): u2r_kept<(n) < 0 ? 0 : (n), first>(a1, a2, k, st, U, upd, dgv, gv, coef, thr, ua[wv], ld, j_keep0, off, lead); break;
     if (j_keep0 == 0) {   // every stored pair is kept: one burst of k + 3 loads per thread, no wait in front of it
       switch (k) {
         U2R_CASE(KB - 8, true) U2R_CASE(KB - 7, true) U2R_CASE(KB - 6, true) U2R_CASE(KB - 5, true) U2R_CASE(KB - 4, true)
         U2R_CASE(KB - 3, true) U2R_CASE(KB - 2, true) U2R_CASE(KB - 1, true) U2R_CASE(KB, true)
         default: break;   // (the host only launches KB - 8 < count <= KB; KB = 8 also takes count = 0)
       }
-      return;
-    }
-    {
-      const float4 x = ld4_so(upd, off), dg = ld4_so(dgv, off), g = ld4_so(gv, off);
-      a1[0] = x.x + dg.x; a1[1] = x.y + dg.y; a1[2] = x.z + dg.z; a1[3] = x.w + dg.w;
-      a2[0] = g.x; a2[1] = g.y; a2[2] = g.z; a2[3] = g.w;
-    }
-    // pairs before the kept window: streamed, eight pairs' loads in flight
-    int j = 0;
-    for (; j + U2D_UNROLL <= j_keep0; j += U2D_UNROLL) {
-      float4 u[U2D_UNROLL];
-      const float* Uj = U + (int64_t)j * ld;
-      asm volatile("" : "+v"(off));
+    } else {
+      {
+        const float4 x = ld4_so(upd, off), dg = ld4_so(dgv, off), g = ld4_so(gv, off);
+        a1[0] = x.x + dg.x; a1[1] = x.y + dg.y; a1[2] = x.z + dg.z; a1[3] = x.w + dg.w;
+        a2[0] = g.x; a2[1] = g.y; a2[2] = g.z; a2[3] = g.w;
+      }
+      // pairs before the kept window: streamed, eight pairs' loads in flight
+      int j = 0;
+      for (; j + U2D_UNROLL <= j_keep0; j += U2D_UNROLL) {
+        float4 u[U2D_UNROLL];
+        const float* Uj = U + (int64_t)j * ld;
+        asm volatile("" : "+v"(off));
 #pragma unroll
-      for (int q = 0; q < U2D_UNROLL; ++q) u[q] = ld4_so(Uj + (int64_t)q * ld, off);
+        for (int q = 0; q < U2D_UNROLL; ++q) u[q] = ld4_so(Uj + (int64_t)q * ld, off);
 #pragma unroll
-      for (int q = 0; q < U2D_UNROLL; ++q) {
-        const float cc = rfl(coef[thr + j + q]), cb = rfl(coef[2 * thr + j + q]);
-        a1[0] = fmaf(-cc, u[q].x, a1[0]); a1[1] = fmaf(-cc, u[q].y, a1[1]); a1[2] = fmaf(-cc, u[q].z, a1[2]); a1[3] = fmaf(-cc, u[q].w, a1[3]);
-        a2[0] = fmaf(-cb, u[q].x, a2[0]); a2[1] = fmaf(-cb, u[q].y, a2[1]); a2[2] = fmaf(-cb, u[q].z, a2[2]); a2[3] = fmaf(-cb, u[q].w, a2[3]);
+        for (int q = 0; q < U2D_UNROLL; ++q) {
+          const float cc = rfl(coef[thr + j + q]), cb = rfl(coef[2 * thr + j + q]);
+          a1[0] = fmaf(-cc, u[q].x, a1[0]); a1[1] = fmaf(-cc, u[q].y, a1[1]); a1[2] = fmaf(-cc, u[q].z, a1[2]); a1[3] = fmaf(-cc, u[q].w, a1[3]);
+          a2[0] = fmaf(-cb, u[q].x, a2[0]); a2[1] = fmaf(-cb, u[q].y, a2[1]); a2[2] = fmaf(-cb, u[q].z, a2[2]); a2[3] = fmaf(-cb, u[q].w, a2[3]);
+        }
+      }
+      for (; j < j_keep0; ++j) {
+        const float cc = rfl(coef[thr + j]), cb = rfl(coef[2 * thr + j]);
+        asm volatile("" : "+v"(off));
+        const float4 u = ld4_so(U + (int64_t)j * ld, off);
+        a1[0] = fmaf(-cc, u.x, a1[0]); a1[1] = fmaf(-cc, u.y, a1[1]); a1[2] = fmaf(-cc, u.z, a1[2]); a1[3] = fmaf(-cc, u.w, a1[3]);
+        a2[0] = fmaf(-cb, u.x, a2[0]); a2[1] = fmaf(-cb, u.y, a2[1]); a2[2] = fmaf(-cb, u.z, a2[2]); a2[3] = fmaf(-cb, u.w, a2[3]);
+      }
+      // the kept pairs: one straight-line instance per count (the count is a kernel argument: scalar jump)
+      switch (k - j_keep0) {
+        U2R_CASE(KB - 8, false) U2R_CASE(KB - 7, false) U2R_CASE(KB - 6, false) U2R_CASE(KB - 5, false) U2R_CASE(KB - 4, false)
+        U2R_CASE(KB - 3, false) U2R_CASE(KB - 2, false) U2R_CASE(KB - 1, false) U2R_CASE(KB, false)
+        default: break;
       }
     }
-    for (; j < j_keep0; ++j) {
-      const float cc = rfl(coef[thr + j]), cb = rfl(coef[2 * thr + j]);
-      asm volatile("" : "+v"(off));
-      const float4 u = ld4_so(U + (int64_t)j * ld, off);
-      a1[0] = fmaf(-cc, u.x, a1[0]); a1[1] = fmaf(-cc, u.y, a1[1]); a1[2] = fmaf(-cc, u.z, a1[2]); a1[3] = fmaf(-cc, u.w, a1[3]);
-      a2[0] = fmaf(-cb, u.x, a2[0]); a2[1] = fmaf(-cb, u.y, a2[1]); a2[2] = fmaf(-cb, u.z, a2[2]); a2[3] = fmaf(-cb, u.w, a2[3]);
-    }
-    // the kept pairs: one straight-line instance per count (the count is a kernel argument: scalar jump)
-    switch (k - j_keep0) {
-      U2R_CASE(KB - 8, false) U2R_CASE(KB - 7, false) U2R_CASE(KB - 6, false) U2R_CASE(KB - 5, false) U2R_CASE(KB - 4, false)
-      U2R_CASE(KB - 3, false) U2R_CASE(KB - 2, false) U2R_CASE(KB - 1, false) U2R_CASE(KB, false)
-      default: break;
-    }
 #undef U2R_CASE
-    return;
-  }
-  // ---- the one ragged wave at the end of the vector (and lanes past it): per-lane bounds, kept pairs simply read twice --
-  // same operations in the same order on every element, so the same bits as the fast path would give
-  const bool in = e0 < M;
-  float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (in) {
-    float dg[4];
-    ldv<4>(upd, e0, M, a1);
-    ldv<4>(dgv, e0, M, dg);
-    ldv<4>(gv, e0, M, a2);
+  } else {
+    // ---- the one ragged wave at the end of the vector (and lanes past it): per-lane bounds, kept pairs simply read twice --
+    // same operations in the same order on every element, so the same bits as the fast path would give
+    const bool in = e0 < M;
+    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (in) {
+      float dg[4];
+      ldv<4>(upd, e0, M, a1);
+      ldv<4>(dgv, e0, M, dg);
+      ldv<4>(gv, e0, M, a2);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a1[i] = a1[i] + dg[i];
-  }
-  for (int j = 0; j < k; ++j) {
-    float u[4] = {0.f, 0.f, 0.f, 0.f};
-    const float cc = coef[thr + j], cb = coef[2 * thr + j];
-    if (in) ldv<4>(U + (int64_t)j * ld, e0, M, u);
+      for (int i = 0; i < 4; ++i) a1[i] = a1[i] + dg[i];
+    }
+    for (int j = 0; j < k; ++j) {
+      float u[4] = {0.f, 0.f, 0.f, 0.f};
+      const float cc = coef[thr + j], cb = coef[2 * thr + j];
+      if (in) ldv<4>(U + (int64_t)j * ld, e0, M, u);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      a1[i] = fmaf(-cc, u[i], a1[i]);
-      a2[i] = fmaf(-cb, u[i], a2[i]);
+      for (int i = 0; i < 4; ++i) {
+        a1[i] = fmaf(-cc, u[i], a1[i]);
+        a2[i] = fmaf(-cb, u[i], a2[i]);
+      }
+    }
+    if (in) {
+      const float sv = (float)st->s, beta = (float)st->beta;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float q = a1[i] / sv;
+        q = (q != q) ? 0.f : q;
+        a1[i] = q;
+        a2[i] = fmaf(-q, beta, a2[i]);
+      }
+      stv<4>(U + (int64_t)k * ld, e0, M, a1);
+      stv<4>(upd, e0, M, a2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (e0 + i >= M) a1[i] = a2[i] = 0.f;   // lanes past the end contribute nothing to the dot products
+    }
+    for (int jj = j_keep0; jj <= k; ++jj) {
+      float u[4] = {a1[0], a1[1], a1[2], a1[3]};
+      if (jj < k) {
+        u[0] = u[1] = u[2] = u[3] = 0.f;
+        if (in) ldv<4>(U + (int64_t)jj * ld, e0, M, u);
+      }
+      float sa = fmaf(u[0], a2[0], fmaf(u[1], a2[1], fmaf(u[2], a2[2], u[3] * a2[3])));
+      sa = wave_sum(sa);
+      if (lead) ua[wv][jj - j_keep0] = sa;
     }
   }
-  if (in) {
-    const float sv = (float)st->s, beta = (float)st->beta;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float q = a1[i] / sv;
-      q = (q != q) ? 0.f : q;
-      a1[i] = q;
-      a2[i] = fmaf(-q, beta, a2[i]);
-    }
-    stv<4>(U + (int64_t)k * ld, e0, M, a1);
-    stv<4>(upd, e0, M, a2);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (e0 + i >= M) a1[i] = a2[i] = 0.f;   // lanes past the end contribute nothing to the dot products
-  }
-  for (int jj = j_keep0; jj <= k; ++jj) {
-    float u[4] = {a1[0], a1[1], a1[2], a1[3]};
-    if (jj < k) {
-      u[0] = u[1] = u[2] = u[3] = 0.f;
-      if (in) ldv<4>(U + (int64_t)jj * ld, e0, M, u);
-    }
-    float sa = fmaf(u[0], a2[0], fmaf(u[1], a2[1], fmaf(u[2], a2[2], u[3] * a2[3])));
-    sa = wave_sum(sa);
-    if (lead) part[(int64_t)jj * npart4 + w] = sa;
-  }
+  // one row of per-block values: entry q = a_{j_keep0 + q}(next), the four waves added in a fixed order
+  __syncthreads();
+  if (tid <= k - j_keep0) part[(int64_t)blockIdx.x * PARTA_LD + tid] = (ua[0][tid] + ua[1][tid]) + (ua[2][tid] + ua[3][tid]);
 }
 // waves per SIMD the register budget of each instantiation allows (512 / (4 KB + working set), MI355X_MICROARCH register table)
 template <int KB> struct U2RWaves { static constexpr int value = KB <= 8 ? 8 : KB <= 16 ? 5 : 4; };
@@ -829,8 +931,8 @@ template <int KB>
 __global__ __launch_bounds__(TB, U2RWaves<KB>::value) void k_sweep_u2r(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
                                                                       float* __restrict__ upd, const float* __restrict__ dgv,
                                                                       const float* __restrict__ gv, const float* __restrict__ coef, int thr,
-                                                                      float* __restrict__ part, int npart4, int64_t ld, int j_keep0) {
-  sweep_u2r_body<KB>(M, k, st, U, upd, dgv, gv, coef, thr, part, npart4, ld, j_keep0);
+                                                                      float* __restrict__ part, int64_t ld, int j_keep0) {
+  sweep_u2r_body<KB>(M, k, st, U, upd, dgv, gv, coef, thr, part, ld, j_keep0);
 }
 
 // axpy pass.  Writes vT (NaN->0) to V[k], D1 to U[k] (unscaled), D2 to upd, partials of vT.dg, vT.g.
@@ -1022,8 +1124,11 @@ static bool u2d_lds_attr(int dev) {
   static int state[64] = {0};   // 0 unknown, 1 granted, -1 refused
   if (dev < 0 || dev >= 64) return false;
   if (state[dev] == 0) {
-    const bool ok = hipFuncSetAttribute((const void*)k_sweep_u2d, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-                    hipFuncSetAttribute((const void*)kb_sweep_u2d, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    // (38 pairs x 16 B x 256 threads = 152 KB of dynamic LDS at most, next to the kernel's 512 B of static LDS: asking for the whole
+    // 160 KB as dynamic is refused -- and the solver then silently ran with the 64 KB limits; tests/test_gpu_solver_forms.py caught it)
+    const int want = 38 * TB * 16;
+    const bool ok = hipFuncSetAttribute((const void*)k_sweep_u2d, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
+                    hipFuncSetAttribute((const void*)kb_sweep_u2d, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
     if (!ok) (void)hipGetLastError();
     state[dev] = ok ? 1 : -1;
   }
@@ -1096,20 +1201,22 @@ static int broyden_alloc(psignn_broyden* s) {
     // more than 64 KB of dynamic LDS has to be asked for, per device (the attribute belongs to the device's code object)
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!u2d_lds_attr(dev)) {   // not granted: stay within the default 64 KB (16 B x 256 threads x 16 pairs)
-      s->u2d_kmax = std::min(s->u2d_kmax, 16);
-      s->u2d_keep = std::min(s->u2d_keep, 16);
+    if (!u2d_lds_attr(dev)) {   // not granted: stay within the default 64 KB (16 B x 256 threads x 15 pairs + the kernel's static 512 B)
+      s->u2d_kmax = std::min(s->u2d_kmax, 15);
+      s->u2d_keep = std::min(s->u2d_keep, 15);
     }
   }
   s->nn_cap = std::max<int>(std::max(s->nblk, s->nblk_ax), s->plan ? (int)s->plan->n_tiles : 0);
+  s->ldp = (s->thr + 63) / 64 * 64;
+  s->pstride = (int64_t)std::max(std::max(s->nblk, s->nblk_u), std::max(s->nblk_ax, 1)) * s->ldp;
   size_t nx = s->keep_trace ? thr + 2 : 3;
   s->ld = (s->M + 63) / 64 * 64;  // row pitch of U and V: every stored vector starts on a 256-byte boundary
   size_t ld = (size_t)s->ld;
   struct { void** p; size_t n; } allocs[] = {
       {(void**)&s->U, thr * ld * 4},  {(void**)&s->V, thr * ld * 4},   {(void**)&s->xbuf, nx * M * 4},
       {(void**)&s->gx, M * 4},        {(void**)&s->dg, M * 4},        {(void**)&s->upd, M * 4},
-      {(void**)&s->fx, M * 4},        {(void**)&s->part, 4 * thr * (size_t)std::max(s->npart, s->npart_u) * 4 + 16}, {(void**)&s->parta, (size_t)(s->u2d_kmax > 0 ? thr + 2 : 2) * s->nblk4 * (TB / 64) * 4 + 16},
-      {(void**)&s->coef, 3 * thr * 4 + 16}, {(void**)&s->st, sizeof(Status)},
+      {(void**)&s->fx, M * 4},        {(void**)&s->part, 3 * (size_t)s->pstride * 4 + 16}, {(void**)&s->parta, (size_t)s->nblk4 * PARTA_LD * 4 + 16},
+      {(void**)&s->coef, (3 + RA) * thr * 4 + 16}, {(void**)&s->st, sizeof(Status)},
       {(void**)&s->nrm_part, 2 * (size_t)s->nn_cap * 4 + 16}, {(void**)&s->part2, 2 * (size_t)std::max(s->nblk, s->nblk_u) * 4 + 16},
       {(void**)&s->rel_trace, thr * 8 + 8}, {(void**)&s->abs_trace, thr * 8 + 8}};
   for (auto& a : allocs) {
@@ -1232,21 +1339,20 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
     if (k == 0) s->a_ready = 0;
     // a_j of this iteration: pairs j >= a_from were delivered by the folded sweep 3 of the last iteration, the others need sweep 1
     const int a_from = s->a_ready ? s->a_from : kd;
-    const int np4 = s->nblk4 * (TB / 64);
     if (std::min(a_from, kd) > 0)
-      VLAUNCH("k_sweep_u1", st, s->vec_u, k_sweep_u1, (gu, TB, 0, st), s->M, std::min(a_from, kd), s->st, s->U, s->upd, s->part, s->npart_u, s->ld);
-    LAUNCH("k_reduce_check", st, (k_reduce_a_check<<<dim3(std::max(kd, 1), 2), TB, 0, st>>>(
-        s->st, s->part, s->npart_u, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace,
-        s->parta, np4, a_from)));
+      VLAUNCH("k_sweep_u1", st, s->vec_u, k_sweep_u1, (gu, TB, 0, st), s->M, std::min(a_from, kd), s->st, s->U, s->upd, s->part, s->ldp, s->ld);
+    LAUNCH("k_reduce_check", st, (k_reduce_a_check<<<dim3(std::max(kd, 1), RA + 1), RB, 0, st>>>(
+        s->st, s->part, s->nblk_u, s->ldp, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace,
+        s->parta, s->nblk4, a_from)));
     s->a_ready = 0;
     if (k >= s->thr) return;
-    VLAUNCH("k_sweep_v", st, s->vec_u, k_sweep_v, (gu, TB, 0, st), s->M, k, s->st, s->V, s->upd, s->dg, s->gx, s->coef, s->part, s->npart_u, s->part2, s->nblk_u, s->ld);
-    LAUNCH("k_reduce_cb", st, (k_reduce_cb<<<dim3(std::max(k, 1), 3), TB, 0, st>>>(s->st, s->part, s->npart_u, s->thr, k, s->coef, s->part2, s->nblk_u)));
+    VLAUNCH("k_sweep_v", st, s->vec_u, k_sweep_v, (gu, TB, 0, st), s->M, k, s->st, s->V, s->upd, s->dg, s->gx, s->coef, s->part, s->pstride, s->ldp, s->part2, s->nblk_u, s->ld, s->thr);
+    LAUNCH("k_reduce_cb", st, (k_reduce_cb<<<dim3(std::max(k, 1), 3), RB, 0, st>>>(s->st, s->part, s->nblk_u, s->pstride, s->ldp, s->thr, k, s->coef, s->part2, s->nblk_u)));
     const int keep0 = k <= s->u2d_kmax ? 0 : k - s->u2d_keep;      // few stored pairs: all kept; later the most recent ones
     if (s->u2d_kmax > 0 && (k <= s->u2d_kmax || s->u2d_keep > 0) && k + 1 < s->thr) {
       const int nk = k - keep0;
       if (s->u2d_reg) {
-#define U2R_ARGS s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->parta, np4, s->ld, keep0
+#define U2R_ARGS s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->parta, s->ld, keep0
         if (nk <= 8) LAUNCH("k_sweep_u2d", st, (k_sweep_u2r<8><<<(unsigned)s->nblk4, TB, 0, st>>>(U2R_ARGS)));
         else if (nk <= 16) LAUNCH("k_sweep_u2d", st, (k_sweep_u2r<16><<<(unsigned)s->nblk4, TB, 0, st>>>(U2R_ARGS)));
         else LAUNCH("k_sweep_u2d", st, (k_sweep_u2r<24><<<(unsigned)s->nblk4, TB, 0, st>>>(U2R_ARGS)));
@@ -1254,7 +1360,7 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
       } else {
         const size_t lds = (size_t)std::max(nk, 1) * TB * 16;
         LAUNCH("k_sweep_u2d", st, (k_sweep_u2d<<<(unsigned)s->nblk4, TB, lds, st>>>(s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->parta,
-                                                                                    np4, s->ld, keep0)));
+                                                                                    s->ld, keep0)));
       }
       s->a_ready = 1;
       s->a_from = keep0;
@@ -1268,9 +1374,9 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
   const int js = (int)cdiv(std::max(k, 1), G);
   const int kd = k >= s->thr ? 0 : k;  // the threshold stop is about to fire: no slot left for another pair
   if (kd > 0)
-    VLAUNCH("k_dots", st, s->vec, k_dots, (dim3(g, G), TB, 0, st), s->M, kd, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->npart, s->thr, js, s->ld);
-  LAUNCH("k_reduce_check", st, (k_reduce_check<<<dim3(std::max(kd, 1), 4), TB, 0, st>>>(
-      s->st, s->part, s->npart, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace)));
+    VLAUNCH("k_dots", st, s->vec, k_dots, (dim3(g, G), TB, 0, st), s->M, kd, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->pstride, s->ldp, js, s->ld);
+  LAUNCH("k_reduce_check", st, (k_reduce_check<<<dim3(std::max(kd, 1), 4), RB, 0, st>>>(
+      s->st, s->part, s->nblk, s->pstride, s->ldp, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace)));
   if (k >= s->thr) return;
   if (s->vec_ax != s->vec) {  // unsplit, own width
     const unsigned ga = (unsigned)s->nblk_ax;
@@ -1425,13 +1531,13 @@ __global__ __launch_bounds__(TB) void kb_dots(const BatchDesc* __restrict__ desc
   const BatchDesc& d = descs[blockIdx.z];
   const int G = batch_groups(d, k);
   if ((int)blockIdx.x >= d.nblk || (int)blockIdx.y >= G) return;
-  dots_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.V, d.upd, d.dg, d.gx, d.part, d.npart, d.thr,
+  dots_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.V, d.upd, d.dg, d.gx, d.part, d.pstride, (d.thr + 63) / 64 * 64,
                  idiv_up(k > 1 ? k : 1, G), d.ld);
 }
-__global__ __launch_bounds__(TB) void kb_reduce_check(const BatchDesc* __restrict__ descs, int k, double eps) {
-  __shared__ double sh[TB];
+__global__ __launch_bounds__(RB) void kb_reduce_check(const BatchDesc* __restrict__ descs, int k, double eps) {
+  __shared__ double sh[RB];
   const BatchDesc& d = descs[blockIdx.z];
-  reduce_check_body(reinterpret_cast<Status*>(d.st), d.part, d.npart, d.thr, k, d.coef, d.nrm_part, d.n_tiles, d.rel_trace,
+  reduce_check_body(reinterpret_cast<Status*>(d.st), d.part, d.nblk, d.pstride, (d.thr + 63) / 64 * 64, d.thr, k, d.coef, d.nrm_part, d.n_tiles, d.rel_trace,
                     d.abs_trace, eps, d.seq_len, d.keep_trace, sh);
 }
 template <int VEC>
@@ -1464,38 +1570,36 @@ template <int VEC>
 __global__ __launch_bounds__(TB) void kb_sweep_u1(const BatchDesc* __restrict__ descs, int k) {
   const BatchDesc& d = descs[blockIdx.z];
   if ((int)blockIdx.x >= d.nblk_u) return;
-  sweep_u1_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, d.part, d.npart_u, d.ld);
+  sweep_u1_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, d.part, (d.thr + 63) / 64 * 64, d.ld);
 }
-__global__ __launch_bounds__(TB) void kb_reduce_a_check(const BatchDesc* __restrict__ descs, int k, double eps, int a_from) {
-  __shared__ double sh[TB];
+__global__ __launch_bounds__(RB) void kb_reduce_a_check(const BatchDesc* __restrict__ descs, int k, double eps, int a_from) {
+  __shared__ double sh[RB];
   const BatchDesc& d = descs[blockIdx.z];
-  reduce_a_check_body(reinterpret_cast<Status*>(d.st), d.part, d.npart_u, d.thr, k, d.coef, d.nrm_part, d.n_tiles, d.rel_trace,
-                      d.abs_trace, eps, d.seq_len, d.keep_trace, sh, d.parta, d.nblk4 * (TB / 64), a_from);
+  reduce_a_check_body(reinterpret_cast<Status*>(d.st), d.part, d.nblk_u, (d.thr + 63) / 64 * 64, d.thr, k, d.coef, d.nrm_part, d.n_tiles, d.rel_trace,
+                      d.abs_trace, eps, d.seq_len, d.keep_trace, sh, d.parta, d.nblk4, a_from);
 }
 __global__ __launch_bounds__(TB) void kb_sweep_u2d(const BatchDesc* __restrict__ descs, int k, int j_keep0) {
   const BatchDesc& d = descs[blockIdx.z];
   if ((int)blockIdx.x >= d.nblk4) return;
-  sweep_u2d_body(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, d.dg, d.gx, d.coef, d.thr, d.parta, d.nblk4 * (TB / 64), d.ld,
-                 j_keep0);
+  sweep_u2d_body(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, d.dg, d.gx, d.coef, d.thr, d.parta, d.ld, j_keep0);
 }
 template <int KB>
 __global__ __launch_bounds__(TB, U2RWaves<KB>::value) void kb_sweep_u2r(const BatchDesc* __restrict__ descs, int k, int j_keep0) {
   const BatchDesc& d = descs[blockIdx.z];
   if ((int)blockIdx.x >= d.nblk4) return;
-  sweep_u2r_body<KB>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, d.dg, d.gx, d.coef, d.thr, d.parta, d.nblk4 * (TB / 64), d.ld,
-                     j_keep0);
+  sweep_u2r_body<KB>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, d.dg, d.gx, d.coef, d.thr, d.parta, d.ld, j_keep0);
 }
 template <int VEC>
 __global__ __launch_bounds__(TB) void kb_sweep_v(const BatchDesc* __restrict__ descs, int k) {
   const BatchDesc& d = descs[blockIdx.z];
   if ((int)blockIdx.x >= d.nblk_u) return;
-  sweep_v_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.V, d.upd, d.dg, d.gx, d.coef, d.part, d.npart_u, d.part2,
-                    d.nblk_u, d.ld);
+  sweep_v_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.V, d.upd, d.dg, d.gx, d.coef, d.part, d.pstride, (d.thr + 63) / 64 * 64, d.part2,
+                    d.nblk_u, d.ld, d.thr);
 }
-__global__ __launch_bounds__(TB) void kb_reduce_cb(const BatchDesc* __restrict__ descs, int k) {
-  __shared__ double sh[TB];
+__global__ __launch_bounds__(RB) void kb_reduce_cb(const BatchDesc* __restrict__ descs, int k) {
+  __shared__ double sh[RB];
   const BatchDesc& d = descs[blockIdx.z];
-  reduce_cb_body(reinterpret_cast<Status*>(d.st), d.part, d.npart_u, d.thr, k, d.coef, d.part2, d.nblk_u, sh);
+  reduce_cb_body(reinterpret_cast<Status*>(d.st), d.part, d.nblk_u, d.pstride, (d.thr + 63) / 64 * 64, d.thr, k, d.coef, d.part2, d.nblk_u, sh);
 }
 template <int VEC>
 __global__ __launch_bounds__(TB) void kb_sweep_u2(const BatchDesc* __restrict__ descs, int k) {
@@ -1581,7 +1685,7 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
     d.nrm_part = s->nrm_part; d.jpart = s->jpart; d.rel_trace = s->rel_trace; d.abs_trace = s->abs_trace;
     d.ctx = p->d_ctx; d.h0p = s->h0p; d.prbp = s->prbp;
     d.part2 = s->part2; d.nblk_u = s->nblk_u; d.npart_u = s->npart_u;
-    d.parta = s->parta; d.nblk4 = s->nblk4; d.pad_ = 0; d.nrmp = nrmp;
+    d.parta = s->parta; d.nblk4 = s->nblk4; d.pad_ = 0; d.nrmp = nrmp; d.pstride = s->pstride;
     max_g4 = std::max(max_g4, s->nblk4);
     base += (int)p->n_tiles;
   }
@@ -1619,10 +1723,10 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
       // (all meshes of the shard carry the same number of stored pairs: one a_from / keep window for the launch)
       const int a_from = a_ready ? a_from_next : kd;
       if (std::min(a_from, kd) > 0) VLAUNCH("k_sweep_u1", st, s0->vec_u, kb_sweep_u1, (gu, TB, 0, st), d_descs, std::min(a_from, kd));
-      LAUNCH("k_reduce_check", st, (kb_reduce_a_check<<<dim3((unsigned)std::max(kd, 1), 2, (unsigned)n), TB, 0, st>>>(d_descs, kd, eps, a_from)));
+      LAUNCH("k_reduce_check", st, (kb_reduce_a_check<<<dim3((unsigned)std::max(kd, 1), RA + 1, (unsigned)n), RB, 0, st>>>(d_descs, kd, eps, a_from)));
       a_ready = false;
       VLAUNCH("k_sweep_v", st, s0->vec_u, kb_sweep_v, (gu, TB, 0, st), d_descs, k);
-      LAUNCH("k_reduce_cb", st, (kb_reduce_cb<<<dim3((unsigned)std::max(k, 1), 3, (unsigned)n), TB, 0, st>>>(d_descs, k)));
+      LAUNCH("k_reduce_cb", st, (kb_reduce_cb<<<dim3((unsigned)std::max(k, 1), 3, (unsigned)n), RB, 0, st>>>(d_descs, k)));
       const int keep0 = k <= s0->u2d_kmax ? 0 : k - s0->u2d_keep;
       if (s0->u2d_kmax > 0 && (k <= s0->u2d_kmax || s0->u2d_keep > 0) && k + 1 < thr) {
         const int nk = k - keep0;
@@ -1643,7 +1747,7 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
     } else {
     if (kd > 0)
       VLAUNCH("k_dots", st, s0->vec, kb_dots, (dim3((unsigned)max_g, (unsigned)max_G, (unsigned)n), TB, 0, st), d_descs, kd);
-    LAUNCH("k_reduce_check", st, (kb_reduce_check<<<dim3((unsigned)std::max(kd, 1), 4, (unsigned)n), TB, 0, st>>>(d_descs, kd, eps)));
+    LAUNCH("k_reduce_check", st, (kb_reduce_check<<<dim3((unsigned)std::max(kd, 1), 4, (unsigned)n), RB, 0, st>>>(d_descs, kd, eps)));
     if (own_width) {
       VLAUNCH("k_axpy", st, s0->vec_ax, kb_axpy, (dim3((unsigned)max_ga, 1, (unsigned)n), TB, 0, st), d_descs, k, 1);
       VLAUNCH("k_final", st, s0->vec_ax, kb_final, (dim3((unsigned)max_ga, 1, (unsigned)n), TB, 0, st), d_descs, k, 1);
@@ -1759,7 +1863,11 @@ extern "C" int psignn_broyden_get_iterate(const psignn_broyden_t* s, int i, floa
 // update form on the device's own state (tests/test_gpu_solver_forms.py).
 extern "C" int psignn_broyden_get_pair(const psignn_broyden_t* s, int j, int which, float* d_dst, void* stream) {
   ARG_CHECK(s && d_dst, "NULL argument");
-  ARG_CHECK(which >= 0 && which <= 2, "which: 0 = U_j, 1 = V_j, 2 = the current update vector");
+  ARG_CHECK(which >= 0 && which <= 3, "which: 0 = U_j, 1 = V_j, 2 = the current update vector, 3 = partials of the folded sweep");
+  if (which == 3) {   // diagnostics: the (nblk4, PARTA_LD) per-block partials of a, as they are (d_dst: at least that many floats)
+    HIP_TRY(hipMemcpyAsync(d_dst, s->parta, (size_t)std::min<int64_t>(s->M, (int64_t)s->nblk4 * PARTA_LD) * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PSIGNN_OK;
+  }
   ARG_CHECK(which == 2 || (j >= 0 && j < s->thr), "pair index out of range");
   const float* row = which == 2 ? s->upd : (which ? s->V : s->U) + (int64_t)j * s->ld;
   if (s->plan && s->plan_order) {

@@ -890,7 +890,7 @@ class DeviceBroyden:
         utilities/solver.py:190-191) or, ``which="update"``, the current update vector (``j`` ignored); caller's numbering."""
         dst = torch.empty_like(like)
         with torch.cuda.device(self.device):
-            nat.check(nat.lib().psignn_broyden_get_pair(self.handle, int(j), {"U": 0, "V": 1, "update": 2}[which], nat.ptr(dst),
+            nat.check(nat.lib().psignn_broyden_get_pair(self.handle, int(j), {"U": 0, "V": 1, "update": 2, "parta": 3}[which], nat.ptr(dst),
                                                         nat.stream_ptr(self.device)), "psignn_broyden_get_pair")
         return dst
 

@@ -111,7 +111,7 @@ class _LazyIterates:
             return self._first
         if not self._it.keep_trace:
             raise RuntimeError("iterates were not kept (trace would exceed the memory budget); pass keep_trace=True")
-        return self._back(self._it.iterate(self._index[i - 1], self._first.reshape(-1))).reshape(self._shape)
+        return self._back(self._it.iterate(self._index[i - 1], self._first.reshape(-1)).reshape(self._shape))
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))

@@ -33,6 +33,7 @@ __global__ __launch_bounds__(TB) void k_sweep(const float* __restrict__ U, long 
   for (int i = 0; i < VEC; ++i) { a1[i] = 1.f + i; a2[i] = 0.f; }
   const int w = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
   const bool lead = (threadIdx.x & 63) == 0;
+  __shared__ float stash[TB / 64][64];
   for (int j0 = 0; j0 < k; j0 += UNR) {
     float u[UNR][VEC];
 #pragma unroll
@@ -47,7 +48,22 @@ __global__ __launch_bounds__(TB) void k_sweep(const float* __restrict__ U, long 
 #pragma unroll
     for (int q = 0; q < UNR; ++q)
       if (j0 + q < k) {
-        if (MODE == 1 || MODE == 3 || MODE == 4 || MODE == 5) {
+        if (MODE == 6) {   // wave sums stashed in LDS, combined per block and stored as one coalesced row per 64 vectors
+          float sa = 0.f;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) sa = fmaf(a1[i], u[q][i], sa);
+          sa = wave_sum(sa);
+          const int j = j0 + q;
+          if (lead) stash[threadIdx.x >> 6][j & 63] = sa;
+          if ((j & 63) == 63 || j == k - 1) {
+            __syncthreads();
+            const int cnt = (j & 63) + 1;
+            if (threadIdx.x < cnt)
+              part[(long long)blockIdx.x * 64 * ((k + 63) / 64) + (j & ~63) + threadIdx.x] =
+                  (stash[0][threadIdx.x] + stash[1][threadIdx.x]) + (stash[2][threadIdx.x] + stash[3][threadIdx.x]);
+            __syncthreads();
+          }
+        } else if (MODE == 1 || MODE == 3 || MODE == 4 || MODE == 5) {
           float sa = 0.f;
 #pragma unroll
           for (int i = 0; i < VEC; ++i) sa = fmaf(a1[i], u[q][i], sa);
@@ -111,6 +127,10 @@ int main(int argc, char** argv) {
     run<16, 4, 1>(U, M, k, coef, part, out, "dot16 store, no wave_sum");
     run<4, 4, 8>(U, M, k, coef, part, out, "dot4 store, no wave_sum");
     run<16, 5, 1>(U, M, k, coef, part, out, "dot16 full-wave store");
+    run<16, 6, 1>(U, M, k, coef, part, out, "dot16 block rows");
+    run<16, 6, 2>(U, M, k, coef, part, out, "dot16 block rows unroll 2");
+    run<4, 6, 8>(U, M, k, coef, part, out, "dot4 block rows unroll 8");
+    run<4, 6, 1>(U, M, k, coef, part, out, "dot4 block rows unroll 1");
     run<16, 2, 1>(U, M, k, coef, part, out, "coef16 unroll 1");
     run<16, 2, 2>(U, M, k, coef, part, out, "coef16 unroll 2");
     run<4, 2, 8>(U, M, k, coef, part, out, "coef4 unroll 8");
