@@ -415,6 +415,12 @@ int psignn_gmres_reorth_count(psignn_gmres_t* s, int* h_count, void* stream);
 void psignn_prof_enable(int on);
 int psignn_prof_collect(void);   /* sync + aggregate per kernel name; returns the number of names */
 int psignn_prof_get(int i, char* name, int cap, int64_t* calls, double* total_ms);
+/* The same plus the sum of the ALGORITHMIC bytes of those launches as the launch sites state them (stored pairs swept, kept
+ * window, meshes of the shard: what actually ran) -- 0 for kernels that state none.  bench.py's roofline figures come from here. */
+int psignn_prof_get2(int i, char* name, int cap, int64_t* calls, double* total_ms, int64_t* alg_bytes);
+/* Launch i of the last collect, in launch order: kernel name, duration, stated algorithmic bytes.  name == NULL: returns the
+ * number of launches.  (scripts/summarise_pmc.py lines rocprofv3's per-dispatch counters up with this log.) */
+int psignn_prof_launch(int i, char* name, int cap, double* ms, int64_t* alg_bytes);
 /* Diagnostics: d_buf = device array of n_tiles * 4 * 8 int64 (or NULL to switch off).  While set, every wave of the f tile
  * kernel stores shader-clock stamps at its phase boundaries (0 start, 1 stage 1 done, 2 past the barrier, 3 neighbour sums
  * done, 4 node update done, 5 stored) -- scripts/tile_phases.py turns them into a per-phase time budget. */

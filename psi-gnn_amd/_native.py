@@ -127,6 +127,8 @@ SIGNATURES = {
     "psignn_prof_tile_stamps": (None, [_P]),
     "psignn_prof_collect": (_INT, []),
     "psignn_prof_get": (_INT, [_INT, C.c_char_p, _INT, C.POINTER(_I64), C.POINTER(C.c_double)]),
+    "psignn_prof_get2": (_INT, [_INT, C.c_char_p, _INT, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(_I64)]),
+    "psignn_prof_launch": (_INT, [_INT, C.c_char_p, _INT, C.POINTER(C.c_double), C.POINTER(_I64)]),
 }
 
 
@@ -134,16 +136,29 @@ def prof_enable(on: bool):
     lib().psignn_prof_enable(int(on))
 
 
-def prof_collect():
-    """{kernel name: (calls, total_ms)} of everything launched since the last collect (HIP events)."""
+def prof_collect(with_bytes=False):
+    """{kernel name: (calls, total_ms)} of everything launched since the last collect (HIP events); ``with_bytes``:
+    (calls, total_ms, algorithmic bytes as stated at the launch sites)."""
     l = lib()
     out = {}
     for i in range(l.psignn_prof_collect()):
         name = C.create_string_buffer(64)
-        calls, ms = _I64(0), C.c_double(0.0)
-        check(l.psignn_prof_get(i, name, 64, C.byref(calls), C.byref(ms)), "psignn_prof_get")
-        out[name.value.decode()] = (int(calls.value), float(ms.value))
+        calls, ms, byts = _I64(0), C.c_double(0.0), _I64(0)
+        check(l.psignn_prof_get2(i, name, 64, C.byref(calls), C.byref(ms), C.byref(byts)), "psignn_prof_get2")
+        out[name.value.decode()] = (int(calls.value), float(ms.value), int(byts.value)) if with_bytes else (int(calls.value), float(ms.value))
     return out
+
+def prof_launch_log():
+    """[(kernel name, ms, algorithmic bytes)] of the launches of the last ``prof_collect``, in launch order."""
+    l = lib()
+    out = []
+    for i in range(l.psignn_prof_launch(0, None, 0, None, None)):
+        name = C.create_string_buffer(64)
+        ms, byts = C.c_double(0.0), _I64(0)
+        check(l.psignn_prof_launch(i, name, 64, C.byref(ms), C.byref(byts)), "psignn_prof_launch")
+        out.append((name.value.decode(), float(ms.value), int(byts.value)))
+    return out
+
 
 _lib = None
 

@@ -157,6 +157,14 @@ void psignn_tiles_free(psignn_plan* p);
 // Off by default: LAUNCH() is then a plain launch.
 // ---------------------------------------------------------------------------------------------
 extern int g_prof_on;
+// the NEXT profiled launch's ALGORITHMIC bytes (every operand read once, every result written once: DESIGN section 4), stated at the
+// launch site from what is actually launched (stored pairs swept, kept window, meshes of the shard) -- bench.py builds its roofline
+// numbers from these records, not from a re-derivation of the solver's schedule.  Consumed (and reset to 0) by prof_begin.
+extern int64_t g_prof_next_bytes;
+#define PROF_BYTES(b)                           \
+  do {                                          \
+    if (g_prof_on) g_prof_next_bytes = (int64_t)(b); \
+  } while (0)
 void prof_begin(const char* name, hipStream_t st);
 void prof_end(hipStream_t st);
 #define LAUNCH(name, st, ...)            \

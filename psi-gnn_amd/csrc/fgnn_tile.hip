@@ -795,6 +795,8 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
   ARG_CHECK(!p->mixed || nrm, "mixed plan needs unit normals");
   const int chunk = (int)cdiv(p->n_tiles, 8);
   const unsigned grid = tile_grid(chunk);
+  // B_f: h, h' (40 N each), prb (8 / 12 N), flags and, mixed, normals; 20 bytes per directed non-self edge
+  PROF_BYTES(((p->mixed ? 102 : 89) * p->N + 20 * p->Ep) * (p->mixed ? 1 : nl));
   if (p->mixed) {
     using L = WLayout<3>;
     if (stage1_mfma(false, true)) {  // single launch, MFMA stage 1 (PSIGNN_STAGE1=mfma)
@@ -839,6 +841,7 @@ int psignn_f_tile_fused(const psignn_plan* p, const float* W, int nl, float* xbu
   const unsigned grid = tile_grid(chunk);
   const int npart = (int)p->n_tiles;
   FuseArgs fa{upd, gx, dg, xbuf, st_words, off_done, off_cur, off_nxt, M, part, npart, g_tile_stamps};
+  PROF_BYTES((p->mixed ? 102 : 89) * p->N + 20 * p->Ep + 16 * M);   // B_f + update, g_old read; g, dg written (x_next replaces f(x))
   if (p->mixed) {
     using L = WLayout<3>;
     if (stage1_mfma(true, true)) {

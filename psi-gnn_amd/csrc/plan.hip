@@ -29,12 +29,14 @@ extern "C" void psignn_reload_knobs(void) { ++g_knob_epoch; }
 #include <map>
 int g_prof_on = 0;
 namespace {
-struct ProfRec { int name; hipEvent_t a, b; };
+struct ProfRec { int name; hipEvent_t a, b; int64_t bytes; };
 std::vector<ProfRec> g_recs;
 std::vector<std::string> g_names;
 std::vector<hipEvent_t> g_pool;
-struct ProfAgg { std::string name; int64_t calls; double ms; };
+struct ProfAgg { std::string name; int64_t calls; double ms; int64_t bytes; };
 std::vector<ProfAgg> g_agg;
+struct ProfLaunch { int name; float ms; int64_t bytes; };
+std::vector<ProfLaunch> g_log;   // the launches of the last collect, in launch order
 hipEvent_t get_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e; (void)hipEventCreate(&e); return e;
@@ -44,8 +46,10 @@ int name_id(const char* n) {
   g_names.push_back(n); return (int)g_names.size() - 1;
 }
 }  // namespace
+int64_t g_prof_next_bytes = 0;
 void prof_begin(const char* name, hipStream_t st) {
-  ProfRec r{name_id(name), get_event(), get_event()};
+  ProfRec r{name_id(name), get_event(), get_event(), g_prof_next_bytes};
+  g_prof_next_bytes = 0;
   (void)hipEventRecord(r.a, st);
   g_recs.push_back(r);
 }
@@ -55,12 +59,14 @@ extern "C" void psignn_prof_enable(int on) { g_prof_on = on; }
 // Waits for the recorded work, aggregates per kernel name, clears the records.  Returns #names.
 extern "C" int psignn_prof_collect(void) {
   std::map<int, ProfAgg> m;
+  g_log.clear();
   for (auto& r : g_recs) {
     (void)hipEventSynchronize(r.b);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, r.a, r.b);
+    g_log.push_back({r.name, ms, r.bytes});
     auto& a = m[r.name];
-    a.name = g_names[r.name]; a.calls += 1; a.ms += ms;
+    a.name = g_names[r.name]; a.calls += 1; a.ms += ms; a.bytes += r.bytes;
     g_pool.push_back(r.a); g_pool.push_back(r.b);
   }
   g_recs.clear();
@@ -73,6 +79,23 @@ extern "C" int psignn_prof_get(int i, char* name, int cap, int64_t* calls, doubl
   snprintf(name, cap, "%s", g_agg[i].name.c_str());
   if (calls) *calls = g_agg[i].calls;
   if (total_ms) *total_ms = g_agg[i].ms;
+  return PSIGNN_OK;
+}
+
+// the same plus the sum of the launches' algorithmic bytes (0 for kernels that state none)
+extern "C" int psignn_prof_get2(int i, char* name, int cap, int64_t* calls, double* total_ms, int64_t* alg_bytes) {
+  int rc = psignn_prof_get(i, name, cap, calls, total_ms);
+  if (rc == PSIGNN_OK && alg_bytes) *alg_bytes = g_agg[i].bytes;
+  return rc;
+}
+
+// launch i of the last collect, in launch order (returns the number of launches when name == NULL)
+extern "C" int psignn_prof_launch(int i, char* name, int cap, double* ms, int64_t* alg_bytes) {
+  if (!name) return (int)g_log.size();
+  if (i < 0 || i >= (int)g_log.size() || cap < 2) return PSIGNN_EINVAL;
+  snprintf(name, cap, "%s", g_names[g_log[i].name].c_str());
+  if (ms) *ms = g_log[i].ms;
+  if (alg_bytes) *alg_bytes = g_log[i].bytes;
   return PSIGNN_OK;
 }
 

@@ -1331,6 +1331,7 @@ static inline int sel_off_nxt() { return offsetof(Status, nxt) / 4; }
 static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, int fused_npart = 0) {
   unsigned g = (unsigned)s->nblk;
   if (!fused_npart)
+    PROF_BYTES(5 * (int64_t)s->M * 4);
     VLAUNCH("k_resid", st, s->vec, k_resid, (g, TB, 0, st), s->M, s->st, s->xbuf, s->fx, s->gx, s->dg, s->nrm_part, s->nblk);
   const int np = fused_npart ? fused_npart : s->nblk;  // one partial pair per block / per tile
   if (s->uvu) {
@@ -1340,16 +1341,19 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
     // a_j of this iteration: pairs j >= a_from were delivered by the folded sweep 3 of the last iteration, the others need sweep 1
     const int a_from = s->a_ready ? s->a_from : kd;
     if (std::min(a_from, kd) > 0)
+      PROF_BYTES((std::min(a_from, kd) + 1) * (int64_t)s->M * 4);   // its columns of U + dx
       VLAUNCH("k_sweep_u1", st, s->vec_u, k_sweep_u1, (gu, TB, 0, st), s->M, std::min(a_from, kd), s->st, s->U, s->upd, s->part, s->ldp, s->ld);
     LAUNCH("k_reduce_check", st, (k_reduce_a_check<<<dim3(std::max(kd, 1), RA + 1), RB, 0, st>>>(
         s->st, s->part, s->nblk_u, s->ldp, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace,
         s->parta, s->nblk4, a_from)));
     s->a_ready = 0;
     if (k >= s->thr) return;
+    PROF_BYTES((k + 4) * (int64_t)s->M * 4);   // k columns of V + dx, dg, g; writes V[k]
     VLAUNCH("k_sweep_v", st, s->vec_u, k_sweep_v, (gu, TB, 0, st), s->M, k, s->st, s->V, s->upd, s->dg, s->gx, s->coef, s->part, s->pstride, s->ldp, s->part2, s->nblk_u, s->ld, s->thr);
     LAUNCH("k_reduce_cb", st, (k_reduce_cb<<<dim3(std::max(k, 1), 3), RB, 0, st>>>(s->st, s->part, s->nblk_u, s->pstride, s->ldp, s->thr, k, s->coef, s->part2, s->nblk_u)));
     const int keep0 = k <= s->u2d_kmax ? 0 : k - s->u2d_keep;      // few stored pairs: all kept; later the most recent ones
     if (s->u2d_kmax > 0 && (k <= s->u2d_kmax || s->u2d_keep > 0) && k + 1 < s->thr) {
+      PROF_BYTES((k + 5) * (int64_t)s->M * 4);   // k columns of U + update, dg, g; writes U[k], update (whichever form runs)
       const int nk = k - keep0;
       if (s->u2d_reg) {
 #define U2R_ARGS s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->parta, s->ld, keep0
@@ -1365,6 +1369,7 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
       s->a_ready = 1;
       s->a_from = keep0;
     } else {
+      PROF_BYTES((k + 5) * (int64_t)s->M * 4);
       VLAUNCH("k_sweep_u2", st, s->vec_u, k_sweep_u2, (gu, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->ld);
     }
     return;
@@ -1374,19 +1379,25 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
   const int js = (int)cdiv(std::max(k, 1), G);
   const int kd = k >= s->thr ? 0 : k;  // the threshold stop is about to fire: no slot left for another pair
   if (kd > 0)
+    PROF_BYTES((2 * kd + 3) * (int64_t)s->M * 4);
     VLAUNCH("k_dots", st, s->vec, k_dots, (dim3(g, G), TB, 0, st), s->M, kd, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->pstride, s->ldp, js, s->ld);
   LAUNCH("k_reduce_check", st, (k_reduce_check<<<dim3(std::max(kd, 1), 4), RB, 0, st>>>(
       s->st, s->part, s->nblk, s->pstride, s->ldp, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace)));
   if (k >= s->thr) return;
   if (s->vec_ax != s->vec) {  // unsplit, own width
     const unsigned ga = (unsigned)s->nblk_ax;
+    PROF_BYTES((2 * k + 6) * (int64_t)s->M * 4);
     VLAUNCH("k_axpy", st, s->vec_ax, k_axpy, (dim3(ga, 1), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->nblk_ax, std::max(k, 1), s->jpart, s->ld);
+    PROF_BYTES(4 * (int64_t)s->M * 4);
     VLAUNCH("k_final", st, s->vec_ax, k_final, (ga, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->ld, s->part, s->nblk_ax);
     return;
   }
+  PROF_BYTES((2 * k + (G > 1 ? 3 * G : 6)) * (int64_t)s->M * 4);   // split: every block row writes its three partial vectors
   VLAUNCH("k_axpy", st, s->vec, k_axpy, (dim3(g, G), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->nblk, js, s->jpart, s->ld);
   if (G > 1)
+    PROF_BYTES((3 * G + 6) * (int64_t)s->M * 4);
     VLAUNCH("k_axpy_combine", st, s->vec, k_axpy_combine, (g, TB, 0, st), s->M, k, G, s->st, s->jpart, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->nblk, s->ld);
+  PROF_BYTES(4 * (int64_t)s->M * 4);
   VLAUNCH("k_final", st, s->vec, k_final, (g, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->ld, s->part, s->nblk);
 }
 
@@ -1499,6 +1510,7 @@ extern "C" int psignn_broyden_solve(psignn_broyden_t* s, const float* W, int nl,
       if (rc < 0) return rc;
       launch_update(s, it, eps, st, rc);
     } else {
+      PROF_BYTES(3 * (int64_t)s->M * 4);
       VLAUNCH("k_xnext", st, s->vec, k_xnext, (g, TB, 0, st), s->M, s->st, s->xbuf, s->upd, nullptr);
       rc = psignn_f_eval_p(p, W, nl, s->xbuf, sel_nxt, s->M, s->h0p, s->prbp, nrmp, s->fx, s->fwork, st);
       if (rc) return rc;
@@ -1663,6 +1675,11 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
     n_slots += (int)s->plan->n_tiles;
   }
   const bool own_width = s0->vec_ax != s0->vec;
+  int64_t Mtot4 = 0, bf_tot = 0;   // bytes of one state vector / of one fused f evaluation, summed over the shard (profiling records)
+  for (int m = 0; m < n; ++m) {
+    Mtot4 += sv[m]->M * 4;
+    bf_tot += (sv[m]->plan->mixed ? 102 : 89) * sv[m]->plan->N + 20 * sv[m]->plan->Ep + 16 * sv[m]->M;
+  }
   // ---- per mesh: status, plan-order inputs, g0 = f(x0) - x0 (exactly the single-mesh prologue)
   std::vector<BatchDesc> hd(n);
   int rc, base = 0;
@@ -1714,6 +1731,7 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
   bool a_ready = false;
   int a_from_next = 0;
   for (int it = 0; it < thr; ++it) {
+    PROF_BYTES(bf_tot);
     rc = psignn_f_tile_fused_batch(d_descs, n, n_slots, max_rows, W, s0->plan->mixed, off_done, sel_off_cur(), sel_off_nxt(), st);
     if (rc) { cleanup(); return rc; }
     const int k = it;
@@ -1722,13 +1740,16 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
       const dim3 gu((unsigned)max_gu, 1, (unsigned)n);
       // (all meshes of the shard carry the same number of stored pairs: one a_from / keep window for the launch)
       const int a_from = a_ready ? a_from_next : kd;
+      PROF_BYTES((std::min(a_from, kd) + 1) * Mtot4);
       if (std::min(a_from, kd) > 0) VLAUNCH("k_sweep_u1", st, s0->vec_u, kb_sweep_u1, (gu, TB, 0, st), d_descs, std::min(a_from, kd));
       LAUNCH("k_reduce_check", st, (kb_reduce_a_check<<<dim3((unsigned)std::max(kd, 1), RA + 1, (unsigned)n), RB, 0, st>>>(d_descs, kd, eps, a_from)));
       a_ready = false;
+      PROF_BYTES((k + 4) * Mtot4);
       VLAUNCH("k_sweep_v", st, s0->vec_u, kb_sweep_v, (gu, TB, 0, st), d_descs, k);
       LAUNCH("k_reduce_cb", st, (kb_reduce_cb<<<dim3((unsigned)std::max(k, 1), 3, (unsigned)n), RB, 0, st>>>(d_descs, k)));
       const int keep0 = k <= s0->u2d_kmax ? 0 : k - s0->u2d_keep;
       if (s0->u2d_kmax > 0 && (k <= s0->u2d_kmax || s0->u2d_keep > 0) && k + 1 < thr) {
+        PROF_BYTES((k + 5) * Mtot4);
         const int nk = k - keep0;
         const dim3 g4((unsigned)max_g4, 1, (unsigned)n);
         if (s0->u2d_reg) {
@@ -1742,19 +1763,25 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
         a_ready = true;
         a_from_next = keep0;
       } else {
+        PROF_BYTES((k + 5) * Mtot4);
         VLAUNCH("k_sweep_u2", st, s0->vec_u, kb_sweep_u2, (gu, TB, 0, st), d_descs, k);
       }
     } else {
     if (kd > 0)
+      PROF_BYTES((2 * kd + 3) * Mtot4);
       VLAUNCH("k_dots", st, s0->vec, kb_dots, (dim3((unsigned)max_g, (unsigned)max_G, (unsigned)n), TB, 0, st), d_descs, kd);
     LAUNCH("k_reduce_check", st, (kb_reduce_check<<<dim3((unsigned)std::max(kd, 1), 4, (unsigned)n), RB, 0, st>>>(d_descs, kd, eps)));
     if (own_width) {
+      PROF_BYTES((2 * k + 6) * Mtot4);
       VLAUNCH("k_axpy", st, s0->vec_ax, kb_axpy, (dim3((unsigned)max_ga, 1, (unsigned)n), TB, 0, st), d_descs, k, 1);
+      PROF_BYTES(4 * Mtot4);
       VLAUNCH("k_final", st, s0->vec_ax, kb_final, (dim3((unsigned)max_ga, 1, (unsigned)n), TB, 0, st), d_descs, k, 1);
     } else {
+      PROF_BYTES((2 * k + 6) * Mtot4);
       VLAUNCH("k_axpy", st, s0->vec, kb_axpy, (dim3((unsigned)max_g, (unsigned)max_G, (unsigned)n), TB, 0, st), d_descs, k, 0);
       if (max_G > 1 && k >= 4 * 2)   // some mesh may split from k = 4 * jgroups on (jgroups >= 2)
         VLAUNCH("k_axpy_combine", st, s0->vec, kb_axpy_combine, (dim3((unsigned)max_g, 1, (unsigned)n), TB, 0, st), d_descs, k);
+      PROF_BYTES(4 * Mtot4);
       VLAUNCH("k_final", st, s0->vec, kb_final, (dim3((unsigned)max_g, 1, (unsigned)n), TB, 0, st), d_descs, k, 0);
     }
     }

@@ -11,9 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(*extra):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--repeats", "2", *extra]
-    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+def _run(*extra, gpus=1, env=None):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "6", "--warmup", "2", "--repeats", "2", *extra]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -44,3 +44,30 @@ def test_bench_batched_workload_line():
     d = _run("--workload", "batch50k", "--nodes", "2000", "--no-cpu-baseline")
     assert d["config"]["meshes_per_gpu"] == 8 and "batched" in d["config"]["parallelism"]
     assert d["iters_per_sec"] > 0 and "roofline" in d and "cpu_baseline" not in d
+
+
+def test_bench_kernel_records_come_from_the_library():
+    """`roofline` / `kernels` are built from the library's launch records (durations AND algorithmic bytes stated at the launch
+    sites): every sweep row carries bytes, the iteration's total equals the sum of the rows, and the dominant kernel is one of them."""
+    d = _run("--workload", "dir100k", "--nodes", "40000", "--no-cpu-baseline")
+    rows = {r["kernel"]: r for r in d["kernels"]}
+    assert "k_f_tile_fused" in rows and rows["k_f_tile_fused"]["launches"] == 6
+    M4 = d["config"]["nodes"] * 10 * 4
+    bf = 89 * d["config"]["nodes"] + 20 * d["config"]["edges_nonself"]
+    assert abs(rows["k_f_tile_fused"]["alg_bytes_per_launch"] - (bf + 4 * M4)) < 1
+    sweep_bytes = sum(r["alg_bytes_per_launch"] * r["work_launches"] for r in d["kernels"] if "alg_bytes_per_launch" in r)
+    assert abs(sweep_bytes - d["roofline_iter"]["alg_bytes"]) < 1e-6 * sweep_bytes
+    assert d["roofline"]["kernel"] in rows and d["roofline"]["alg_bytes_per_launch"] > 0
+    assert d["ms_per_step_first"] > 0 and "warmup_extra" in d and d["ranks"]["world_size"] == 1
+
+
+def test_bench_two_ranks_self_launched_on_one_card():
+    """``bench.py --gpus 2`` started bare launches its two ranks itself (here both on the box's one card, rendezvous over gloo --
+    RCCL refuses two ranks on one device): n_gpus = 2 in the line, twice the meshes, value = sum over ranks."""
+    env = dict(os.environ, PSIGNN_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    d = _run("--workload", "batch50k", "--nodes", "3000", "--no-cpu-baseline", gpus=2, env=env)
+    assert d["n_gpus"] == 2 and d["ranks"]["world_size"] == 2 and d["ranks"]["backend"] == "gloo"
+    assert d["config"]["meshes_per_gpu"] == 8 and "x16" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 8 * d["config"]["edges_nonself"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]

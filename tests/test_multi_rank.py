@@ -2,12 +2,15 @@
 over replicas, max-over-ranks timing as bench.py does it).  No GPU work: per-mesh results are stand-ins."""
 import os
 import socket
+import sys
 
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import pkg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -165,3 +168,43 @@ def test_uneven_shards_do_not_hang_two_ranks_gloo(tmp_path):
         assert (tmp_path / f).exists(), f
     ck = torch.load(tmp_path / "final_model.pt", weights_only=True)
     assert ck["epoch"] == 1 and len(ck["hist_train"]["loss"]) == 2
+
+
+def _bench(env_extra, *argv):
+    import json
+    import subprocess
+    env = dict(os.environ, PSIGNN_BENCH_DRYRUN="1", **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p.returncode, [json.loads(l) for l in lines], p.stderr
+
+
+def test_bench_launches_its_own_ranks():
+    """``python bench.py --gpus N`` without a launcher (no RANK / WORLD_SIZE in the environment) starts its N ranks itself: fresh
+    child processes with the rendezvous variables set, rank 0's single JSON line relayed, exit code non-zero if any rank
+    fails.  Rehearsed here without a GPU (PSIGNN_BENCH_DRYRUN=1: the ranks only rendezvous over gloo, take the MAX of a
+    per-rank time and report the world size); the GPU form of the same launch is tests/test_gpu_bench_contract.py."""
+    rc, lines, err = _bench({}, "--gpus", "2", "--steps", "3", "--warmup", "1")
+    assert rc == 0 and len(lines) == 1, err[-2000:]
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"] == "gloo" and d["steps"] == 3
+    assert abs(d["max_over_ranks_s"] - 0.002) < 1e-12            # MAX over ranks of 0.001 * (rank + 1)
+    rc, lines, err = _bench({}, "--gpus", "1", "--steps", "3")
+    assert rc == 0 and lines[0]["n_gpus"] == 1 and lines[0]["ranks"] == 1
+    # a failing rank makes the launcher fail, whatever rank 0 printed
+    rc, lines, err = _bench({"PSIGNN_BENCH_DRYRUN_FAIL": "1"}, "--gpus", "2", "--steps", "3")
+    assert rc != 0 and "ranks failed" in err
+    # under a launcher (RANK / WORLD_SIZE set by torch.distributed.run) the process is one rank and spawns nothing
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       env=dict(os.environ, PSIGNN_BENCH_DRYRUN="1"), capture_output=True, text=True, timeout=300)
+    import json
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["ranks"] == 2, p.stderr[-2000:]
