@@ -1330,9 +1330,10 @@ static inline int sel_off_nxt() { return offsetof(Status, nxt) / 4; }
 // fused_npart > 0: the f kernel already produced g, dg and the norm partials (fused_npart entries each)
 static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, int fused_npart = 0) {
   unsigned g = (unsigned)s->nblk;
-  if (!fused_npart)
+  if (!fused_npart) {
     PROF_BYTES(5 * (int64_t)s->M * 4);
     VLAUNCH("k_resid", st, s->vec, k_resid, (g, TB, 0, st), s->M, s->st, s->xbuf, s->fx, s->gx, s->dg, s->nrm_part, s->nblk);
+  }
   const int np = fused_npart ? fused_npart : s->nblk;  // one partial pair per block / per tile
   if (s->uvu) {
     const int kd = k >= s->thr ? 0 : k;
@@ -1340,15 +1341,18 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
     if (k == 0) s->a_ready = 0;
     // a_j of this iteration: pairs j >= a_from were delivered by the folded sweep 3 of the last iteration, the others need sweep 1
     const int a_from = s->a_ready ? s->a_from : kd;
-    if (std::min(a_from, kd) > 0)
+    if (std::min(a_from, kd) > 0) {
       PROF_BYTES((std::min(a_from, kd) + 1) * (int64_t)s->M * 4);   // its columns of U + dx
       VLAUNCH("k_sweep_u1", st, s->vec_u, k_sweep_u1, (gu, TB, 0, st), s->M, std::min(a_from, kd), s->st, s->U, s->upd, s->part, s->ldp, s->ld);
+    }
     LAUNCH("k_reduce_check", st, (k_reduce_a_check<<<dim3(std::max(kd, 1), RA + 1), RB, 0, st>>>(
         s->st, s->part, s->nblk_u, s->ldp, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace,
         s->parta, s->nblk4, a_from)));
     s->a_ready = 0;
     if (k >= s->thr) return;
-    PROF_BYTES((k + 4) * (int64_t)s->M * 4);   // k columns of V + dx, dg, g; writes V[k]
+    // (iteration thr's stop test has just fired: the two sweeps below return at once and state no bytes)
+    const bool last = k + 1 >= s->thr;
+    PROF_BYTES(last ? 0 : (k + 4) * (int64_t)s->M * 4);   // k columns of V + dx, dg, g; writes V[k]
     VLAUNCH("k_sweep_v", st, s->vec_u, k_sweep_v, (gu, TB, 0, st), s->M, k, s->st, s->V, s->upd, s->dg, s->gx, s->coef, s->part, s->pstride, s->ldp, s->part2, s->nblk_u, s->ld, s->thr);
     LAUNCH("k_reduce_cb", st, (k_reduce_cb<<<dim3(std::max(k, 1), 3), RB, 0, st>>>(s->st, s->part, s->nblk_u, s->pstride, s->ldp, s->thr, k, s->coef, s->part2, s->nblk_u)));
     const int keep0 = k <= s->u2d_kmax ? 0 : k - s->u2d_keep;      // few stored pairs: all kept; later the most recent ones
@@ -1369,7 +1373,7 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
       s->a_ready = 1;
       s->a_from = keep0;
     } else {
-      PROF_BYTES((k + 5) * (int64_t)s->M * 4);
+      PROF_BYTES(last ? 0 : (k + 5) * (int64_t)s->M * 4);
       VLAUNCH("k_sweep_u2", st, s->vec_u, k_sweep_u2, (gu, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->ld);
     }
     return;
@@ -1378,26 +1382,28 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
   const int G = (s->jgroups > 1 && k >= 4 * s->jgroups) ? s->jgroups : 1;
   const int js = (int)cdiv(std::max(k, 1), G);
   const int kd = k >= s->thr ? 0 : k;  // the threshold stop is about to fire: no slot left for another pair
-  if (kd > 0)
+  if (kd > 0) {
     PROF_BYTES((2 * kd + 3) * (int64_t)s->M * 4);
     VLAUNCH("k_dots", st, s->vec, k_dots, (dim3(g, G), TB, 0, st), s->M, kd, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->pstride, s->ldp, js, s->ld);
+  }
   LAUNCH("k_reduce_check", st, (k_reduce_check<<<dim3(std::max(kd, 1), 4), RB, 0, st>>>(
       s->st, s->part, s->nblk, s->pstride, s->ldp, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace)));
   if (k >= s->thr) return;
   if (s->vec_ax != s->vec) {  // unsplit, own width
     const unsigned ga = (unsigned)s->nblk_ax;
-    PROF_BYTES((2 * k + 6) * (int64_t)s->M * 4);
+    PROF_BYTES(k + 1 >= s->thr ? 0 : (2 * k + 6) * (int64_t)s->M * 4);
     VLAUNCH("k_axpy", st, s->vec_ax, k_axpy, (dim3(ga, 1), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->nblk_ax, std::max(k, 1), s->jpart, s->ld);
-    PROF_BYTES(4 * (int64_t)s->M * 4);
+    PROF_BYTES(k + 1 >= s->thr ? 0 : 4 * (int64_t)s->M * 4);
     VLAUNCH("k_final", st, s->vec_ax, k_final, (ga, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->ld, s->part, s->nblk_ax);
     return;
   }
-  PROF_BYTES((2 * k + (G > 1 ? 3 * G : 6)) * (int64_t)s->M * 4);   // split: every block row writes its three partial vectors
+  PROF_BYTES(k + 1 >= s->thr ? 0 : (2 * k + (G > 1 ? 3 * G : 6)) * (int64_t)s->M * 4);   // split: every block row writes its three partial vectors
   VLAUNCH("k_axpy", st, s->vec, k_axpy, (dim3(g, G), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->nblk, js, s->jpart, s->ld);
-  if (G > 1)
-    PROF_BYTES((3 * G + 6) * (int64_t)s->M * 4);
+  if (G > 1) {
+    PROF_BYTES(k + 1 >= s->thr ? 0 : (3 * G + 6) * (int64_t)s->M * 4);
     VLAUNCH("k_axpy_combine", st, s->vec, k_axpy_combine, (g, TB, 0, st), s->M, k, G, s->st, s->jpart, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->nblk, s->ld);
-  PROF_BYTES(4 * (int64_t)s->M * 4);
+  }
+  PROF_BYTES(k + 1 >= s->thr ? 0 : 4 * (int64_t)s->M * 4);
   VLAUNCH("k_final", st, s->vec, k_final, (g, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->ld, s->part, s->nblk);
 }
 
@@ -1744,7 +1750,8 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
       if (std::min(a_from, kd) > 0) VLAUNCH("k_sweep_u1", st, s0->vec_u, kb_sweep_u1, (gu, TB, 0, st), d_descs, std::min(a_from, kd));
       LAUNCH("k_reduce_check", st, (kb_reduce_a_check<<<dim3((unsigned)std::max(kd, 1), RA + 1, (unsigned)n), RB, 0, st>>>(d_descs, kd, eps, a_from)));
       a_ready = false;
-      PROF_BYTES((k + 4) * Mtot4);
+      const bool last = k + 1 >= thr;   // the stop test of iteration thr has fired: the sweeps below return at once
+      PROF_BYTES(last ? 0 : (k + 4) * Mtot4);
       VLAUNCH("k_sweep_v", st, s0->vec_u, kb_sweep_v, (gu, TB, 0, st), d_descs, k);
       LAUNCH("k_reduce_cb", st, (kb_reduce_cb<<<dim3((unsigned)std::max(k, 1), 3, (unsigned)n), RB, 0, st>>>(d_descs, k)));
       const int keep0 = k <= s0->u2d_kmax ? 0 : k - s0->u2d_keep;
@@ -1763,25 +1770,26 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
         a_ready = true;
         a_from_next = keep0;
       } else {
-        PROF_BYTES((k + 5) * Mtot4);
+        PROF_BYTES(last ? 0 : (k + 5) * Mtot4);
         VLAUNCH("k_sweep_u2", st, s0->vec_u, kb_sweep_u2, (gu, TB, 0, st), d_descs, k);
       }
     } else {
-    if (kd > 0)
+    if (kd > 0) {
       PROF_BYTES((2 * kd + 3) * Mtot4);
       VLAUNCH("k_dots", st, s0->vec, kb_dots, (dim3((unsigned)max_g, (unsigned)max_G, (unsigned)n), TB, 0, st), d_descs, kd);
+    }
     LAUNCH("k_reduce_check", st, (kb_reduce_check<<<dim3((unsigned)std::max(kd, 1), 4, (unsigned)n), RB, 0, st>>>(d_descs, kd, eps)));
     if (own_width) {
-      PROF_BYTES((2 * k + 6) * Mtot4);
+      PROF_BYTES(k + 1 >= thr ? 0 : (2 * k + 6) * Mtot4);
       VLAUNCH("k_axpy", st, s0->vec_ax, kb_axpy, (dim3((unsigned)max_ga, 1, (unsigned)n), TB, 0, st), d_descs, k, 1);
-      PROF_BYTES(4 * Mtot4);
+      PROF_BYTES(k + 1 >= thr ? 0 : 4 * Mtot4);
       VLAUNCH("k_final", st, s0->vec_ax, kb_final, (dim3((unsigned)max_ga, 1, (unsigned)n), TB, 0, st), d_descs, k, 1);
     } else {
-      PROF_BYTES((2 * k + 6) * Mtot4);
+      PROF_BYTES(k + 1 >= thr ? 0 : (2 * k + 6) * Mtot4);
       VLAUNCH("k_axpy", st, s0->vec, kb_axpy, (dim3((unsigned)max_g, (unsigned)max_G, (unsigned)n), TB, 0, st), d_descs, k, 0);
       if (max_G > 1 && k >= 4 * 2)   // some mesh may split from k = 4 * jgroups on (jgroups >= 2)
         VLAUNCH("k_axpy_combine", st, s0->vec, kb_axpy_combine, (dim3((unsigned)max_g, 1, (unsigned)n), TB, 0, st), d_descs, k);
-      PROF_BYTES(4 * Mtot4);
+      PROF_BYTES(k + 1 >= thr ? 0 : 4 * Mtot4);
       VLAUNCH("k_final", st, s0->vec, kb_final, (dim3((unsigned)max_g, 1, (unsigned)n), TB, 0, st), d_descs, k, 0);
     }
     }
