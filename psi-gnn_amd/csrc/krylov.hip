@@ -40,7 +40,8 @@ struct psignn_gmres {
   int m = 0;
   int vec = 16, nblk = 0, npart = 0;
   float* V = nullptr;        // caller-owned basis: (m + 1, ld)
-  float* part = nullptr;     // (m + 2, npart) dot partials
+  float* part = nullptr;     // (nblk, ldp) dot partials: one value per block and basis vector, vectors contiguous
+  int ldp = 0;               // m + 2 rounded up to 64
   float* coef = nullptr;     // (m + 2) coefficients of the current pass (float, like the vectors)
   double* H = nullptr;       // (m + 1, m) column-major: R after the rotations (column j has j + 1 entries) | raw h in work
   double *cs = nullptr, *sn = nullptr, *g = nullptr, *hcol = nullptr, *y = nullptr, *res_hist = nullptr;
@@ -107,12 +108,14 @@ __global__ __launch_bounds__(TB) void k_gm_scale(int64_t M, const float* __restr
   stv<VEC>(dst, e0, M, x);
 }
 
-// dots pass: optional first transform w <- w - shift * v_j (stored back); per-wave partials of <v_i, w>, i <= j
-// pass 0 also leaves the per-wave partials of |w|^2 in row j + 1 of `part`; pass 1 returns at once unless st->reorth
+// dots pass: optional first transform w <- w - shift * v_j (stored back); per-BLOCK partials of <v_i, w>, i <= j, written as
+// coalesced rows part[block * ldp + i] (vec_helpers.h PairStash: round 2's one 4-byte store per wave and basis vector cost the
+// sweep 8 % of its rate).  pass 0 also leaves the partials of |w|^2 in column j + 1; pass 1 returns at once unless st->reorth
 template <int VEC>
 __global__ __launch_bounds__(TB) void k_gm_dots(int64_t M, int64_t ld, int j, float shift, const GmresState* __restrict__ st,
                                                 const float* __restrict__ V, float* __restrict__ w, float* __restrict__ part,
-                                                int npart, int pass) {
+                                                int ldp, int pass) {
+  __shared__ PairStash<1> sh;
   if (st->done || (pass && !st->reorth)) return;
   int64_t e0 = elem0<VEC>();
   const bool act = e0 < M;
@@ -130,36 +133,41 @@ __global__ __launch_bounds__(TB) void k_gm_dots(int64_t M, int64_t ld, int j, fl
 #pragma unroll
     for (int i = 0; i < VEC; ++i) x[i] = 0.f;
   }
-  const int wv = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+  const int wv = threadIdx.x >> 6;
   const bool lead = (threadIdx.x & 63) == 0;
-  for (int i = 0; i <= j; ++i) {
+  float* rowb = part + (int64_t)blockIdx.x * ldp;
+  const int last = pass == 0 ? j + 1 : j;     // columns 0 .. last: the j + 1 dot products (+ |w|^2 in pass 0)
+  for (int i = 0; i <= last; ++i) {
     float s = 0.f;
-    if (act) {
-      float v[VEC];
-      ldv_stream<VEC>(V + (int64_t)i * ld, e0, M, v);
+    if (i <= j) {
+      if (act) {
+        float v[VEC];
+        ldv_stream<VEC>(V + (int64_t)i * ld, e0, M, v);
 #pragma unroll
-      for (int c = 0; c < VEC; ++c) s = fmaf(v[c], x[c], s);
+        for (int c = 0; c < VEC; ++c) s = fmaf(v[c], x[c], s);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) s = fmaf(x[c], x[c], s);
     }
     s = wave_sum(s);
-    if (lead) part[(int64_t)i * npart + wv] = s;
-  }
-  if (pass == 0) {
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < VEC; ++c) s = fmaf(x[c], x[c], s);
-    s = wave_sum(s);
-    if (lead) part[(int64_t)(j + 1) * npart + wv] = s;
+    const int q = i & 63;
+    if (lead) sh.v[0][wv][q] = s;
+    if (q == 63 || i == last) {
+      float* const rows[1] = {rowb + (i - q)};
+      stash_flush<1>(sh, q + 1, rows);
+    }
   }
 }
 
-// one block per coefficient: coef[i] = sum of partials (rounded to float like the vectors they scale)
-// (pass 0: one more block, i = n_coef, sums the |w|^2 partials into st->n0sq)
-__global__ __launch_bounds__(TB) void k_gm_reduce(GmresState* __restrict__ st, const float* __restrict__ part, int npart,
+// one block per coefficient: coef[i] = sum over the blocks of column i of the partials (rounded to float like the vectors they scale)
+// (pass 0: one more block, i = n_coef, sums the |w|^2 column into st->n0sq)
+__global__ __launch_bounds__(TB) void k_gm_reduce(GmresState* __restrict__ st, const float* __restrict__ part, int nrows, int ldp,
                                                   float* __restrict__ coef, double* __restrict__ hcol, int accumulate, int n_coef) {
   __shared__ double sh[TB];
   if (st->done || (accumulate && !st->reorth)) return;
   const int i = blockIdx.x;
-  const double s = block_sum_partials(part + (int64_t)i * npart, npart, sh);
+  const double s = block_sum_col(part + i, nrows, ldp, sh);
   if (i == n_coef) {
     if (threadIdx.x == 0) st->n0sq = s;
     return;
@@ -352,9 +360,10 @@ extern "C" int psignn_gmres_create(psignn_gmres_t** out, int64_t n_elems, int64_
   s->vec = n_elems >= ((int64_t)3 << 18) ? 16 : 4;
   s->nblk = (int)cdiv(n_elems, (int64_t)s->vec * TB);
   s->npart = s->nblk * (TB / 64);
+  s->ldp = (m_max + 2 + 63) / 64 * 64;
   const size_t m = (size_t)m_max;
   struct { void** p; size_t n; } allocs[] = {
-      {(void**)&s->part, (m + 2) * s->npart * 4 + 16}, {(void**)&s->coef, (m + 2) * 4 + 16},
+      {(void**)&s->part, (size_t)s->nblk * s->ldp * 4 + 16}, {(void**)&s->coef, (m + 2) * 4 + 16},
       {(void**)&s->H, (m + 1) * (m + 1) * 8}, {(void**)&s->cs, (m + 2) * 8}, {(void**)&s->sn, (m + 2) * 8},
       {(void**)&s->g, (m + 3) * 8}, {(void**)&s->hcol, (m + 2) * 8}, {(void**)&s->y, (m + 2) * 8},
       {(void**)&s->res_hist, (m + 3) * 8}, {(void**)&s->st, sizeof(GmresState)}};
@@ -409,8 +418,8 @@ extern "C" int psignn_gmres_step(psignn_gmres_t* s, int j, double shift, double 
   float* w = s->V + (size_t)(j + 1) * s->ld;
   KNOB_INT(always, [] { const char* e = getenv("PSIGNN_GMRES_REORTH"); return e && strcmp(e, "always") == 0 ? 1 : 0; }());
   for (int pass = 0; pass < 2; ++pass) {
-    VLAUNCH("k_gm_dots", st, s->vec, k_gm_dots, (g, TB, 0, st), s->M, s->ld, j, 0.f, s->st, s->V, w, s->part, s->npart, pass);
-    LAUNCH("k_gm_reduce", st, (k_gm_reduce<<<(unsigned)(j + 1 + (pass == 0)), TB, 0, st>>>(s->st, s->part, s->npart, s->coef, s->hcol, pass, j + 1)));
+    VLAUNCH("k_gm_dots", st, s->vec, k_gm_dots, (g, TB, 0, st), s->M, s->ld, j, 0.f, s->st, s->V, w, s->part, s->ldp, pass);
+    LAUNCH("k_gm_reduce", st, (k_gm_reduce<<<(unsigned)(j + 1 + (pass == 0)), TB, 0, st>>>(s->st, s->part, s->nblk, s->ldp, s->coef, s->hcol, pass, j + 1)));
     VLAUNCH("k_gm_axpy", st, s->vec, k_gm_axpy, (g, TB, 0, st), s->M, s->ld, j, s->st, s->V, w, s->coef, s->part, s->nblk, pass);
     if (pass == 0) LAUNCH("k_gm_decide", st, (k_gm_decide<<<1, TB, 0, st>>>(s->st, s->part, s->nblk, always)));
   }

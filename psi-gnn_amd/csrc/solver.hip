@@ -46,48 +46,11 @@ struct Status {
 // order and store ONE contiguous row segment: part[plane][block * ldp + j].  Same bench: 0.76.  The reduce kernels read a
 // column of that (blocks x pairs) matrix per pair -- 64-byte sectors from L2, a quarter as many elements as before.
 #define PARTA_LD 32            // row pitch of the folded sweep's partials: at most U2R_KB_MAX + 1 = 25 kept pairs
-template <int NV>
-struct PairStash {
-  float v[NV][TB / 64][64];
-};
-// every thread of the block calls this with the same j, cnt (1..64 pairs stashed at slots 0..cnt-1) -- it contains barriers
-template <int NV>
-__device__ __forceinline__ void stash_flush(PairStash<NV>& sh, int cnt, float* const (&row)[NV]) {
-  __syncthreads();
-  const int t = threadIdx.x;
-  if (t < cnt) {
-#pragma unroll
-    for (int q = 0; q < NV; ++q) row[q][t] = (sh.v[q][0][t] + sh.v[q][1][t]) + (sh.v[q][2][t] + sh.v[q][3][t]);
-  }
-  __syncthreads();
-}
-// sum of n values p[b * stride], b = 0 .. n-1 (one column of a partials plane; stride 1: a contiguous list), fixed shape for a
-// given block size: thread-strided, 4 loads in flight, tree.  (RB = 1 024 threads per reduce block was tried for the column reads:
+// (block_sum_col, vec_helpers.h: RB = 1 024 threads per reduce block was tried for the column reads:
 // k_reduce_cb 9.7 vs 8.3 us, k_reduce_a_check unchanged -- a block's time is the 64-byte sectors it pulls through ONE CU, not
 // its load rounds; what helps is more blocks per column, RA below.)
 #define RB 256
 #define RA 8     // row chunks per column of the a-reduction: coef_a arrives as RA partial sums that sweep 2 adds up itself
-__device__ inline double block_sum_col(const float* __restrict__ p, int n, int64_t stride, double* sh) {
-  const int T = blockDim.x;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int i = threadIdx.x;
-  for (; i + 3 * T < n; i += 4 * T) {
-    const float a = p[(int64_t)i * stride], b = p[(int64_t)(i + T) * stride], c = p[(int64_t)(i + 2 * T) * stride],
-                d = p[(int64_t)(i + 3 * T) * stride];
-    s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
-  }
-  for (; i < n; i += T) s0 += (double)p[(int64_t)i * stride];
-  sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  for (int o = T / 2; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-    __syncthreads();
-  }
-  const double r = sh[0];
-  __syncthreads();
-  return r;
-}
-
 struct psignn_broyden {
   const psignn_plan* plan = nullptr;
   int64_t M = 0;
@@ -594,25 +557,46 @@ template <int VEC>
 __device__ __forceinline__ void sweep_u2_body(int64_t M, int k, const Status* __restrict__ st, float* __restrict__ U,
                                               float* __restrict__ upd, const float* __restrict__ dgv,
                                               const float* __restrict__ gv, const float* __restrict__ coef, int thr, int64_t ld) {
-  if (st->done) return;
+  if (__builtin_amdgcn_readfirstlane(st->done)) return;
   int64_t e0 = elem0<VEC>();
-  if (e0 >= M) return;
+  // (whole waves past the end leave; inside the last wave every lane stays for the coefficient hand-out below -- v_readlane reads
+  // the lane's register whether the lane is active or not, but an inactive lane would never have loaded its coefficient)
+  if (((int64_t)blockIdx.x * TB + (threadIdx.x & ~63)) * VEC >= M) return;
+  const bool act = e0 < M;
   float a1[VEC], a2[VEC], dg[VEC];
-  ldv<VEC>(upd, e0, M, a1);
-  ldv<VEC>(dgv, e0, M, dg);
-  ldv<VEC>(gv, e0, M, a2);
+  if (act) {
+    ldv<VEC>(upd, e0, M, a1);
+    ldv<VEC>(dgv, e0, M, dg);
+    ldv<VEC>(gv, e0, M, a2);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) a1[i] = a2[i] = dg[i] = 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < VEC; ++i) a1[i] = a1[i] + dg[i];
+  const int lane = threadIdx.x & 63;
+  float cwc = 0.f, cwb = 0.f;   // c_j, b_j of the current chunk of 64 pairs, lane q <-> pair jc + q (one vector load each; see sweep_v_body)
   for (int j = 0; j < k; ++j) {
     float u[VEC];
-    const float cc = coef[thr + j], cb = coef[2 * thr + j];
-    ldv_stream<VEC>(U + (int64_t)j * ld, e0, M, u);
+    const int q = j & 63;
+    if (q == 0) {
+      cwc = (j + lane < k) ? coef[thr + j + lane] : 0.f;
+      cwb = (j + lane < k) ? coef[2 * thr + j + lane] : 0.f;
+    }
+    const float cc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cwc), q));
+    const float cb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cwb), q));
+    if (act) ldv_stream<VEC>(U + (int64_t)j * ld, e0, M, u);
+    else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) u[i] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       a1[i] = fmaf(-cc, u[i], a1[i]);
       a2[i] = fmaf(-cb, u[i], a2[i]);
     }
   }
+  if (!act) return;
   const float sv = (float)st->s, beta = (float)st->beta;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
@@ -844,15 +828,20 @@ __device__ __forceinline__ void sweep_u2r_body(int64_t M, int k, const Status* _
       }
       // pairs before the kept window: streamed, eight pairs' loads in flight
       int j = 0;
+      const int lane8 = tid & 7, half = (tid >> 3) & 1;
       for (; j + U2D_UNROLL <= j_keep0; j += U2D_UNROLL) {
         float4 u[U2D_UNROLL];
         const float* Uj = U + (int64_t)j * ld;
         asm volatile("" : "+v"(off));
+        // the chunk's 16 coefficients in ONE vector load (lanes 0..7: c_j .. c_j+7, lanes 8..15: b_j ..), handed out by v_readlane: in
+        // the batched kernel a per-pair scalar read is a vector load whose latency sits inside the loop (see u2r_kept)
+        const float cv = coef[(1 + half) * thr + j + lane8];
 #pragma unroll
         for (int q = 0; q < U2D_UNROLL; ++q) u[q] = ld4_so(Uj + (int64_t)q * ld, off);
 #pragma unroll
         for (int q = 0; q < U2D_UNROLL; ++q) {
-          const float cc = rfl(coef[thr + j + q]), cb = rfl(coef[2 * thr + j + q]);
+          const float cc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv), q));
+          const float cb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv), 8 + q));
           a1[0] = fmaf(-cc, u[q].x, a1[0]); a1[1] = fmaf(-cc, u[q].y, a1[1]); a1[2] = fmaf(-cc, u[q].z, a1[2]); a1[3] = fmaf(-cc, u[q].w, a1[3]);
           a2[0] = fmaf(-cb, u[q].x, a2[0]); a2[1] = fmaf(-cb, u[q].y, a2[1]); a2[2] = fmaf(-cb, u[q].z, a2[2]); a2[3] = fmaf(-cb, u[q].w, a2[3]);
         }
@@ -1746,8 +1735,10 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
       const dim3 gu((unsigned)max_gu, 1, (unsigned)n);
       // (all meshes of the shard carry the same number of stored pairs: one a_from / keep window for the launch)
       const int a_from = a_ready ? a_from_next : kd;
-      PROF_BYTES((std::min(a_from, kd) + 1) * Mtot4);
-      if (std::min(a_from, kd) > 0) VLAUNCH("k_sweep_u1", st, s0->vec_u, kb_sweep_u1, (gu, TB, 0, st), d_descs, std::min(a_from, kd));
+      if (std::min(a_from, kd) > 0) {
+        PROF_BYTES((std::min(a_from, kd) + 1) * Mtot4);
+        VLAUNCH("k_sweep_u1", st, s0->vec_u, kb_sweep_u1, (gu, TB, 0, st), d_descs, std::min(a_from, kd));
+      }
       LAUNCH("k_reduce_check", st, (kb_reduce_a_check<<<dim3((unsigned)std::max(kd, 1), RA + 1, (unsigned)n), RB, 0, st>>>(d_descs, kd, eps, a_from)));
       a_ready = false;
       const bool last = k + 1 >= thr;   // the stop test of iteration thr has fired: the sweeps below return at once

@@ -164,6 +164,48 @@ __device__ inline double block_sum_contig(const float* __restrict__ p, int n, do
   return r;
 }
 
+// ---- dot-product partials as coalesced per-block rows (solver.hip, krylov.hip) ---------------------------------------------------
+// The lead lane of every wave stashes its wave sums of stored vector j in LDS; after every 64 vectors (and after the last) the
+// block's first 64 threads add the four waves' values in a fixed order and store ONE contiguous row segment -- instead of one
+// 4-byte store per wave and vector, which costs a streaming sweep 8 - 16 % of its rate (profiles/r3_ubench_sweep2.txt).
+template <int NV>
+struct PairStash {
+  float v[NV][TB / 64][64];
+};
+// every thread of the block calls this with the same j, cnt (1..64 pairs stashed at slots 0..cnt-1) -- it contains barriers
+template <int NV>
+__device__ __forceinline__ void stash_flush(PairStash<NV>& sh, int cnt, float* const (&row)[NV]) {
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < cnt) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) row[q][t] = (sh.v[q][0][t] + sh.v[q][1][t]) + (sh.v[q][2][t] + sh.v[q][3][t]);
+  }
+  __syncthreads();
+}
+// sum of n values p[b * stride], b = 0 .. n-1 (one column of a partials matrix; stride 1: a contiguous list), fixed shape for a given
+// block size: thread-strided, 4 loads in flight, tree
+__device__ inline double block_sum_col(const float* __restrict__ p, int n, int64_t stride, double* sh) {
+  const int T = blockDim.x;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * T < n; i += 4 * T) {
+    const float a = p[(int64_t)i * stride], b = p[(int64_t)(i + T) * stride], c = p[(int64_t)(i + 2 * T) * stride],
+                d = p[(int64_t)(i + 3 * T) * stride];
+    s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
+  }
+  for (; i < n; i += T) s0 += (double)p[(int64_t)i * stride];
+  sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  for (int o = T / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
 // launch a VEC-templated kernel with the solver's vector width
 #define VPLAIN(vec, kern, cfg, ...)                                     \
   do {                                                                  \
