@@ -187,7 +187,7 @@ struct BatchDesc {
   int64_t M, ld;
   int32_t nblk, npart, nblk_ax, jgroups, thr, seq_len, keep_trace, n_tiles, tile_base;
   int32_t* st;                 // the mesh's Status block, int32 view
-  float *U, *V, *xbuf, *gx, *dg, *upd, *part, *coef, *nrm_part, *jpart;
+  float *U, *V, *xbuf, *g0, *g1, *upd, *part, *coef, *nrm_part, *jpart;
   double *rel_trace, *abs_trace;
   const struct TileCtx* ctx;
   const float *h0p, *prbp;

@@ -100,8 +100,8 @@ static int stage1_mfma(bool fused, bool mixed) {
 // -- the work of k_xnext and k_resid without their extra passes over the state vectors.
 struct FuseArgs {
   const float* upd;   // update vector, plan order
-  float* gx;          // in: g_old, out: g_new
-  float* dg;          // out
+  float* gnew;        // out: g = f(x_next) - x_next  (g of the previous iterate stays in the solver's other g buffer: the
+                      // update kernels form dg = g_new - g_old themselves; round 2 read g_old and wrote dg here, +80 MB/step at 1M nodes)
   float* xbuf;        // iterate buffers (stride M)
   const int32_t* st;  // device status block (int32 view)
   int off_done, off_cur, off_nxt;
@@ -618,17 +618,14 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
   // ---- fused Broyden epilogue
   float sg = 0.f, sf = 0.f;
   if (active) {
-    float go[D], gn[D];
-    load10(fa.gx + n * D, go);
+    float gn[D];
 #pragma unroll
     for (int o = 0; o < D; ++o) {
       gn[o] = y[o] - x[o];
       sg = fmaf(gn[o], gn[o], sg);
       sf = fmaf(y[o], y[o], sf);
-      go[o] = gn[o] - go[o];
     }
-    store10(fa.gx + n * D, gn);
-    store10(fa.dg + n * D, go);
+    store10(fa.gnew + n * D, gn);
     if (!X_RELOAD || dirichlet) store10(fa.xbuf + (int64_t)fa.st[fa.off_nxt] * fa.M + n * D, x);
   }
   // one partial pair per tile: wave shuffles, then the 4 wave sums through LDS in a fixed order
@@ -697,7 +694,7 @@ static unsigned tile_grid(int chunk);
 #endif
 template <int P, bool MIXED>
 __global__ __launch_bounds__(TILE_THREADS) BATCH_WPE_ATTR void k_f_tile_batch(const BatchDesc* __restrict__ descs, int n_mesh, int n_slots, int chunk,
-                                                              int off_done, int off_cur, int off_nxt,
+                                                              int off_done, int off_cur, int off_nxt, int par,
                                                               const float* __restrict__ W, int lofs, int tofs, int tnofs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int slot = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
@@ -706,7 +703,7 @@ __global__ __launch_bounds__(TILE_THREADS) BATCH_WPE_ATTR void k_f_tile_batch(co
   while (m + 1 < n_mesh && descs[m + 1].tile_base <= slot) ++m;   // wave-uniform scalar walk (a shard has few meshes)
   const BatchDesc& d = descs[m];
   if (d.st[off_done]) return;
-  FuseArgs fa{d.upd, d.gx, d.dg, d.xbuf, d.st, off_done, off_cur, off_nxt, d.M, d.nrm_part, d.n_tiles, nullptr};
+  FuseArgs fa{d.upd, par ? d.g0 : d.g1, d.xbuf, d.st, off_done, off_cur, off_nxt, d.M, d.nrm_part, d.n_tiles, nullptr};
   f_tile_body<P, MIXED, true, false>(fa, slot - d.tile_base, nullptr, d.ctx, W, lofs, tofs, tnofs, 1, d.xbuf, nullptr, 0, d.h0p, d.prbp,
                                      d.nrmp, nullptr, lds);
 }
@@ -716,16 +713,16 @@ __global__ __launch_bounds__(TILE_THREADS) BATCH_WPE_ATTR void k_f_tile_batch(co
 // what the single-mesh fused step does below 2 048 plain tiles, and bit-identical to its two-group launch above that
 // (tests/test_gpu_configs.py::test_mixed_two_group_launch_at_natural_size).
 int psignn_f_tile_fused_batch(const BatchDesc* d_descs, int n_mesh, int n_slots, int max_rows, const float* W, int mixed,
-                              int off_done, int off_cur, int off_nxt, hipStream_t st) {
+                              int off_done, int off_cur, int off_nxt, int par, hipStream_t st) {
   const int chunk = (int)cdiv(n_slots, 8);
   if (mixed) {
     using L = WLayout<3>;
     LAUNCH("k_f_tile_fused", st, (k_f_tile_batch<3, true><<<tile_grid(chunk), TILE_THREADS, (size_t)max_rows * TileRow<true>::RS * 4, st>>>(
-        d_descs, n_mesh, n_slots, chunk, off_done, off_cur, off_nxt, W, L::layer(0), L::tp_layer(1, true, 0), L::tp_neu(1))));
+        d_descs, n_mesh, n_slots, chunk, off_done, off_cur, off_nxt, par, W, L::layer(0), L::tp_layer(1, true, 0), L::tp_neu(1))));
   } else {
     using L = WLayout<2>;
     LAUNCH("k_f_tile_fused", st, (k_f_tile_batch<2, false><<<tile_grid(chunk), TILE_THREADS, (size_t)max_rows * TileRow<false>::RS * 4, st>>>(
-        d_descs, n_mesh, n_slots, chunk, off_done, off_cur, off_nxt, W, L::layer(0), L::tp_layer(1, false, 0), 0)));
+        d_descs, n_mesh, n_slots, chunk, off_done, off_cur, off_nxt, par, W, L::layer(0), L::tp_layer(1, false, 0), 0)));
   }
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
@@ -830,18 +827,18 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
   return PSIGNN_OK;
 }
 
-// Fused Broyden step (single-layer models): x_next = x_cur + upd, f(x_next), g/dg/x_next/norm partials.
+// Fused Broyden step (single-layer models): x_next = x_cur + upd, f(x_next), g_new / x_next / norm partials.
 // Returns the number of partial entries per norm (n_tiles), or a negative error.
 int psignn_f_tile_fused(const psignn_plan* p, const float* W, int nl, float* xbuf, int64_t M, const int32_t* st_words,
-                        int off_done, int off_cur, int off_nxt, const float* upd, float* gx, float* dg,
+                        int off_done, int off_cur, int off_nxt, const float* upd, float* gnew,
                         const float* h0, const float* prb, const float* nrm, float* part, hipStream_t st) {
   ARG_CHECK(p && p->tiled, "plan has no tile structures");
   ARG_CHECK(nl == 1 || p->mixed, "fused step supports single-layer evaluation");
   const int chunk = (int)cdiv(p->n_tiles, 8);
   const unsigned grid = tile_grid(chunk);
   const int npart = (int)p->n_tiles;
-  FuseArgs fa{upd, gx, dg, xbuf, st_words, off_done, off_cur, off_nxt, M, part, npart, g_tile_stamps};
-  PROF_BYTES((p->mixed ? 102 : 89) * p->N + 20 * p->Ep + 16 * M);   // B_f + update, g_old read; g, dg written (x_next replaces f(x))
+  FuseArgs fa{upd, gnew, xbuf, st_words, off_done, off_cur, off_nxt, M, part, npart, g_tile_stamps};
+  PROF_BYTES((p->mixed ? 102 : 89) * p->N + 20 * p->Ep + 8 * M);   // B_f + update read, g_new written (x_next replaces f(x))
   if (p->mixed) {
     using L = WLayout<3>;
     if (stage1_mfma(true, true)) {

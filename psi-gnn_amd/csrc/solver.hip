@@ -64,7 +64,11 @@ struct psignn_broyden {
   float* jpart = nullptr;   // (jgroups, 3, M) partial axpy sums when jgroups > 1
   float *U = nullptr, *V = nullptr;
   float* xbuf = nullptr;    // (thr+2, M) with trace, else (3, M)
-  float *gx = nullptr, *dg = nullptr, *upd = nullptr, *fx = nullptr, *fwork = nullptr;
+  // g = f(x) - x of two consecutive iterates: g of iterate i lives in gbuf[i & 1].  Round 2 kept g and dg = g_new - g_old as two
+  // vectors that f had to read (g_old) and write (g_new, dg); every consumer of dg also reads g_new, so it now forms dg = g_new - g_old
+  // itself from the two g buffers (the same fp32 subtraction): f neither reads g_old nor writes dg -- 80 MB less per 1M-node step
+  float* gbuf[2] = {nullptr, nullptr};
+  float *upd = nullptr, *fx = nullptr, *fwork = nullptr;
   float* nrm_part = nullptr;  // norm partials of the f / residual kernel: 2 * nn floats
   float* part2 = nullptr;     // three-sweep update: block partials of vT.dg, vT.g (2 * nblk floats)
   int uvu = 0;                // the update runs as three single-array sweeps U, V, U (broyden_alloc)
@@ -162,30 +166,27 @@ __global__ __launch_bounds__(TB) void k_xtrial(int64_t M, const Status* __restri
   if (commit) stv<VEC>(upd, e0, M, b);
 }
 
-// g_new = fx - x_next ; dg = g_new - g ; g = g_new ; per-wave partials of |g_new|^2 and |fx|^2
+// g_new = fx - x_next ; per-wave partials of |g_new|^2 and |fx|^2   (dg = g_new - g_old is formed by its consumers)
 template <int VEC>
 __global__ __launch_bounds__(TB) void k_resid(int64_t M, const Status* __restrict__ st, const float* __restrict__ xb,
-                                              const float* __restrict__ fx, float* __restrict__ gx,
-                                              float* __restrict__ dg, float* __restrict__ part, int npart) {
+                                              const float* __restrict__ fx, float* __restrict__ gnew,
+                                              float* __restrict__ part, int npart) {
   if (st->done) return;
   int64_t e0 = elem0<VEC>();
   float sg = 0.f, sf = 0.f;
   if (e0 < M) {
     const float* xn = xb + (int64_t)st->nxt * M;
-    float x[VEC], f[VEC], g[VEC];
+    float x[VEC], f[VEC];
     ldv<VEC>(xn, e0, M, x);
     ldv<VEC>(fx, e0, M, f);
-    ldv<VEC>(gx, e0, M, g);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       float gn = f[i] - x[i];
       sg = fmaf(gn, gn, sg);
       sf = fmaf(f[i], f[i], sf);
-      g[i] = gn - g[i];
       x[i] = gn;
     }
-    stv<VEC>(gx, e0, M, x);
-    stv<VEC>(dg, e0, M, g);
+    stv<VEC>(gnew, e0, M, x);
   }
   block_pair_store(sg, sf, part, npart);
 }
@@ -281,6 +282,8 @@ __device__ __forceinline__ void dots_body(int64_t M, int k, const Status* __rest
     ldv<VEC>(dxv, e0, M, dx);
     ldv<VEC>(dgv, e0, M, dg);
     ldv<VEC>(gv, e0, M, g);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) dg[i] = g[i] - dg[i];   // dgv holds g of the previous iterate
   } else {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) dx[i] = dg[i] = g[i] = 0.f;
@@ -459,6 +462,8 @@ __device__ __forceinline__ void sweep_v_body(int64_t M, int k, const Status* __r
     ldv<VEC>(dgv, e0, M, dg);
     ldv<VEC>(gv, e0, M, g);
 #pragma unroll
+    for (int i = 0; i < VEC; ++i) dg[i] = g[i] - dg[i];   // dgv holds g of the previous iterate
+#pragma unroll
     for (int i = 0; i < VEC; ++i) av[i] = -av[i];
   } else {
 #pragma unroll
@@ -568,6 +573,8 @@ __device__ __forceinline__ void sweep_u2_body(int64_t M, int k, const Status* __
     ldv<VEC>(upd, e0, M, a1);
     ldv<VEC>(dgv, e0, M, dg);
     ldv<VEC>(gv, e0, M, a2);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) dg[i] = a2[i] - dg[i];   // dgv holds g of the previous iterate
   } else {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) a1[i] = a2[i] = dg[i] = 0.f;
@@ -642,6 +649,8 @@ __device__ __forceinline__ void sweep_u2d_body(int64_t M, int k, const Status* _
     ldv<4>(upd, e0, M, a1);
     ldv<4>(dgv, e0, M, dg);
     ldv<4>(gv, e0, M, a2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dg[i] = a2[i] - dg[i];   // dgv holds g of the previous iterate
 #pragma unroll
     for (int i = 0; i < 4; ++i) a1[i] = a1[i] + dg[i];
   } else {
@@ -753,8 +762,8 @@ __device__ __forceinline__ void u2r_kept(float (&a1)[4], float (&a2)[4], int k, 
 #pragma unroll
   for (int q = 0; q < NK; ++q) kp[q] = ld4_so(Ub + (int64_t)q * ld, off);
   if (FIRST) {   // all pairs are kept (j_keep0 = 0): the three state vectors are requested in the same burst as the NK rows of U
-    const float4 x = ld4_so(upd, off), dg = ld4_so(dgv, off), g = ld4_so(gv, off);
-    a1[0] = x.x + dg.x; a1[1] = x.y + dg.y; a1[2] = x.z + dg.z; a1[3] = x.w + dg.w;
+    const float4 x = ld4_so(upd, off), go = ld4_so(dgv, off), g = ld4_so(gv, off);
+    a1[0] = x.x + (g.x - go.x); a1[1] = x.y + (g.y - go.y); a1[2] = x.z + (g.z - go.z); a1[3] = x.w + (g.w - go.w);
     a2[0] = g.x; a2[1] = g.y; a2[2] = g.z; a2[3] = g.w;
   }
   // The 2 NK coefficients: lane q of the wave loads the pair of stored pair q (ONE vector load each for c and b), v_readlane hands
@@ -822,8 +831,8 @@ __device__ __forceinline__ void sweep_u2r_body(int64_t M, int k, const Status* _
       }
     } else {
       {
-        const float4 x = ld4_so(upd, off), dg = ld4_so(dgv, off), g = ld4_so(gv, off);
-        a1[0] = x.x + dg.x; a1[1] = x.y + dg.y; a1[2] = x.z + dg.z; a1[3] = x.w + dg.w;
+        const float4 x = ld4_so(upd, off), go = ld4_so(dgv, off), g = ld4_so(gv, off);
+        a1[0] = x.x + (g.x - go.x); a1[1] = x.y + (g.y - go.y); a1[2] = x.z + (g.z - go.z); a1[3] = x.w + (g.w - go.w);
         a2[0] = g.x; a2[1] = g.y; a2[2] = g.z; a2[3] = g.w;
       }
       // pairs before the kept window: streamed, eight pairs' loads in flight
@@ -871,6 +880,8 @@ __device__ __forceinline__ void sweep_u2r_body(int64_t M, int k, const Status* _
       ldv<4>(upd, e0, M, a1);
       ldv<4>(dgv, e0, M, dg);
       ldv<4>(gv, e0, M, a2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dg[i] = a2[i] - dg[i];   // dgv holds g of the previous iterate
 #pragma unroll
       for (int i = 0; i < 4; ++i) a1[i] = a1[i] + dg[i];
     }
@@ -959,6 +970,8 @@ __device__ __forceinline__ void axpy_body(int64_t M, int k, const Status* __rest
       ldv<VEC>(dgv, e0, M, dg);
       ldv<VEC>(gv, e0, M, g);
 #pragma unroll
+      for (int i = 0; i < VEC; ++i) dg[i] = g[i] - dg[i];   // dgv holds g of the previous iterate
+#pragma unroll
       for (int i = 0; i < VEC; ++i) {
         a1[i] = av[i] + dg[i];
         a2[i] = g[i];
@@ -1016,6 +1029,8 @@ __device__ __forceinline__ void axpy_combine_body(int64_t M, int k, int G, const
     ldv<VEC>(upd, e0, M, av);
     ldv<VEC>(dgv, e0, M, dg);
     ldv<VEC>(gv, e0, M, g);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) dg[i] = g[i] - dg[i];   // dgv holds g of the previous iterate
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       a1[i] = av[i] + dg[i];
@@ -1103,11 +1118,11 @@ int psignn_f_eval_p(const psignn_plan_t* p, const float* W, int nl, const float*
                     hipStream_t st);
 
 int psignn_f_tile_fused(const psignn_plan* p, const float* W, int nl, float* xbuf, int64_t M, const int32_t* st_words,
-                        int off_done, int off_cur, int off_nxt, const float* upd, float* gx, float* dg,
+                        int off_done, int off_cur, int off_nxt, const float* upd, float* gnew,
                         const float* h0, const float* prb, const float* nrm, float* part, hipStream_t st);
 
 #define U2R_KB_MAX 24
-__global__ __launch_bounds__(TB) void kb_sweep_u2d(const BatchDesc* __restrict__ descs, int k, int j_keep0);
+__global__ __launch_bounds__(TB) void kb_sweep_u2d(const BatchDesc* __restrict__ descs, int k, int j_keep0, int par);
 // LDS form of the folded sweep: up to 38 pairs x 16 B x 256 threads of dynamic LDS; asked for once per device
 static bool u2d_lds_attr(int dev) {
   static int state[64] = {0};   // 0 unknown, 1 granted, -1 refused
@@ -1203,7 +1218,7 @@ static int broyden_alloc(psignn_broyden* s) {
   size_t ld = (size_t)s->ld;
   struct { void** p; size_t n; } allocs[] = {
       {(void**)&s->U, thr * ld * 4},  {(void**)&s->V, thr * ld * 4},   {(void**)&s->xbuf, nx * M * 4},
-      {(void**)&s->gx, M * 4},        {(void**)&s->dg, M * 4},        {(void**)&s->upd, M * 4},
+      {(void**)&s->gbuf[0], M * 4},   {(void**)&s->gbuf[1], M * 4},   {(void**)&s->upd, M * 4},
       {(void**)&s->fx, M * 4},        {(void**)&s->part, 3 * (size_t)s->pstride * 4 + 16}, {(void**)&s->parta, (size_t)s->nblk4 * PARTA_LD * 4 + 16},
       {(void**)&s->coef, (3 + RA) * thr * 4 + 16}, {(void**)&s->st, sizeof(Status)},
       {(void**)&s->nrm_part, 2 * (size_t)s->nn_cap * 4 + 16}, {(void**)&s->part2, 2 * (size_t)std::max(s->nblk, s->nblk_u) * 4 + 16},
@@ -1247,7 +1262,7 @@ static int broyden_alloc(psignn_broyden* s) {
 
 extern "C" void psignn_broyden_destroy(psignn_broyden_t* s) {
   if (!s) return;
-  void* ptrs[] = {s->U, s->V, s->xbuf, s->gx, s->dg, s->upd, s->fx, s->fwork, s->part, s->coef, s->st, s->nrm_part, s->part2, s->parta,
+  void* ptrs[] = {s->U, s->V, s->xbuf, s->gbuf[0], s->gbuf[1], s->upd, s->fx, s->fwork, s->part, s->coef, s->st, s->nrm_part, s->part2, s->parta,
                   s->rel_trace, s->abs_trace, s->h0p, s->prbp, s->nrmp, s->jpart};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -1319,9 +1334,11 @@ static inline int sel_off_nxt() { return offsetof(Status, nxt) / 4; }
 // fused_npart > 0: the f kernel already produced g, dg and the norm partials (fused_npart entries each)
 static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, int fused_npart = 0) {
   unsigned g = (unsigned)s->nblk;
+  float* const gnew = s->gbuf[(k + 1) & 1];        // g of the iterate just evaluated
+  const float* const gold = s->gbuf[k & 1];        // g of the iterate before it
   if (!fused_npart) {
-    PROF_BYTES(5 * (int64_t)s->M * 4);
-    VLAUNCH("k_resid", st, s->vec, k_resid, (g, TB, 0, st), s->M, s->st, s->xbuf, s->fx, s->gx, s->dg, s->nrm_part, s->nblk);
+    PROF_BYTES(3 * (int64_t)s->M * 4);
+    VLAUNCH("k_resid", st, s->vec, k_resid, (g, TB, 0, st), s->M, s->st, s->xbuf, s->fx, gnew, s->nrm_part, s->nblk);
   }
   const int np = fused_npart ? fused_npart : s->nblk;  // one partial pair per block / per tile
   if (s->uvu) {
@@ -1342,28 +1359,28 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
     // (iteration thr's stop test has just fired: the two sweeps below return at once and state no bytes)
     const bool last = k + 1 >= s->thr;
     PROF_BYTES(last ? 0 : (k + 4) * (int64_t)s->M * 4);   // k columns of V + dx, dg, g; writes V[k]
-    VLAUNCH("k_sweep_v", st, s->vec_u, k_sweep_v, (gu, TB, 0, st), s->M, k, s->st, s->V, s->upd, s->dg, s->gx, s->coef, s->part, s->pstride, s->ldp, s->part2, s->nblk_u, s->ld, s->thr);
+    VLAUNCH("k_sweep_v", st, s->vec_u, k_sweep_v, (gu, TB, 0, st), s->M, k, s->st, s->V, s->upd, gold, gnew, s->coef, s->part, s->pstride, s->ldp, s->part2, s->nblk_u, s->ld, s->thr);
     LAUNCH("k_reduce_cb", st, (k_reduce_cb<<<dim3(std::max(k, 1), 3), RB, 0, st>>>(s->st, s->part, s->nblk_u, s->pstride, s->ldp, s->thr, k, s->coef, s->part2, s->nblk_u)));
     const int keep0 = k <= s->u2d_kmax ? 0 : k - s->u2d_keep;      // few stored pairs: all kept; later the most recent ones
     if (s->u2d_kmax > 0 && (k <= s->u2d_kmax || s->u2d_keep > 0) && k + 1 < s->thr) {
       PROF_BYTES((k + 5) * (int64_t)s->M * 4);   // k columns of U + update, dg, g; writes U[k], update (whichever form runs)
       const int nk = k - keep0;
       if (s->u2d_reg) {
-#define U2R_ARGS s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->parta, s->ld, keep0
+#define U2R_ARGS s->M, k, s->st, s->U, s->upd, gold, gnew, s->coef, s->thr, s->parta, s->ld, keep0
         if (nk <= 8) LAUNCH("k_sweep_u2d", st, (k_sweep_u2r<8><<<(unsigned)s->nblk4, TB, 0, st>>>(U2R_ARGS)));
         else if (nk <= 16) LAUNCH("k_sweep_u2d", st, (k_sweep_u2r<16><<<(unsigned)s->nblk4, TB, 0, st>>>(U2R_ARGS)));
         else LAUNCH("k_sweep_u2d", st, (k_sweep_u2r<24><<<(unsigned)s->nblk4, TB, 0, st>>>(U2R_ARGS)));
 #undef U2R_ARGS
       } else {
         const size_t lds = (size_t)std::max(nk, 1) * TB * 16;
-        LAUNCH("k_sweep_u2d", st, (k_sweep_u2d<<<(unsigned)s->nblk4, TB, lds, st>>>(s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->parta,
+        LAUNCH("k_sweep_u2d", st, (k_sweep_u2d<<<(unsigned)s->nblk4, TB, lds, st>>>(s->M, k, s->st, s->U, s->upd, gold, gnew, s->coef, s->thr, s->parta,
                                                                                     s->ld, keep0)));
       }
       s->a_ready = 1;
       s->a_from = keep0;
     } else {
       PROF_BYTES(last ? 0 : (k + 5) * (int64_t)s->M * 4);
-      VLAUNCH("k_sweep_u2", st, s->vec_u, k_sweep_u2, (gu, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->dg, s->gx, s->coef, s->thr, s->ld);
+      VLAUNCH("k_sweep_u2", st, s->vec_u, k_sweep_u2, (gu, TB, 0, st), s->M, k, s->st, s->U, s->upd, gold, gnew, s->coef, s->thr, s->ld);
     }
     return;
   }
@@ -1373,7 +1390,7 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
   const int kd = k >= s->thr ? 0 : k;  // the threshold stop is about to fire: no slot left for another pair
   if (kd > 0) {
     PROF_BYTES((2 * kd + 3) * (int64_t)s->M * 4);
-    VLAUNCH("k_dots", st, s->vec, k_dots, (dim3(g, G), TB, 0, st), s->M, kd, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->pstride, s->ldp, js, s->ld);
+    VLAUNCH("k_dots", st, s->vec, k_dots, (dim3(g, G), TB, 0, st), s->M, kd, s->st, s->U, s->V, s->upd, gold, gnew, s->part, s->pstride, s->ldp, js, s->ld);
   }
   LAUNCH("k_reduce_check", st, (k_reduce_check<<<dim3(std::max(kd, 1), 4), RB, 0, st>>>(
       s->st, s->part, s->nblk, s->pstride, s->ldp, s->thr, kd, s->coef, s->nrm_part, np, s->rel_trace, s->abs_trace, eps, s->seq_len, s->keep_trace)));
@@ -1381,16 +1398,16 @@ static void launch_update(psignn_broyden* s, int k, double eps, hipStream_t st, 
   if (s->vec_ax != s->vec) {  // unsplit, own width
     const unsigned ga = (unsigned)s->nblk_ax;
     PROF_BYTES(k + 1 >= s->thr ? 0 : (2 * k + 6) * (int64_t)s->M * 4);
-    VLAUNCH("k_axpy", st, s->vec_ax, k_axpy, (dim3(ga, 1), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->nblk_ax, std::max(k, 1), s->jpart, s->ld);
+    VLAUNCH("k_axpy", st, s->vec_ax, k_axpy, (dim3(ga, 1), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, gold, gnew, s->coef, s->thr, s->part, s->nblk_ax, std::max(k, 1), s->jpart, s->ld);
     PROF_BYTES(k + 1 >= s->thr ? 0 : 4 * (int64_t)s->M * 4);
     VLAUNCH("k_final", st, s->vec_ax, k_final, (ga, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->ld, s->part, s->nblk_ax);
     return;
   }
   PROF_BYTES(k + 1 >= s->thr ? 0 : (2 * k + (G > 1 ? 3 * G : 6)) * (int64_t)s->M * 4);   // split: every block row writes its three partial vectors
-  VLAUNCH("k_axpy", st, s->vec, k_axpy, (dim3(g, G), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, s->dg, s->gx, s->coef, s->thr, s->part, s->nblk, js, s->jpart, s->ld);
+  VLAUNCH("k_axpy", st, s->vec, k_axpy, (dim3(g, G), TB, 0, st), s->M, k, s->st, s->U, s->V, s->upd, gold, gnew, s->coef, s->thr, s->part, s->nblk, js, s->jpart, s->ld);
   if (G > 1) {
     PROF_BYTES(k + 1 >= s->thr ? 0 : (3 * G + 6) * (int64_t)s->M * 4);
-    VLAUNCH("k_axpy_combine", st, s->vec, k_axpy_combine, (g, TB, 0, st), s->M, k, G, s->st, s->jpart, s->U, s->V, s->upd, s->dg, s->gx, s->part, s->nblk, s->ld);
+    VLAUNCH("k_axpy_combine", st, s->vec, k_axpy_combine, (g, TB, 0, st), s->M, k, G, s->st, s->jpart, s->U, s->V, s->upd, gold, gnew, s->part, s->nblk, s->ld);
   }
   PROF_BYTES(k + 1 >= s->thr ? 0 : 4 * (int64_t)s->M * 4);
   VLAUNCH("k_final", st, s->vec, k_final, (g, TB, 0, st), s->M, k, s->st, s->U, s->upd, s->ld, s->part, s->nblk);
@@ -1458,7 +1475,7 @@ extern "C" int psignn_broyden_solve(psignn_broyden_t* s, const float* W, int nl,
   const float* nrmp = p->mixed ? s->nrmp : nullptr;
   // gx0 = f(x0) - x0, update = gx0 (solver.py:131-136)
   if ((rc = psignn_f_eval_p(p, W, nl, s->h0p, nullptr, 0, s->h0p, s->prbp, nrmp, s->fx, s->fwork, st))) return rc;
-  VPLAIN(s->vec, k_begin, (g, TB, 0, st), s->M, s->h0p, s->fx, s->xbuf, s->gx, s->upd);
+  VPLAIN(s->vec, k_begin, (g, TB, 0, st), s->M, s->h0p, s->fx, s->xbuf, s->gbuf[0], s->upd);
   const bool fused = p->tiled && (nl == 1 || p->mixed);
   const int32_t* st_words = reinterpret_cast<const int32_t*>(s->st);
   KNOB_INT(use_graph, [] { const char* e = getenv("PSIGNN_GRAPH"); return (int)(e && atoi(e) != 0); }());
@@ -1482,7 +1499,7 @@ extern "C" int psignn_broyden_solve(psignn_broyden_t* s, const float* W, int nl,
         HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         for (int it = c * poll_every; it < std::min(s->thr, (c + 1) * poll_every); ++it) {
           rc = psignn_f_tile_fused(p, W, nl, s->xbuf, s->M, st_words, offsetof(Status, done) / 4, sel_off_cur(), sel_off_nxt(),
-                                   s->upd, s->gx, s->dg, s->h0p, s->prbp, nrmp, s->nrm_part, st);
+                                   s->upd, s->gbuf[(it + 1) & 1], s->h0p, s->prbp, nrmp, s->nrm_part, st);
           if (rc >= 0) launch_update(s, it, eps, st, rc);
         }
         HIP_TRY(hipStreamEndCapture(st, &graph));
@@ -1501,7 +1518,7 @@ extern "C" int psignn_broyden_solve(psignn_broyden_t* s, const float* W, int nl,
     if (fused) {
       // one kernel: x_next = x_cur + update, f(x_next), g_new, dg, x_next and the norm partials
       rc = psignn_f_tile_fused(p, W, nl, s->xbuf, s->M, st_words, offsetof(Status, done) / 4, sel_off_cur(),
-                               sel_off_nxt(), s->upd, s->gx, s->dg, s->h0p, s->prbp, nrmp, s->nrm_part, st);
+                               sel_off_nxt(), s->upd, s->gbuf[(it + 1) & 1], s->h0p, s->prbp, nrmp, s->nrm_part, st);
       if (rc < 0) return rc;
       launch_update(s, it, eps, st, rc);
     } else {
@@ -1532,13 +1549,16 @@ static __device__ __forceinline__ int batch_groups(const BatchDesc& d, int k) {
   return (d.jgroups > 1 && k >= 4 * d.jgroups) ? d.jgroups : 1;
 }
 static __device__ __forceinline__ int idiv_up(int a, int b) { return (a + b - 1) / b; }
+// g of iterate i lives in g[i & 1] (see psignn_broyden::gbuf); par = iteration & 1
+static __device__ __forceinline__ const float* bd_gold(const BatchDesc& d, int par) { return par ? d.g1 : d.g0; }
+static __device__ __forceinline__ float* bd_gnew(const BatchDesc& d, int par) { return par ? d.g0 : d.g1; }
 
 template <int VEC>
-__global__ __launch_bounds__(TB) void kb_dots(const BatchDesc* __restrict__ descs, int k) {
+__global__ __launch_bounds__(TB) void kb_dots(const BatchDesc* __restrict__ descs, int k, int par) {
   const BatchDesc& d = descs[blockIdx.z];
   const int G = batch_groups(d, k);
   if ((int)blockIdx.x >= d.nblk || (int)blockIdx.y >= G) return;
-  dots_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.V, d.upd, d.dg, d.gx, d.part, d.pstride, (d.thr + 63) / 64 * 64,
+  dots_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.V, d.upd, bd_gold(d, par), bd_gnew(d, par), d.part, d.pstride, (d.thr + 63) / 64 * 64,
                  idiv_up(k > 1 ? k : 1, G), d.ld);
 }
 __global__ __launch_bounds__(RB) void kb_reduce_check(const BatchDesc* __restrict__ descs, int k, double eps) {
@@ -1548,21 +1568,21 @@ __global__ __launch_bounds__(RB) void kb_reduce_check(const BatchDesc* __restric
                     d.abs_trace, eps, d.seq_len, d.keep_trace, sh);
 }
 template <int VEC>
-__global__ __launch_bounds__(TB) void kb_axpy(const BatchDesc* __restrict__ descs, int k, int own_width) {
+__global__ __launch_bounds__(TB) void kb_axpy(const BatchDesc* __restrict__ descs, int k, int own_width, int par) {
   const BatchDesc& d = descs[blockIdx.z];
   // own_width: the axpy / final passes run unsplit with their own vector width (broyden_alloc: vec_ax != vec)
   const int G = own_width ? 1 : batch_groups(d, k);
   const int nb = own_width ? d.nblk_ax : d.nblk;
   if ((int)blockIdx.x >= nb || (int)blockIdx.y >= G) return;
-  axpy_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.V, d.upd, d.dg, d.gx, d.coef, d.thr, d.part, nb,
+  axpy_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.V, d.upd, bd_gold(d, par), bd_gnew(d, par), d.coef, d.thr, d.part, nb,
                  idiv_up(k > 1 ? k : 1, G), d.jpart, d.ld, G > 1);
 }
 template <int VEC>
-__global__ __launch_bounds__(TB) void kb_axpy_combine(const BatchDesc* __restrict__ descs, int k) {
+__global__ __launch_bounds__(TB) void kb_axpy_combine(const BatchDesc* __restrict__ descs, int k, int par) {
   const BatchDesc& d = descs[blockIdx.z];
   const int G = batch_groups(d, k);
   if ((int)blockIdx.x >= d.nblk || G <= 1) return;
-  axpy_combine_body<VEC>(d.M, k, G, reinterpret_cast<const Status*>(d.st), d.jpart, d.U, d.V, d.upd, d.dg, d.gx, d.part, d.nblk, d.ld);
+  axpy_combine_body<VEC>(d.M, k, G, reinterpret_cast<const Status*>(d.st), d.jpart, d.U, d.V, d.upd, bd_gold(d, par), bd_gnew(d, par), d.part, d.nblk, d.ld);
 }
 template <int VEC>
 __global__ __launch_bounds__(TB) void kb_final(const BatchDesc* __restrict__ descs, int k, int own_width) {
@@ -1585,22 +1605,22 @@ __global__ __launch_bounds__(RB) void kb_reduce_a_check(const BatchDesc* __restr
   reduce_a_check_body(reinterpret_cast<Status*>(d.st), d.part, d.nblk_u, (d.thr + 63) / 64 * 64, d.thr, k, d.coef, d.nrm_part, d.n_tiles, d.rel_trace,
                       d.abs_trace, eps, d.seq_len, d.keep_trace, sh, d.parta, d.nblk4, a_from);
 }
-__global__ __launch_bounds__(TB) void kb_sweep_u2d(const BatchDesc* __restrict__ descs, int k, int j_keep0) {
+__global__ __launch_bounds__(TB) void kb_sweep_u2d(const BatchDesc* __restrict__ descs, int k, int j_keep0, int par) {
   const BatchDesc& d = descs[blockIdx.z];
   if ((int)blockIdx.x >= d.nblk4) return;
-  sweep_u2d_body(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, d.dg, d.gx, d.coef, d.thr, d.parta, d.ld, j_keep0);
+  sweep_u2d_body(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, bd_gold(d, par), bd_gnew(d, par), d.coef, d.thr, d.parta, d.ld, j_keep0);
 }
 template <int KB>
-__global__ __launch_bounds__(TB, U2RWaves<KB>::value) void kb_sweep_u2r(const BatchDesc* __restrict__ descs, int k, int j_keep0) {
+__global__ __launch_bounds__(TB, U2RWaves<KB>::value) void kb_sweep_u2r(const BatchDesc* __restrict__ descs, int k, int j_keep0, int par) {
   const BatchDesc& d = descs[blockIdx.z];
   if ((int)blockIdx.x >= d.nblk4) return;
-  sweep_u2r_body<KB>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, d.dg, d.gx, d.coef, d.thr, d.parta, d.ld, j_keep0);
+  sweep_u2r_body<KB>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, bd_gold(d, par), bd_gnew(d, par), d.coef, d.thr, d.parta, d.ld, j_keep0);
 }
 template <int VEC>
-__global__ __launch_bounds__(TB) void kb_sweep_v(const BatchDesc* __restrict__ descs, int k) {
+__global__ __launch_bounds__(TB) void kb_sweep_v(const BatchDesc* __restrict__ descs, int k, int par) {
   const BatchDesc& d = descs[blockIdx.z];
   if ((int)blockIdx.x >= d.nblk_u) return;
-  sweep_v_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.V, d.upd, d.dg, d.gx, d.coef, d.part, d.pstride, (d.thr + 63) / 64 * 64, d.part2,
+  sweep_v_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.V, d.upd, bd_gold(d, par), bd_gnew(d, par), d.coef, d.part, d.pstride, (d.thr + 63) / 64 * 64, d.part2,
                     d.nblk_u, d.ld, d.thr);
 }
 __global__ __launch_bounds__(RB) void kb_reduce_cb(const BatchDesc* __restrict__ descs, int k) {
@@ -1609,10 +1629,10 @@ __global__ __launch_bounds__(RB) void kb_reduce_cb(const BatchDesc* __restrict__
   reduce_cb_body(reinterpret_cast<Status*>(d.st), d.part, d.nblk_u, d.pstride, (d.thr + 63) / 64 * 64, d.thr, k, d.coef, d.part2, d.nblk_u, sh);
 }
 template <int VEC>
-__global__ __launch_bounds__(TB) void kb_sweep_u2(const BatchDesc* __restrict__ descs, int k) {
+__global__ __launch_bounds__(TB) void kb_sweep_u2(const BatchDesc* __restrict__ descs, int k, int par) {
   const BatchDesc& d = descs[blockIdx.z];
   if ((int)blockIdx.x >= d.nblk_u) return;
-  sweep_u2_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, d.dg, d.gx, d.coef, d.thr, d.ld);
+  sweep_u2_body<VEC>(d.M, k, reinterpret_cast<const Status*>(d.st), d.U, d.upd, bd_gold(d, par), bd_gnew(d, par), d.coef, d.thr, d.ld);
 }
 // *all_done = 1 when every mesh's stop test has fired
 __global__ void kb_all_done(const BatchDesc* __restrict__ descs, int n, int off_done, int32_t* __restrict__ all_done) {
@@ -1624,7 +1644,7 @@ __global__ void kb_all_done(const BatchDesc* __restrict__ descs, int n, int off_
 }
 
 int psignn_f_tile_fused_batch(const BatchDesc* d_descs, int n_mesh, int n_slots, int max_rows, const float* W, int mixed,
-                              int off_done, int off_cur, int off_nxt, hipStream_t st);
+                              int off_done, int off_cur, int off_nxt, int par, hipStream_t st);
 
 // 1 when psignn_broyden_solve_batch takes these solvers together: tiled plans of ONE boundary-condition family and one size
 // class (the vector width / split layout / threshold / fold limits that broyden_alloc derives from the shard size) -- a host-side
@@ -1673,7 +1693,7 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
   int64_t Mtot4 = 0, bf_tot = 0;   // bytes of one state vector / of one fused f evaluation, summed over the shard (profiling records)
   for (int m = 0; m < n; ++m) {
     Mtot4 += sv[m]->M * 4;
-    bf_tot += (sv[m]->plan->mixed ? 102 : 89) * sv[m]->plan->N + 20 * sv[m]->plan->Ep + 16 * sv[m]->M;
+    bf_tot += (sv[m]->plan->mixed ? 102 : 89) * sv[m]->plan->N + 20 * sv[m]->plan->Ep + 8 * sv[m]->M;
   }
   // ---- per mesh: status, plan-order inputs, g0 = f(x0) - x0 (exactly the single-mesh prologue)
   std::vector<BatchDesc> hd(n);
@@ -1688,12 +1708,12 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
     if (p->mixed && (rc = psignn_plan_permute(p, nrm[m], 2, s->nrmp, 1, st))) return rc;
     const float* nrmp = p->mixed ? s->nrmp : nullptr;
     if ((rc = psignn_f_eval_p(p, W, nl, s->h0p, nullptr, 0, s->h0p, s->prbp, nrmp, s->fx, s->fwork, st))) return rc;
-    VPLAIN(s->vec, k_begin, ((unsigned)s->nblk, TB, 0, st), s->M, s->h0p, s->fx, s->xbuf, s->gx, s->upd);
+    VPLAIN(s->vec, k_begin, ((unsigned)s->nblk, TB, 0, st), s->M, s->h0p, s->fx, s->xbuf, s->gbuf[0], s->upd);
     BatchDesc& d = hd[m];
     d.M = s->M; d.ld = s->ld; d.nblk = s->nblk; d.npart = s->npart; d.nblk_ax = s->nblk_ax; d.jgroups = s->jgroups;
     d.thr = s->thr; d.seq_len = s->seq_len; d.keep_trace = s->keep_trace; d.n_tiles = (int)p->n_tiles; d.tile_base = base;
     d.st = reinterpret_cast<int32_t*>(s->st);
-    d.U = s->U; d.V = s->V; d.xbuf = s->xbuf; d.gx = s->gx; d.dg = s->dg; d.upd = s->upd; d.part = s->part; d.coef = s->coef;
+    d.U = s->U; d.V = s->V; d.xbuf = s->xbuf; d.g0 = s->gbuf[0]; d.g1 = s->gbuf[1]; d.upd = s->upd; d.part = s->part; d.coef = s->coef;
     d.nrm_part = s->nrm_part; d.jpart = s->jpart; d.rel_trace = s->rel_trace; d.abs_trace = s->abs_trace;
     d.ctx = p->d_ctx; d.h0p = s->h0p; d.prbp = s->prbp;
     d.part2 = s->part2; d.nblk_u = s->nblk_u; d.npart_u = s->npart_u;
@@ -1727,7 +1747,8 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
   int a_from_next = 0;
   for (int it = 0; it < thr; ++it) {
     PROF_BYTES(bf_tot);
-    rc = psignn_f_tile_fused_batch(d_descs, n, n_slots, max_rows, W, s0->plan->mixed, off_done, sel_off_cur(), sel_off_nxt(), st);
+    const int par = it & 1;
+    rc = psignn_f_tile_fused_batch(d_descs, n, n_slots, max_rows, W, s0->plan->mixed, off_done, sel_off_cur(), sel_off_nxt(), par, st);
     if (rc) { cleanup(); return rc; }
     const int k = it;
     const int kd = k >= thr ? 0 : k;
@@ -1743,7 +1764,7 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
       a_ready = false;
       const bool last = k + 1 >= thr;   // the stop test of iteration thr has fired: the sweeps below return at once
       PROF_BYTES(last ? 0 : (k + 4) * Mtot4);
-      VLAUNCH("k_sweep_v", st, s0->vec_u, kb_sweep_v, (gu, TB, 0, st), d_descs, k);
+      VLAUNCH("k_sweep_v", st, s0->vec_u, kb_sweep_v, (gu, TB, 0, st), d_descs, k, par);
       LAUNCH("k_reduce_cb", st, (kb_reduce_cb<<<dim3((unsigned)std::max(k, 1), 3, (unsigned)n), RB, 0, st>>>(d_descs, k)));
       const int keep0 = k <= s0->u2d_kmax ? 0 : k - s0->u2d_keep;
       if (s0->u2d_kmax > 0 && (k <= s0->u2d_kmax || s0->u2d_keep > 0) && k + 1 < thr) {
@@ -1751,35 +1772,35 @@ extern "C" int psignn_broyden_solve_batch(int n, psignn_broyden_t** sv, const fl
         const int nk = k - keep0;
         const dim3 g4((unsigned)max_g4, 1, (unsigned)n);
         if (s0->u2d_reg) {
-          if (nk <= 8) LAUNCH("k_sweep_u2d", st, (kb_sweep_u2r<8><<<g4, TB, 0, st>>>(d_descs, k, keep0)));
-          else if (nk <= 16) LAUNCH("k_sweep_u2d", st, (kb_sweep_u2r<16><<<g4, TB, 0, st>>>(d_descs, k, keep0)));
-          else LAUNCH("k_sweep_u2d", st, (kb_sweep_u2r<24><<<g4, TB, 0, st>>>(d_descs, k, keep0)));
+          if (nk <= 8) LAUNCH("k_sweep_u2d", st, (kb_sweep_u2r<8><<<g4, TB, 0, st>>>(d_descs, k, keep0, par)));
+          else if (nk <= 16) LAUNCH("k_sweep_u2d", st, (kb_sweep_u2r<16><<<g4, TB, 0, st>>>(d_descs, k, keep0, par)));
+          else LAUNCH("k_sweep_u2d", st, (kb_sweep_u2r<24><<<g4, TB, 0, st>>>(d_descs, k, keep0, par)));
         } else {
           const size_t lds = (size_t)std::max(nk, 1) * TB * 16;
-          LAUNCH("k_sweep_u2d", st, (kb_sweep_u2d<<<g4, TB, lds, st>>>(d_descs, k, keep0)));
+          LAUNCH("k_sweep_u2d", st, (kb_sweep_u2d<<<g4, TB, lds, st>>>(d_descs, k, keep0, par)));
         }
         a_ready = true;
         a_from_next = keep0;
       } else {
         PROF_BYTES(last ? 0 : (k + 5) * Mtot4);
-        VLAUNCH("k_sweep_u2", st, s0->vec_u, kb_sweep_u2, (gu, TB, 0, st), d_descs, k);
+        VLAUNCH("k_sweep_u2", st, s0->vec_u, kb_sweep_u2, (gu, TB, 0, st), d_descs, k, par);
       }
     } else {
     if (kd > 0) {
       PROF_BYTES((2 * kd + 3) * Mtot4);
-      VLAUNCH("k_dots", st, s0->vec, kb_dots, (dim3((unsigned)max_g, (unsigned)max_G, (unsigned)n), TB, 0, st), d_descs, kd);
+      VLAUNCH("k_dots", st, s0->vec, kb_dots, (dim3((unsigned)max_g, (unsigned)max_G, (unsigned)n), TB, 0, st), d_descs, kd, par);
     }
     LAUNCH("k_reduce_check", st, (kb_reduce_check<<<dim3((unsigned)std::max(kd, 1), 4, (unsigned)n), RB, 0, st>>>(d_descs, kd, eps)));
     if (own_width) {
       PROF_BYTES(k + 1 >= thr ? 0 : (2 * k + 6) * Mtot4);
-      VLAUNCH("k_axpy", st, s0->vec_ax, kb_axpy, (dim3((unsigned)max_ga, 1, (unsigned)n), TB, 0, st), d_descs, k, 1);
+      VLAUNCH("k_axpy", st, s0->vec_ax, kb_axpy, (dim3((unsigned)max_ga, 1, (unsigned)n), TB, 0, st), d_descs, k, 1, par);
       PROF_BYTES(k + 1 >= thr ? 0 : 4 * Mtot4);
       VLAUNCH("k_final", st, s0->vec_ax, kb_final, (dim3((unsigned)max_ga, 1, (unsigned)n), TB, 0, st), d_descs, k, 1);
     } else {
       PROF_BYTES(k + 1 >= thr ? 0 : (2 * k + 6) * Mtot4);
-      VLAUNCH("k_axpy", st, s0->vec, kb_axpy, (dim3((unsigned)max_g, (unsigned)max_G, (unsigned)n), TB, 0, st), d_descs, k, 0);
+      VLAUNCH("k_axpy", st, s0->vec, kb_axpy, (dim3((unsigned)max_g, (unsigned)max_G, (unsigned)n), TB, 0, st), d_descs, k, 0, par);
       if (max_G > 1 && k >= 4 * 2)   // some mesh may split from k = 4 * jgroups on (jgroups >= 2)
-        VLAUNCH("k_axpy_combine", st, s0->vec, kb_axpy_combine, (dim3((unsigned)max_g, 1, (unsigned)n), TB, 0, st), d_descs, k);
+        VLAUNCH("k_axpy_combine", st, s0->vec, kb_axpy_combine, (dim3((unsigned)max_g, 1, (unsigned)n), TB, 0, st), d_descs, k, par);
       PROF_BYTES(k + 1 >= thr ? 0 : 4 * Mtot4);
       VLAUNCH("k_final", st, s0->vec, kb_final, (dim3((unsigned)max_g, 1, (unsigned)n), TB, 0, st), d_descs, k, 0);
     }
@@ -1853,7 +1874,7 @@ extern "C" int psignn_broyden_solve_adjoint(psignn_broyden_t* s, const float* W,
   k_init_status<<<4, TB, 0, st>>>(s->st, s->rel_trace, s->abs_trace, s->thr, s->stop_abs);
   // y0 = 0, map(y0) = grad  ->  g0 = grad, update = grad  (solver.py:131-136 with f(0) = grad)
   HIP_TRY(hipMemsetAsync(s->h0p, 0, (size_t)s->M * 4, st));
-  VPLAIN(s->vec, k_begin, (g, TB, 0, st), s->M, s->h0p, grad, s->xbuf, s->gx, s->upd);
+  VPLAIN(s->vec, k_begin, (g, TB, 0, st), s->M, s->h0p, grad, s->xbuf, s->gbuf[0], s->upd);
   for (int it = 0; it < s->thr; ++it) {
     // x_next = x + update, kept also in h0p (fixed address for the VJP kernels)
     VLAUNCH("k_xnext", st, s->vec, k_xnext, (g, TB, 0, st), s->M, s->st, s->xbuf, s->upd, s->h0p);
@@ -1909,7 +1930,7 @@ extern "C" int psignn_broyden_ext_begin(psignn_broyden_t* s, const float* d_x0, 
   ARG_CHECK(s && d_x0 && d_fx0, "NULL argument");
   hipStream_t st = (hipStream_t)stream;
   k_init_status<<<4, TB, 0, st>>>(s->st, s->rel_trace, s->abs_trace, s->thr, s->stop_abs);
-  VPLAIN(s->vec, k_begin, ((unsigned)s->nblk, TB, 0, st), s->M, d_x0, d_fx0, s->xbuf, s->gx, s->upd);
+  VPLAIN(s->vec, k_begin, ((unsigned)s->nblk, TB, 0, st), s->M, d_x0, d_fx0, s->xbuf, s->gbuf[0], s->upd);
   s->ext_iter = 0;
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;

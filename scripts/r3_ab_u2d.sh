@@ -7,7 +7,7 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 ks={x['kernel']:x for x in d['kernels']}
 g=lambda n:((round(ks[n]['avg_us'],1), round(ks[n].get('frac_of_8TBps',0),3)) if n in ks else None)
-print('it/s', round(d['iters_per_sec'],1), 'ms/step', d['ms_per_step_all'], 'u2d', g('k_sweep_u2d'), 'v', g('k_sweep_v'), 'u1', g('k_sweep_u1'), 'f', g('f(k_f_tile_fused)'), 'red', g('k_reduce_check'), g('k_reduce_cb'))"; }
+print('it/s', round(d['iters_per_sec'],1), 'ms/step', d['ms_per_step_all'], 'u2d', g('k_sweep_u2d'), 'v', g('k_sweep_v'), 'u1', g('k_sweep_u1'), 'f', g('k_f_tile_fused'), 'red', g('k_reduce_check'), g('k_reduce_cb'))"; }
 for rep in 1 2; do
 for form in reg lds; do
   for K in 20 50; do
