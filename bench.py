@@ -35,7 +35,7 @@ One JSON line on stdout (rank 0).  Extra objects:
   roofline_f    the same for the GNN block f inside the loop (k_f_tile_fused: x + update, f, g, dg, norms in one kernel) --
                 the kernel north_star's 60 % target is about
   f_only        plain f (k_f_tile), 100 back-to-back evaluations: us per evaluation, edges/s, fraction of the HBM peak
-  roofline_jvp  the analytic JVP kernel of the Newton-Krylov path (k_jvp_tile), 50 back-to-back products
+  roofline_jvp  the JVP of the Newton-Krylov path (k_jvp_lin: stored linearisation), 50 back-to-back products; roofline_jvp_direct: k_jvp_tile
   newton_krylov one inner solve of that path: 30 Arnoldi steps of the device GMRES around the JVP
   roofline_iter whole-iteration algorithmic bytes (sum over every launch of the instrumented repeat) / un-instrumented wall time
   cpu_baseline  the CPU oracle (port of the reference path) timed on this box's host cores on a bounded sample
@@ -409,11 +409,26 @@ def main():
             b_jvp = b_f + 40 * N                                                    # + the tangent v (B_jvp)
             vp = torch.randn_like(xp)
             us_j = timed(lambda: fmap.jvp_p(xp, vp), 50)
-            result["roofline_jvp"] = {"kernel": "k_jvp_tile", "bound": "hbm", "achieved": b_jvp / us_j * 1e-3,
-                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_jvp / us_j * 1e-3 / HBM_PEAK_GBS,
-                                      "traffic": None, "avg_launch_us": us_j, "alg_bytes_per_launch": b_jvp,
-                                      "note": "analytic J_f(x) v of the Newton-Krylov path (BASELINE configs[4]); 50 back-to-back "
-                                              "products, HIP events on the launch stream (includes the host's launch overhead)"}
+            result["roofline_jvp_direct"] = {"kernel": "k_jvp_tile", "bound": "hbm", "achieved": b_jvp / us_j * 1e-3,
+                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_jvp / us_j * 1e-3 / HBM_PEAK_GBS,
+                                             "traffic": None, "avg_launch_us": us_j, "alg_bytes_per_launch": b_jvp,
+                                             "note": "J_f(x) v with the value path recomputed per product (any state, any plan); "
+                                                     "50 back-to-back products, HIP events on the launch stream"}
+            # what Newton-Krylov applies (csrc/fgnn_tile_lin.hip): masks and per-node quantities stored once per Newton step
+            # (psignn_lin_build), the product reads v, the 96-byte node record and one dword per slot (psignn_lin_jvp)
+            lin = fmap.linearize_p(xp)
+            b_lin = N * (81 + 96) + int(fmap.plan.ell_rows) * 64 * 4
+            b_build = 49 * N + 20 * Ep + N * 96 + int(fmap.plan.ell_rows) * 64 * 4
+            us_b = timed(lambda: fmap.linearize_p(xp, lin), 20)
+            us_l = timed(lambda: lin.jvp_p(vp), 50)
+            result["roofline_jvp"] = {"kernel": "k_jvp_lin", "bound": "hbm", "achieved": b_lin / us_l * 1e-3,
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_lin / us_l * 1e-3 / HBM_PEAK_GBS,
+                                      "traffic": None, "avg_launch_us": us_l, "alg_bytes_per_launch": b_lin,
+                                      "build_us": us_b, "build_alg_bytes": b_build, "build_frac": b_build / us_b * 1e-3 / HBM_PEAK_GBS,
+                                      "frac_by_survey_B_jvp": b_jvp / us_l * 1e-3 / HBM_PEAK_GBS,
+                                      "note": "J_f(x) v of the Newton-Krylov path (BASELINE configs[4]) from the stored "
+                                              "linearisation: one build per Newton step (build_us), then this product per "
+                                              "Krylov vector; 50 back-to-back products, HIP events on the launch stream"}
             # one inner solve of that path: m Arnoldi steps of the device GMRES (csrc/krylov.hip) on (J - I) dx = -g at this
             # iterate -- step j = one JVP + classical Gram-Schmidt against j + 1 basis vectors: one dots + one axpy sweep
             # (2 (j + 1) vectors), and the same again when the device's DGKS test asks for re-orthogonalisation
@@ -424,8 +439,9 @@ def main():
 
             def arnoldi():
                 gm.begin(neg_g)
+                fmap.linearize_p(xp, lin)
                 for j in range(m_nk):
-                    fmap.jvp_p(xp, gm.row(j, xp.shape), out=gm.row(j + 1, xp.shape))
+                    lin.jvp_p(gm.row(j, xp.shape), out=gm.row(j + 1, xp.shape))
                     gm.step(j, 1.0, 0.0, poll=False)
             us_nk = timed(arnoldi, 3)
             hist = gm.history()
@@ -433,7 +449,7 @@ def main():
             Mb = xp.numel() * 4
             # every step: JVP + first pass 2 (j + 1) + 3 vectors; the n_reorth steps that re-orthogonalised: 2 (j + 1) more.  Which
             # steps they were is not recorded: the bound below prices them as the LAST n_reorth steps (most bytes) and as the FIRST
-            lo = sum(b_jvp + (2 * (j + 1) + 3) * Mb for j in range(m_nk))
+            lo = b_build + sum(b_lin + (2 * (j + 1) + 3) * Mb for j in range(m_nk))
             extra = sorted(2 * (j + 1) * Mb for j in range(m_nk))
             nk_lo, nk_hi = lo + sum(extra[:n_reorth]), lo + sum(extra[m_nk - n_reorth:])
             result["newton_krylov"] = {"arnoldi_steps": m_nk, "reorthogonalised_steps": n_reorth, "us_per_inner_solve": us_nk,
@@ -441,10 +457,11 @@ def main():
                                        "achieved": nk_hi / us_nk * 1e-3, "unit": "GB/s", "frac": nk_hi / us_nk * 1e-3 / HBM_PEAK_GBS,
                                        "frac_lower": nk_lo / us_nk * 1e-3 / HBM_PEAK_GBS,
                                        "linear_residual_after_m": float(hist[-1]) if len(hist) else None,
-                                       "note": "device GMRES without restarts around the analytic JVP, Hessenberg / Givens on the "
+                                       "note": "one linearisation + device GMRES without restarts around its JVP, Hessenberg / Givens on the "
                                                "device, no host synchronisation inside the m steps; bytes priced with the number of "
                                                "steps whose second Gram-Schmidt pass ran (psignn_gmres_reorth_count)"}
             gm.close()
+            lin.close()
     for sv in solvers:
         sv.close()
 

@@ -139,6 +139,21 @@ int psignn_f_jvp(const psignn_plan_t* plan, const float* d_weights, int n_layers
                  const float* d_h, const float* d_prb, const float* d_normals,
                  const float* d_v, float* d_out, float* d_work, void* stream);
 
+/* Linearisation of f at a fixed state h, for Krylov solvers that apply J_f(h) to many vectors (Newton-Krylov, BASELINE config 5):
+ * psignn_lin_build evaluates the value path of f once and stores what the Jacobian needs (relu masks of every edge direction as
+ * wave-level bit masks, per-node gate / update / LayerNorm quantities); psignn_lin_jvp then applies J_f(h) as a linear operator,
+ * at about half the cost of psignn_f_jvp.  Tiled dirichlet plans, single-layer blocks; h, prb, v, out in PLAN order
+ * (psignn_plan_permute).  The handle keeps a pointer to the plan: destroy it before the plan.
+ * replaces: nothing executable in the reference (see psignn_f_jvp); same product as psignn_f_jvp up to fp32 summation order. */
+typedef struct psignn_lin psignn_lin_t;
+int psignn_lin_create(psignn_lin_t** out, const psignn_plan_t* plan);
+void psignn_lin_destroy(psignn_lin_t* lin);
+size_t psignn_lin_bytes(const psignn_lin_t* lin);
+int psignn_lin_build(psignn_lin_t* lin, const float* d_weights, int n_layers, const float* d_h_plan, const float* d_prb_plan,
+                     void* stream);
+int psignn_lin_jvp(const psignn_lin_t* lin, const float* d_weights, int n_layers, const float* d_v_plan, float* d_out_plan,
+                   void* stream);
+
 /* Vector-Jacobian product out = w^T (df/dh) at h (both families), as two gather passes over the plan's
  * CSR/CSC lists (no atomics).  d_normals: (N,2) for mixed plans, else NULL.
  * replaces: torch.autograd.grad(new_H_star, H_star, y) inside the implicit backward hook

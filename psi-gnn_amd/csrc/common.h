@@ -137,6 +137,7 @@ struct psignn_plan {
   // mixed plans: tiles without Neumann nodes first, then the (few, boundary) tiles with Neumann nodes -- the f kernel
   // runs the first group without the Phi_neumann columns in LDS (80-byte rows, one more workgroup per CU)
   int32_t* tile_order = nullptr;               // (n_tiles) tile ids
+  mutable int32_t* tile_order_cost = nullptr;  // experiment (PSIGNN_TILE_ORDER=cost, fgnn_tile.hip): per XCD run, costliest tiles first
   int64_t n_tiles_plain = 0;                   // tiles in the first group
   float cell_size = 0.f, xmin = 0.f, ymin = 0.f;
   int nx = 0, ny = 0;
@@ -198,3 +199,10 @@ struct BatchDesc {
   const float* nrmp;           // mixed family: unit normals in plan order (NULL for dirichlet plans)
   int64_t pstride;             // plane stride of the dot partials (solver.hip: part = 3 planes of (blocks, ldp))
 };
+
+// PSIGNN_TILE_LDS_MIN = lower limit in bytes of the dynamic LDS request of the dirichlet f / JVP launches (<= 65536): caps the
+// workgroups per CU (160 KB / request) without touching the code -- the occupancy sweeps of profiles/r3_f_model.txt.
+static inline size_t tile_lds_min() {
+  KNOB_INT(mn, [] { const char* e = getenv("PSIGNN_TILE_LDS_MIN"); return e ? atoi(e) : 0; }());
+  return (size_t)(mn < 0 ? 0 : (mn > 65536 ? 65536 : mn));
+}

@@ -747,6 +747,40 @@ __global__ void k_permute_rows(int64_t N, int cols, const int32_t* __restrict__ 
 // Grid of a tile-kernel launch over `chunk` tiles per XCD: one workgroup per tile, a multiple of 8.
 static unsigned tile_grid(int chunk) { return (unsigned)(chunk * 8); }
 
+// ---- experiments behind run-time knobs ("the bound of k_f_tile"; defaults leave the launch unchanged)
+// PSIGNN_TILE_ORDER = cost: inside each XCD's run of tiles, launch the tiles with the most work first (stage-1 rows + slot
+// rows), so that the launch ends on its shortest tiles.  Results are tile-order invariant (norm partials are stored per tile).
+static const int32_t* tile_cost_order(const psignn_plan* p, int chunk, hipStream_t st) {
+  KNOB_INT(mode, [] { const char* e = getenv("PSIGNN_TILE_ORDER"); return (int)(e && strcmp(e, "cost") == 0); }());
+  if (!mode || p->mixed) return nullptr;
+  if (p->tile_order_cost) return p->tile_order_cost;
+  const int64_t nt = p->n_tiles;
+  std::vector<int32_t> tptr(nt + 1), tsl(nt + 1), hc(nt), order(nt);
+  std::vector<uint8_t> deg(p->n_slices);
+  if (hipMemcpy(tptr.data(), p->tile_ptr, (nt + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(tsl.data(), p->tile_slice, (nt + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(hc.data(), p->halo_cnt, nt * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(deg.data(), p->slice_deg, p->n_slices, hipMemcpyDeviceToHost) != hipSuccess)
+    return nullptr;
+  std::vector<int64_t> cost(nt);
+  for (int64_t t = 0; t < nt; ++t) {
+    int dmax = 0;
+    for (int s = tsl[t]; s < tsl[t + 1]; ++s) dmax = std::max(dmax, (int)deg[s]);
+    cost[t] = (int64_t)(tptr[t + 1] - tptr[t] + hc[t]) + 16 * (int64_t)dmax;   // a slot row costs ~ 60 instructions, a staged row ~ 4 per lane
+  }
+  for (int64_t t = 0; t < nt; ++t) order[t] = (int32_t)t;
+  for (int x = 0; x < 8; ++x) {
+    const int64_t a = std::min<int64_t>(nt, (int64_t)x * chunk), b = std::min<int64_t>(nt, (int64_t)(x + 1) * chunk);
+    std::stable_sort(order.begin() + a, order.begin() + b, [&](int32_t u, int32_t v) { return cost[u] > cost[v]; });
+  }
+  int32_t* d = nullptr;
+  if (hipMalloc((void**)&d, nt * 4) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, order.data(), nt * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+  p->tile_order_cost = d;
+  (void)st;
+  return d;
+}
+
 static FuseArgs plain_args() {
   FuseArgs a{};
   a.stamps = g_tile_stamps;
@@ -806,7 +840,8 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
     }
   } else {
     using L = WLayout<2>;
-    size_t lds = (size_t)p->max_rows * TileRow<false>::RS * 4;
+    size_t lds = std::max((size_t)p->max_rows * TileRow<false>::RS * 4, tile_lds_min());
+    const int32_t* tlist = tile_cost_order(p, chunk, st);
     ARG_CHECK(nl == 1 || work, "multi-layer evaluation needs a workspace");
     float* pp[2] = {work, work ? work + p->N * D : nullptr};
     const float* cur = h;
@@ -814,11 +849,11 @@ int psignn_f_tile_forward(const psignn_plan* p, const float* W, int nl, const fl
       float* dst = (l == nl - 1) ? out : pp[l & 1];
       if (stage1_mfma(false, false))
         LAUNCH("k_f_tile", st, (k_f_tile<2, false, false, true><<<grid, TILE_THREADS, lds, st>>>(
-            plain_args(), (int)p->n_tiles, chunk, nullptr, TILE_ARGS, W, L::layer(l), L::tp_layer(nl, false, l), 0, l == nl - 1, cur,
+            plain_args(), (int)p->n_tiles, chunk, tlist, TILE_ARGS, W, L::layer(l), L::tp_layer(nl, false, l), 0, l == nl - 1, cur,
             l == 0 ? hsel : nullptr, hstride, h0, prb, nrm, dst)));
       else
         LAUNCH("k_f_tile", st, (k_f_tile<2, false, false, false><<<grid, TILE_THREADS, lds, st>>>(
-            plain_args(), (int)p->n_tiles, chunk, nullptr, TILE_ARGS, W, L::layer(l), L::tp_layer(nl, false, l), 0, l == nl - 1, cur,
+            plain_args(), (int)p->n_tiles, chunk, tlist, TILE_ARGS, W, L::layer(l), L::tp_layer(nl, false, l), 0, l == nl - 1, cur,
             l == 0 ? hsel : nullptr, hstride, h0, prb, nrm, dst)));
       cur = dst;
     }
@@ -851,14 +886,15 @@ int psignn_f_tile_fused(const psignn_plan* p, const float* W, int nl, float* xbu
     }
   } else {
     using L = WLayout<2>;
-    size_t lds = (size_t)p->max_rows * TileRow<false>::RS * 4;
+    size_t lds = std::max((size_t)p->max_rows * TileRow<false>::RS * 4, tile_lds_min());
+    const int32_t* tlist = tile_cost_order(p, chunk, st);
     if (stage1_mfma(true, false))
       LAUNCH("k_f_tile_fused", st, (k_f_tile<2, false, true, true><<<grid, TILE_THREADS, lds, st>>>(
-        fa, (int)p->n_tiles, chunk, nullptr, TILE_ARGS, W, L::layer(0), L::tp_layer(nl, false, 0), 0, 1, xbuf, nullptr, 0, h0, prb, nrm,
+        fa, (int)p->n_tiles, chunk, tlist, TILE_ARGS, W, L::layer(0), L::tp_layer(nl, false, 0), 0, 1, xbuf, nullptr, 0, h0, prb, nrm,
         nullptr)));
     else
       LAUNCH("k_f_tile_fused", st, (k_f_tile<2, false, true, false><<<grid, TILE_THREADS, lds, st>>>(
-        fa, (int)p->n_tiles, chunk, nullptr, TILE_ARGS, W, L::layer(0), L::tp_layer(nl, false, 0), 0, 1, xbuf, nullptr, 0, h0, prb, nrm,
+        fa, (int)p->n_tiles, chunk, tlist, TILE_ARGS, W, L::layer(0), L::tp_layer(nl, false, 0), 0, 1, xbuf, nullptr, 0, h0, prb, nrm,
         nullptr)));
   }
   HIP_TRY(hipGetLastError());

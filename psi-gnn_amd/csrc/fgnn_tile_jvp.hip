@@ -15,6 +15,7 @@
 #include "tile_helpers.h"
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #ifndef JVP_STAGE1_DEFAULT_MFMA
 #define JVP_STAGE1_DEFAULT_MFMA 0   // A/B at 1M nodes: 114 us (mfma) vs 100 us (valu)
 #endif
@@ -85,16 +86,13 @@ __device__ __forceinline__ float edge_pass_jvp(const uint4* __restrict__ slots, 
 #ifndef JVP_XRELOAD
 #define JVP_XRELOAD 1
 #endif
-#ifndef JVP_BOTH
-#define JVP_BOTH 1    // interior rows: both directions in ONE slot walk, clamp form of the relu / of its mask (A/B in DESIGN.md)
-#endif
 __device__ __forceinline__ v2f pk_mul_clamp(v2f a, v2f b) {   // clamp(a * b, 0, 1)
   v2f r;
   asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 // Both directions of the neighbour sums and of their tangents in one walk over the pair-merged slots (the f kernel's
-// edge_pass_both_clamp plus the tangent): the 160-byte LDS row [Pj_to | Pj_fr | dPj_to | dPj_fr] of the neighbour is read once.
+// edge_pass_both_clamp plus the tangent): the neighbour's LDS rows [Pj_to | Pj_fr] and [dPj_to | dPj_fr] (doff floats apart) are read once.
 // relu(z) = 2^40 clamp(2^-40 z) as there; the mask 1[z > 0] = clamp(2^126 * clamp(2^-40 z)) is a packed multiply instead of two
 // compares and two selects per pair (exact for |z| >= 2^-86; below that the f kernel's relu has already flushed the edge to 0
 // while this factor is a fraction -- a pre-activation that small does not occur on finite inputs of O(1) weights).
@@ -102,7 +100,8 @@ template <int RS>
 __device__ __forceinline__ void edge_pass_jvp_both(const uint4* __restrict__ slots, int nslots, const float* __restrict__ lds,
                                                    const float* __restrict__ AT_to, const float* __restrict__ AT_fr,
                                                    const v2f* Pi_to, const v2f* dPi_to, const v2f* Pi_fr, const v2f* dPi_fr,
-                                                   v2f* S_to, v2f* dS_to, v2f* S_fr, v2f* dS_fr, float& deg_in, float& deg_out) {
+                                                   v2f* S_to, v2f* dS_to, v2f* S_fr, v2f* dS_fr, float& deg_in, float& deg_out,
+                                                   const int doff) {
   v2f wt[15], wf[15], pt[5], pf[5];
 #pragma unroll
   for (int i = 0; i < 15; ++i) {
@@ -125,8 +124,9 @@ __device__ __forceinline__ void edge_pass_jvp_both(const uint4* __restrict__ slo
       const v2f a01 = (v2f){__uint_as_float(c0.y), __uint_as_float(c0.z)} * sc;
       const v2f a2 = (v2f){__uint_as_float(c0.w) * RELU_SCALE, 0.f};
       const float4* row = reinterpret_cast<const float4*>(lds + (int)(w & 0xFFFFu) * RS);
+      const float4* rowd = reinterpret_cast<const float4*>(lds + (int)(w & 0xFFFFu) * RS + doff);   // tangent row (see k_jvp_tile)
       if (w & SLOT_IN) {
-        const float4 v0 = row[0], v1 = row[1], v2 = row[2], v5 = row[5], v6 = row[6], v7 = row[7];
+        const float4 v0 = row[0], v1 = row[1], v2 = row[2], v5 = rowd[0], v6 = rowd[1], v7 = rowd[2];
         v2f z[5] = {(v2f){v0.x, v0.y}, (v2f){v0.z, v0.w}, (v2f){v1.x, v1.y}, (v2f){v1.z, v1.w}, (v2f){v2.x, v2.y}};
         const v2f d[5] = {(v2f){v5.x, v5.y}, (v2f){v5.z, v5.w}, (v2f){v6.x, v6.y}, (v2f){v6.z, v6.w}, (v2f){v7.x, v7.y}};
         deg_in += 1.f;
@@ -145,7 +145,7 @@ __device__ __forceinline__ void edge_pass_jvp_both(const uint4* __restrict__ slo
         }
       }
       if (w & SLOT_OUT) {
-        const float4 v2 = row[2], v3 = row[3], v4 = row[4], v7 = row[7], v8 = row[8], v9 = row[9];
+        const float4 v2 = row[2], v3 = row[3], v4 = row[4], v7 = rowd[2], v8 = rowd[3], v9 = rowd[4];
         v2f z[5] = {(v2f){v2.z, v2.w}, (v2f){v3.x, v3.y}, (v2f){v3.z, v3.w}, (v2f){v4.x, v4.y}, (v2f){v4.z, v4.w}};
         const v2f d[5] = {(v2f){v7.z, v7.w}, (v2f){v8.x, v8.y}, (v2f){v8.z, v8.w}, (v2f){v9.x, v9.y}, (v2f){v9.z, v9.w}};
         deg_out += 1.f;
@@ -186,7 +186,13 @@ __global__ __launch_bounds__(TILE_THREADS) JVP_OCC void k_jvp_tile(int n_tiles, 
                                                            const float* __restrict__ prb, const float* __restrict__ nrm,
                                                            const float* __restrict__ tv, float* __restrict__ out) {
   using L = WLayout<P>;
-  constexpr int RS = MIXED ? 60 : 40;   // [Pj_to | Pj_from | dPj_to | dPj_from (| Pj_neu | dPj_neu)]
+  // LDS rows.  Tiles with Neumann nodes: one 240-byte row [Pj_to | Pj_from | dPj_to | dPj_from | Pj_neu | dPj_neu] per staged node.
+  // All other tiles: TWO arrays of 80-byte rows, values [Pj_to | Pj_from] and, behind them, tangents [dPj_to | dPj_from].  A
+  // ds_read_b128 is served in groups of 16 lanes over 16 slots of 16 bytes: with 160-byte rows a row starts on an EVEN slot
+  // (10 r mod 16), neighbouring lanes' (mostly consecutive) rows share slots and 73 % of the LDS cycles of the launch were bank
+  // conflicts (SQ_LDS_BANK_CONFLICT 21.1 M of SQ_LDS_IDX_ACTIVE 29.0 M cycles, LDS pipe 47 % busy at 1M nodes); 80-byte rows start on
+  // 5 r mod 16 -- every slot, sixteen consecutive rows conflict-free -- as in k_f_tile.
+  constexpr int RS = MIXED ? 60 : 20;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int slot_ = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (slot_ >= n_tiles) return;
@@ -198,6 +204,7 @@ __global__ __launch_bounds__(TILE_THREADS) JVP_OCC void k_jvp_tile(int n_tiles, 
   const int n_h = halo_cnt[tile];
   const int32_t* hl = halo + (int64_t)tile * HALO_CAP;
   const float* T = W + tofs;
+  const int doff = MIXED ? 2 * D : (n_t + n_h) * RS;   // floats from a node's value row to its tangent row
   // ---- stage 1
   float x[D], dx[D];
   if constexpr (MFMA1) {
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(TILE_THREADS) JVP_OCC void k_jvp_tile(int n_tiles, 
           for (int sk = 0; sk < 3; ++sk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][sk], xb[sk], acc, 0, 0, 0);
           const int o0 = 16 * mt + 4 * g;
           if (ok && o0 < 2 * D)
-            *reinterpret_cast<float4*>(lds + row * RS + 2 * D * src + o0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4*>(lds + row * RS + (src ? doff : 0) + o0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
       }
     }
@@ -273,11 +280,12 @@ __global__ __launch_bounds__(TILE_THREADS) JVP_OCC void k_jvp_tile(int n_tiles, 
     q[2] = make_float4(ta[4].x, ta[4].y, tb[0].x, tb[0].y);
     q[3] = make_float4(tb[1].x, tb[1].y, tb[2].x, tb[2].y);
     q[4] = make_float4(tb[3].x, tb[3].y, tb[4].x, tb[4].y);
-    q[5] = make_float4(da[0].x, da[0].y, da[1].x, da[1].y);
-    q[6] = make_float4(da[2].x, da[2].y, da[3].x, da[3].y);
-    q[7] = make_float4(da[4].x, da[4].y, db[0].x, db[0].y);
-    q[8] = make_float4(db[1].x, db[1].y, db[2].x, db[2].y);
-    q[9] = make_float4(db[3].x, db[3].y, db[4].x, db[4].y);
+    float4* qd = reinterpret_cast<float4*>(lds + row * RS + doff);
+    qd[0] = make_float4(da[0].x, da[0].y, da[1].x, da[1].y);
+    qd[1] = make_float4(da[2].x, da[2].y, da[3].x, da[3].y);
+    qd[2] = make_float4(da[4].x, da[4].y, db[0].x, db[0].y);
+    qd[3] = make_float4(db[1].x, db[1].y, db[2].x, db[2].y);
+    qd[4] = make_float4(db[3].x, db[3].y, db[4].x, db[4].y);
     if (MIXED) {   // Phi_neumann columns of the state and the tangent row
 #pragma unroll
       for (int p = 0; p < 5; ++p) ta[p] = da[p] = splat(0.f);
@@ -362,7 +370,6 @@ __global__ __launch_bounds__(TILE_THREADS) JVP_OCC void k_jvp_tile(int n_tiles, 
   float deg_in, deg_out;
 #pragma unroll
   for (int p = 0; p < 5; ++p) S_to[p] = S_fr[p] = dS_to[p] = dS_fr[p] = splat(0.f);
-#if JVP_BOTH
   {
     v2f Pi[5], dPi[5], Pi2[5], dPi2[5];
     ld5(T + L::T_B1_TO, Pi);
@@ -376,31 +383,12 @@ __global__ __launch_bounds__(TILE_THREADS) JVP_OCC void k_jvp_tile(int n_tiles, 
     mv2<D>(T + L::T_W1I_FR, x, Pi2);
     mv2<D>(T + L::T_W1I_FR, dx, dPi2);
     edge_pass_jvp_both<RS>(slots, nslots, lds, T + L::T_A_TO, T + L::T_A_FR, Pi, dPi, Pi2, dPi2, S_to, dS_to, S_fr, dS_fr, deg_in,
-                           deg_out);
+                           deg_out, doff);
   }
 #if JVP_XRELOAD
   PHASE();   // x / dx are not needed during the walk: re-read them (L2 hits) instead of holding 20 VGPRs across it
   load10(h + n * D, x);
   load10(tv + n * D, dx);
-#endif
-#else
-  {
-  v2f Pi[5], dPi[5];
-  ld5(T + L::T_B1_TO, Pi);
-#pragma unroll
-  for (int p = 0; p < 5; ++p) dPi[p] = splat(0.f);
-  PHASE();
-  mv2<D>(T + L::T_W1I_TO, x, Pi);
-  mv2<D>(T + L::T_W1I_TO, dx, dPi);
-  deg_in = edge_pass_jvp<RS, 0, 2 * D, SLOT_IN>(slots, nslots, lds, T + L::T_A_TO, Pi, dPi, S_to, dS_to);
-  ld5(T + L::T_B1_FR, Pi);
-#pragma unroll
-  for (int p = 0; p < 5; ++p) dPi[p] = splat(0.f);
-  PHASE();
-  mv2<D>(T + L::T_W1I_FR, x, Pi);
-  mv2<D>(T + L::T_W1I_FR, dx, dPi);
-  deg_out = edge_pass_jvp<RS, D, 3 * D, SLOT_OUT>(slots, nslots, lds, T + L::T_A_FR, Pi, dPi, S_fr, dS_fr);
-  }
 #endif
   // ---- gate and update MLP (second Phi layer folded), values and tangents
   const float* Wf = W + lofs + L::L_FOLD;
@@ -520,7 +508,7 @@ int psignn_f_tile_jvp(const psignn_plan* p, const float* W, int nl, const float*
   }
   using L = WLayout<2>;
   const int chunk = (int)cdiv(p->n_tiles, 8);
-  const size_t lds = (size_t)p->max_rows * 40 * 4;
+  const size_t lds = std::max((size_t)p->max_rows * 40 * 4, tile_lds_min());
   ARG_CHECK(lds <= 160 * 1024, "tile + halo rows exceed the LDS budget of the tiled JVP");
   // stage-1 form: PSIGNN_JVP_STAGE1 = mfma | valu (default: see the A/B in DESIGN.md)
   KNOB_INT(use_mfma, [] {

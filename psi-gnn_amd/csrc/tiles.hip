@@ -336,11 +336,11 @@ int psignn_exclusive_scan(const int32_t* in, int64_t n, int32_t* out, int32_t* b
 
 void psignn_tiles_free(psignn_plan* p) {
   void* ptrs[] = {p->perm, p->inv, p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt,
-                  p->slice_off, p->slice_deg, p->ell, p->flags_p, p->tile_order, p->d_ctx};
+                  p->slice_off, p->slice_deg, p->ell, p->flags_p, p->tile_order, p->d_ctx, p->tile_order_cost};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   p->perm = p->inv = p->tile_ptr = p->tile_slice = p->halo = p->halo_cnt = p->slice_off = nullptr;
-  p->slice_deg = nullptr; p->ell = nullptr; p->flags_p = nullptr; p->tile_order = nullptr; p->d_ctx = nullptr;
+  p->slice_deg = nullptr; p->ell = nullptr; p->flags_p = nullptr; p->tile_order = nullptr; p->d_ctx = nullptr; p->tile_order_cost = nullptr;
   p->tiled = 0;
 }
 

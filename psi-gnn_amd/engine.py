@@ -352,6 +352,22 @@ class FixedPointMap:
                                                nat.stream_ptr(Hc.device)), "psignn_f_jvp_p")
         return out
 
+    def can_linearize(self):
+        """True when ``linearize_p`` applies: tiled dirichlet plan, single-layer block (csrc/fgnn_tile_lin.hip)."""
+        return bool(self.plan.tiled) and not self.plan.mixed and self.weights.n_layers == 1
+
+    def linearize_p(self, Hp, lin=None):
+        """Linearisation of f at ``Hp`` (plan order) for solvers that apply J_f(Hp) to many vectors: one pass stores the relu
+        masks and per-node gate / update / LayerNorm quantities, ``lin.jvp_p(Vp)`` then applies the Jacobian as a linear
+        operator (about half the cost of ``jvp_p``, same product up to fp32 summation order).  ``lin``: a Linearization of this
+        map to rebuild at the new state (keeps its device buffers)."""
+        if self._p is None:
+            self.fp(Hp)
+        if lin is None:
+            lin = Linearization(self)
+        lin.build(Hp)
+        return lin
+
     def vjp(self, H, Wv):
         """Wv^T J_f(H): what ``autograd.grad(f(H), H, Wv)`` returns in the reference (model.py:214,432,449)."""
         Hc, Wc = _f32c(H), _f32c(Wv)
@@ -800,6 +816,53 @@ def residual(plan: MeshPlan, u, y):
 # device Broyden
 # ---------------------------------------------------------------------------------------------
 TRACE_BUDGET_BYTES = 8 << 30  # keep every iterate only while (thr+2)*N*d*4 stays under this
+
+
+class Linearization:
+    """Stored linearisation of a FixedPointMap at one state (psignn_lin_* in include/psignn_hip.h)."""
+
+    def __init__(self, fmap):
+        if not fmap.can_linearize():
+            raise nat.NativeError("linearize_p: tiled dirichlet plans with a single-layer block (use jvp_p otherwise)")
+        self.fmap = fmap
+        h = C.c_void_p()
+        with torch.cuda.device(fmap.weights.flat.device):
+            nat.check(nat.lib().psignn_lin_create(C.byref(h), fmap.plan.handle), "psignn_lin_create")
+        self.handle = h
+        self.bytes = int(nat.lib().psignn_lin_bytes(h))
+
+    def build(self, Hp):
+        fm = self.fmap
+        _, prbp, _ = fm._p
+        Hc = _f32c(Hp)
+        with torch.cuda.device(Hc.device):
+            nat.check(nat.lib().psignn_lin_build(self.handle, nat.ptr(fm.weights.flat), fm.weights.n_layers, nat.ptr(Hc),
+                                                 nat.ptr(prbp), nat.stream_ptr(Hc.device)), "psignn_lin_build")
+        return self
+
+    def jvp_p(self, Vp, out=None):
+        """J_f(H) Vp for the H of the last ``build`` (plan order); ``out`` as in FixedPointMap.jvp_p."""
+        fm = self.fmap
+        Vc = _f32c(Vp)
+        if out is None:
+            out = torch.empty_like(Vc)
+        elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != Vc.numel():
+            raise nat.NativeError("jvp_p: out must be a contiguous float32 tensor of the state's size")
+        with torch.cuda.device(Vc.device):
+            nat.check(nat.lib().psignn_lin_jvp(self.handle, nat.ptr(fm.weights.flat), fm.weights.n_layers, nat.ptr(Vc),
+                                               nat.ptr(out), nat.stream_ptr(Vc.device)), "psignn_lin_jvp")
+        return out
+
+    def close(self):
+        if self.handle is not None:
+            nat.lib().psignn_lin_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DeviceBroyden:

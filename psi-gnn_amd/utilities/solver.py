@@ -13,6 +13,8 @@ only polls a done flag; for any other callable the low-rank machinery is still n
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import _native as nat
@@ -256,6 +258,9 @@ def newton_krylov(f, x0, threshold=30, eps=1e-5, inner_m=200, inner_tol=1e-2, ma
         x = f.to_plan(x0.to(torch.float32).contiguous())
     M = x.numel()
     gm = DeviceGmres(M, x.device, inner_m)
+    # PSIGNN_NK_LIN=0 keeps the direct JVP kernel (A/B runs, tests)
+    use_lin = os.environ.get("PSIGNN_NK_LIN", "1") != "0" and hasattr(f, "can_linearize") and f.can_linearize()
+    lin = None
     neg_g = torch.empty_like(x)
     xt = torch.empty_like(x)
     trace = {"abs": [], "rel": []}
@@ -274,8 +279,13 @@ def newton_krylov(f, x0, threshold=30, eps=1e-5, inner_m=200, inner_tol=1e-2, ma
                 break
             gm.begin(neg_g)
             k = 0
+            if use_lin:   # J_f(x) is applied to every Krylov vector of this step: linearise once (engine.Linearization)
+                lin = f.linearize_p(x, lin)
             for j in range(inner_m):
-                f.jvp_p(x, gm.row(j, x.shape), out=gm.row(j + 1, x.shape))
+                if use_lin:
+                    lin.jvp_p(gm.row(j, x.shape), out=gm.row(j + 1, x.shape))
+                else:
+                    f.jvp_p(x, gm.row(j, x.shape), out=gm.row(j + 1, x.shape))
                 n_feval += 1
                 k = j + 1
                 if gm.step(j, 1.0, inner_tol, poll=(k % poll_every == 0 or k == inner_m)):
@@ -331,6 +341,8 @@ def newton_krylov(f, x0, threshold=30, eps=1e-5, inner_m=200, inner_tol=1e-2, ma
             if rel < lowest:
                 lowest, lowest_x, lowest_step = rel, x, nstep
     gm.close()
+    if lin is not None:
+        lin.close()
     back = f.from_plan
     return {"result": back(lowest_x).reshape(shape), "lowest": lowest, "nstep": lowest_step, "prot_break": False,
             "abs_trace": trace["abs"], "rel_trace": trace["rel"], "xest_trace": [back(t).reshape(shape) for t in xest_trace],

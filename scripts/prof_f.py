@@ -41,7 +41,9 @@ if len(sys.argv) > 5 and sys.argv[5] == "adjoint":
     H = fm.from_plan(x)
     V = torch.randn_like(H)
     Vp = fm.to_plan(V)
-    for name, fn in (("jvp", lambda: fm.jvp(H, V)), ("vjp", lambda: fm.vjp(H, V)), ("f (caller order)", lambda: fm(H)),
+    lin = fm.linearize_p(x) if fm.can_linearize() else None
+    extra = ((("lin build (plan order)", lambda: fm.linearize_p(x, lin)), ("lin jvp (plan order)", lambda: lin.jvp_p(Vp))) if lin else ())
+    for name, fn in extra + (("jvp", lambda: fm.jvp(H, V)), ("vjp", lambda: fm.vjp(H, V)), ("f (caller order)", lambda: fm(H)),
                      ("vjp_p (plan order)", lambda: fm.vjp_p(x, Vp)), ("jvp_p (plan order)", lambda: fm.jvp_p(x, Vp))):
         fn(); torch.cuda.synchronize()
         t0.record()

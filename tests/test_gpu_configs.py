@@ -432,3 +432,48 @@ def test_newton_krylov_at_100k_nodes(dev):
     assert np.isfinite(out["lowest"]) and out["lowest"] <= ob["lowest"] * (1 + 1e-6)
     assert all(b <= a for a, b in zip(out["abs_trace"], out["abs_trace"][1:]))
     assert out["n_feval"] >= 60 and out["result"].shape == fm.h0.shape and bool(torch.isfinite(out["result"]).all())
+
+
+def test_linearised_jvp_on_many_tiles_and_in_newton_krylov(dev, monkeypatch):
+    """csrc/fgnn_tile_lin.hip on a 100k-node mesh (391 tiles with halos, ragged last tile): the stored linearisation applies the
+    same Jacobian as the direct tile kernel at a state well inside the solve, and Newton-Krylov driven by it reaches the same
+    iterates as with the direct kernel (PSIGNN_NK_LIN=0) on a 5k-node mesh."""
+    data, solver = pkg("data"), pkg("utilities.solver")
+    sd = load_weights("dirichlet")
+    mesh = data.make_hex_problem(data.hex_n_for_nodes(100000), seed=2, compute_sol=False)
+    md, h0, plan, fm = _fmap(mesh, sd, dev)
+    assert plan.n_tiles > 300 and fm.can_linearize()
+    x = fm.to_plan(fm.h0)
+    for _ in range(12):
+        x = fm.fp(x)
+    gen = torch.Generator().manual_seed(5)
+    V = fm.to_plan(torch.randn(h0.shape, generator=gen).to(dev))
+    lin = fm.linearize_p(x)
+    a, b = lin.jvp_p(V), fm.jvp_p(x, V)
+    assert rel_l2(a, b) < 2e-6, rel_l2(a, b)
+    assert float((a - b).abs().max()) < 1e-5 * float(b.abs().max())
+    lin.close()
+    # Newton-Krylov on a mesh inside the range where it converges (20 tiles): the first outer steps follow each other closely
+    # (same Newton systems up to rounding), the final residuals are of one order
+    mesh = data.make_hex_problem(data.hex_n_for_nodes(5000), seed=2, compute_sol=False)
+    md, h0, plan, fm = _fmap(mesh, sd, dev)
+    assert fm.can_linearize()
+    outs, calls = {}, {"1": 0, "0": 0}
+    eng = pkg("engine")
+    orig = eng.Linearization.jvp_p
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PSIGNN_NK_LIN", mode)
+
+        def counted(self, Vp, out=None, _m=mode):
+            calls[_m] += 1
+            return orig(self, Vp, out=out)
+        monkeypatch.setattr(eng.Linearization, "jvp_p", counted)
+        outs[mode] = solver.newton_krylov(fm, fm.h0, threshold=8, eps=1e-6, inner_m=40)
+    monkeypatch.delenv("PSIGNN_NK_LIN")
+    monkeypatch.setattr(eng.Linearization, "jvp_p", orig)
+    assert calls["1"] >= sum(outs["1"]["n_krylov"]) > 0 and calls["0"] == 0   # the stored linearisation is what the default run applied
+    a, b = outs["1"], outs["0"]
+    print("NK lin / direct:", a["rel_trace"], b["rel_trace"], a["n_krylov"], b["n_krylov"])
+    np.testing.assert_allclose(a["rel_trace"][:2], b["rel_trace"][:2], rtol=2e-2)
+    assert a["n_krylov"][0] == b["n_krylov"][0]
+    assert 0.3 < a["lowest"] / b["lowest"] < 3.0 and a["lowest"] < 0.1 * a["rel_trace"][0]

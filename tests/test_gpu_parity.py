@@ -237,6 +237,44 @@ def test_jvp_parity(name, form, dev, knobs):
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(rhs))
 
 
+@pytest.mark.parametrize("name", ["original_dirichlet_s0", "hex13_dirichlet_s0", "hex26_dirichlet_s0"])
+def test_linearised_jvp_parity(name, dev):
+    """Stored linearisation (csrc/fgnn_tile_lin.hip: relu masks and per-node quantities computed once at h, J_f(h) applied as a
+    linear operator): against float64 autograd like the direct kernel, against the direct kernel itself, exact linearity, and
+    a rebuild at another state replaces the operator."""
+    if name not in CASES:
+        pytest.skip("fixture not in this build")
+    g, mesh, md, sd, fmap = bind(name, dev)
+    if "jv_point" not in g:
+        pytest.skip("fixture has no JVP vectors")
+    assert fmap.can_linearize()
+    hp = torch.from_numpy(g["jv_point"]).float().to(dev)
+    v = torch.from_numpy(g["jv_dir"]).float().to(dev)
+    Hp, Vp = fmap.to_plan(hp), fmap.to_plan(v)
+    lin = fmap.linearize_p(Hp)
+    jv = fmap.from_plan(lin.jvp_p(Vp))
+    assert rel_l2(jv, g["jvp64"]) < 1e-5, rel_l2(jv, g["jvp64"])
+    assert rel_l2(jv, fmap.jvp(hp, v)) < 2e-6
+    # a linear operator: J (a v + b w) == a J v + b J w up to rounding of the sums
+    w = torch.roll(Vp, 7, 0).contiguous()
+    comb = lin.jvp_p(1.5 * Vp - 0.25 * w)
+    assert rel_l2(comb, 1.5 * lin.jvp_p(Vp) - 0.25 * lin.jvp_p(w)) < 2e-6
+    # rebuild in place at another state: same handle, the other state's Jacobian
+    H2 = fmap.fp(Hp)
+    lin2 = fmap.linearize_p(H2, lin)
+    assert lin2 is lin
+    assert rel_l2(fmap.from_plan(lin.jvp_p(Vp)), fmap.jvp(fmap.from_plan(H2), v)) < 2e-6
+    out = torch.empty_like(Vp)
+    assert lin.jvp_p(Vp, out=out) is out
+    lin.close()
+    mixed = [n for n in CASES if "mixed" in n]
+    if mixed:
+        gm_, mesh_m, md_m, sd_m, fmap_m = bind(mixed[0], dev)
+        assert not fmap_m.can_linearize()
+        with pytest.raises(pkg("_native").NativeError):
+            fmap_m.linearize_p(fmap_m.to_plan(fmap_m.h0))
+
+
 # ------------------------------------------------------------------------------------------ Broyden
 @pytest.mark.parametrize("name", list(CASES))
 def test_device_broyden_reference_operating_point(name, dev):
