@@ -127,7 +127,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_lin_build(int n_tiles, int chu
   const int lane = tid & 63;
   const int64_t n = (int64_t)t0 + tid;
   if (C.flags_p[n] & FLAG_DIRICHLET) return;   // (the product kernel writes zeros for such a row without looking at its slots)
-  const int slice = (tn ? tile * (tn >> 6) : C.tile_slice[tile]) + (tid >> 6);
+  const int slice = __builtin_amdgcn_readfirstlane((tn ? tile * (tn >> 6) : C.tile_slice[tile]) + (tid >> 6));
   const int srow0 = C.slice_off[slice];
   const int nslots = C.slice_deg[slice];
   const uint4* slots = C.ell + (int64_t)srow0 * 64 + lane;
@@ -329,14 +329,19 @@ __global__ __launch_bounds__(TILE_THREADS) LIN_OCC void k_jvp_lin(int n_tiles, i
     return;
   }
   const int lane = tid & 63;
-  const int slice = (tn ? tile * (tn >> 6) : C.tile_slice[tile]) + (tid >> 6);
+  // (wave-uniform by construction; said so to the compiler: scalar loads, scalar branches in the walk)
+  const int slice = __builtin_amdgcn_readfirstlane((tn ? tile * (tn >> 6) : C.tile_slice[tile]) + (tid >> 6));
   const int srow0 = C.slice_off[slice];
   const int nslots = C.slice_deg[slice];
   const uint32_t* si = slot + (int64_t)srow0 * 64 + lane;
   // all slot dwords of the node are requested at once (clamped index: unconditional loads), ahead of the own-side projections
   uint32_t sw[LIN_CHUNK];
 #pragma unroll
-  for (int i = 0; i < LIN_CHUNK; ++i) sw[i] = nslots > 0 ? si[(int64_t)min(i, nslots - 1) * 64] : 0u;
+  for (int i = 0; i < LIN_CHUNK; ++i) sw[i] = 0u;
+  if (nslots > 0) {
+#pragma unroll
+    for (int i = 0; i < LIN_CHUNK; ++i) sw[i] = si[(int64_t)min(i, nslots - 1) * 64];
+  }
   const float4* rp = reinterpret_cast<const float4*>(rec + n * LIN_REC);
 #if LIN_REC_EARLY
   const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5];   // requested ahead of the walk
