@@ -11,6 +11,13 @@
 //            bitwise reproducible), then gate / update MLP / LayerNorm / boundary rows.
 // The second Phi layer (W2 S + deg b2) is linear and is folded into the consumers' first-layer weights on
 // the host (WLayout fold block).  All node tensors are in PLAN order; the solver keeps its state there.
+// weight loads of mv2 pinned chunk by chunk (tile_helpers.h; A/B in profiles/r3_ab_mv2.txt: fused step 75.8 -> 73.4 us, plain f unchanged)
+#ifndef MV2_LAUNDER
+#define MV2_LAUNDER 2
+#endif
+#ifndef MV2_CH
+#define MV2_CH 10
+#endif
 #include "tile_helpers.h"
 #ifndef TILE_WPE
 #define TILE_WPE 0    // > 0: __attribute__((amdgpu_waves_per_eu(TILE_WPE, TILE_WPE))) on k_f_tile: the register allocator is held to 96 VGPRs (5 waves per SIMD)

@@ -17,6 +17,10 @@
 // Against k_jvp_tile at 1M nodes: ~0.4 x the VALU instructions per wave, 80-byte LDS rows (tangent projections only: six
 // workgroups per CU instead of three), about the same bytes (the 96-byte node record replaces the h row, the 16-byte slot records
 // shrink to 4 bytes).  Dirichlet plans with a single-layer block; other plans keep k_jvp_tile (psignn_lin_create refuses them).
+// weight loads of mv2 pinned chunk by chunk (tile_helpers.h; A/B in profiles/r3_ab_mv2.txt: k_jvp_lin 53 -> 48.5 us)
+#ifndef MV2_LAUNDER
+#define MV2_LAUNDER 2
+#endif
 #include "tile_helpers.h"
 #include <stdlib.h>
 #include <string.h>

@@ -37,12 +37,43 @@ __device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
 #ifndef MV2_CH
 #define MV2_CH 5
 #endif
+// MV2_LAUNDER (round 3): the barrier alone does not hold the loads back -- the weights sit behind a `const __restrict__` kernel
+// argument, their loads are invariant for the optimiser and were still hoisted over it: the fused f step and k_jvp_lin carried
+// 220 / 204 v_writelane / v_readlane per wave (a sixth of their VALU instructions) for parked weights.  Adding an
+// offset that went through an empty asm (always 0) to the block's pointer per chunk makes the chunk's loads data-dependent on
+// that statement: they cannot move above it.  (Laundering the pointer itself loses its no-alias property: vector loads, 256 VGPRs.)
+#ifndef MV2_LAUNDER
+#define MV2_LAUNDER 0   // 0: barrier only; 1: offset re-made per chunk; 2: ... by a statement that also waits for the chunk before.  Chosen per
+                        // file (fgnn_tile.hip, fgnn_tile_lin.hip: 2); which form leaves fewest parked SGPRs differs from kernel to kernel
+#endif
 template <int K>
-__device__ __forceinline__ void mv2(const float* __restrict__ WT, const float* x, v2f* acc) {
+__device__ __forceinline__ void mv2(const float* __restrict__ WT, const float* x, v2f* acc, const float after = 0.f) {
   const v2f* w = reinterpret_cast<const v2f*>(WT);
+#if MV2_LAUNDER
+  // An offset the optimiser cannot see through (always 0; the POINTER stays derived from the restrict argument: scalar loads),
+  // re-made per chunk by a statement that also consumes the accumulators of the chunk before -- the chunk's loads can neither be
+  // hoisted over it nor can the statement itself float above the arithmetic it waits for.  `after`: a value of the caller's that
+  // the first chunk has to wait for (e.g. the last output of an independent product issued just before).
+  int zero = 0;
+#if MV2_LAUNDER == 2
+  asm volatile("" : "+s"(zero) : "v"(acc[0]), "v"(acc[4]), "v"(after));
+#else
+  asm volatile("" : "+s"(zero));
+#endif
+  w += zero;
+#endif
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    if (MV2_CH > 0 && k > 0 && k % MV2_CH == 0) PHASE();
+    if (MV2_CH > 0 && k > 0 && k % MV2_CH == 0) {
+      PHASE();
+#if MV2_LAUNDER == 2
+      asm volatile("" : "+s"(zero) : "v"(acc[0]), "v"(acc[4]));
+      w += zero;
+#elif MV2_LAUNDER
+      asm volatile("" : "+s"(zero));
+      w += zero;
+#endif
+    }
     const v2f xs = splat(x[k]);
 #pragma unroll
     for (int p = 0; p < 5; ++p) acc[p] = __builtin_elementwise_fma(w[k * 5 + p], xs, acc[p]);
