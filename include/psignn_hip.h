@@ -180,8 +180,9 @@ int psignn_f_vjp_p(const psignn_plan_t* plan, const float* d_weights, int n_laye
  * derived (fold) slots stay zero.  d_work: psignn_f_param_vjp_workspace_floats(plan) floats. */
 int64_t psignn_param_grad_size(int mixed, int n_layers);
 int64_t psignn_f_param_vjp_workspace_floats(const psignn_plan_t* plan);
-/* the same in the caller's numbering and for every single-layer plan: mixed family (d_normals required) and untiled
- * plans run global-gather kernels; d_grad then also covers phi_neumann{W1,b1,W2,b2} | update_neumann{N1,nb1,N2,nb2}. */
+/* the same in the caller's numbering and for every single-layer plan: tiled plans of both families run the tile kernels in
+ * record mode (mixed family: d_normals required; d_grad then also covers phi_neumann{W1,b1,W2,b2} |
+ * update_neumann{N1,nb1,N2,nb2}; mixed/psignn/model.py:216-245 under loss.backward()), untiled plans the global-gather kernels. */
 int psignn_f_param_vjp(const psignn_plan_t* plan, const float* d_weights, int n_layers, const float* d_h,
                        const float* d_prb, const float* d_normals, const float* d_w, float* d_grad, float* d_out_h,
                        float* d_work, void* stream);

@@ -14,13 +14,15 @@
 //   3. k_pgrad_reduce: sum of the per-block partial tiles (fp64) and scatter into the flat gradient, laid out like
 //      the base section of the packed weights (WLayout: shared | phi_to | phi_from | update).
 #include "fgnn_common.h"
+#include <stdlib.h>
+#include <string.h>
 
 #define PGREC 320
 #define PG_TILES 16
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-int psignn_f_tile_vjp_rec(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* w,
-                          float* out, float* work, float* rec, hipStream_t st);
+int psignn_f_tile_vjp_rec(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* nrm,
+                          const float* w, float* out, float* work, float* rec, hipStream_t st);
 
 // Record tables: accumulator tile t = (A group, B group) of the record; A group -1 = the constant row (column sums).
 struct TabF {  // f_theta: 20 groups (layout in k_vjp_tile_a), 16 tiles
@@ -224,12 +226,38 @@ extern "C" int64_t psignn_f_param_vjp_workspace_floats(const psignn_plan_t* p) {
   if (!p) return 0;
   int npw;
   const int nblk = pgrad_blocks(p->N, &npw);
-  // VJP scratch (<= N * 90) + plan-order copies (<= N * 32) + records (N * 480 mixed) + partial tiles (per wave for mixed)
-  return p->N * (9 * D + 32 + TabX::NG * 16) + (int64_t)nblk * 4 * TabX::NT * 256;
+  // VJP scratch (<= N * 90) + plan-order copies (<= N * 36) + records (N * 480 mixed) + partial tiles (per wave for mixed)
+  return p->N * (9 * D + 36 + TabX::NG * 16) + (int64_t)nblk * 4 * TabX::NT * 256;
 }
 
 extern "C" int64_t psignn_param_grad_size(int mixed, int nl) {
   return mixed ? WLayout<3>::base_total(nl, true) : WLayout<2>::base_total(nl, false);
+}
+
+// Tiled plans of both families, everything in PLAN order: the tiled VJP kernels in record mode, then the MFMA reduction of the
+// records (dirichlet: 20 groups, 16 tiles; mixed: 30 groups, 24 tiles -- the Neumann factors of fgnn_vjp.hip's PgRec).
+static int param_vjp_tiled(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* nrm,
+                           const float* w, float* d_grad, float* d_out_h, float* work, hipStream_t st) {
+  const int64_t N = p->N;
+  float* B = work;
+  float* rec = B + N * 4 * D;
+  int npw;
+  const int nblk = pgrad_blocks(N, &npw);
+  int rc = psignn_f_tile_vjp_rec(p, W, nl, h, prb, nrm, w, d_out_h, B, rec, st);
+  if (rc) return rc;
+  if (p->mixed) {
+    float* part = rec + N * TabX::NG * 16;
+    HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)WLayout<3>::base_total(nl, true) * 4, st));
+    LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabX><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
+    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabX::NT * 8, 256, 0, st>>>(nblk * 4, TabX::NT, part, d_grad, MapX())));
+  } else {
+    float* part = rec + N * PGREC;
+    HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)WLayout<2>::base_total(nl, false) * 4, st));
+    LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabF><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
+    LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabF::NT * 8, 256, 0, st>>>(nblk, TabF::NT, part, d_grad, MapF())));
+  }
+  HIP_TRY(hipGetLastError());
+  return PSIGNN_OK;
 }
 
 // h, prb, w in PLAN order.  d_grad: psignn_param_grad_size floats (fold slots left zero); d_out_h: (N, 10) = w^T df/dh.
@@ -237,21 +265,8 @@ extern "C" int psignn_f_param_vjp_p(const psignn_plan_t* p, const float* W, int 
                                     const float* w, float* d_grad, float* d_out_h, float* work, void* stream) {
   ARG_CHECK(p && W && h && prb && w && d_grad && d_out_h && work, "NULL argument");
   ARG_CHECK(p->tiled && !p->mixed && nl == 1,
-            "parameter gradients are implemented for tiled single-layer dirichlet plans (mesh positions required)");
-  hipStream_t st = (hipStream_t)stream;
-  const int64_t N = p->N;
-  float* B = work;
-  float* rec = B + N * 4 * D;
-  float* part = rec + N * PGREC;
-  int npw;
-  const int nblk = pgrad_blocks(N, &npw);
-  int rc = psignn_f_tile_vjp_rec(p, W, nl, h, prb, w, d_out_h, B, rec, st);
-  if (rc) return rc;
-  HIP_TRY(hipMemsetAsync(d_grad, 0, (size_t)WLayout<2>::base_total(nl, false) * 4, st));
-  LAUNCH("k_pgrad_outer", st, (k_pgrad_outer<TabF><<<nblk, 256, 0, st>>>(N, npw, rec, part)));
-  LAUNCH("k_pgrad_reduce", st, (k_pgrad_reduce<<<TabF::NT * 8, 256, 0, st>>>(nblk, TabF::NT, part, d_grad, MapF())));
-  HIP_TRY(hipGetLastError());
-  return PSIGNN_OK;
+            "plan-order parameter gradients: tiled single-layer dirichlet plans (mixed plans: psignn_f_param_vjp, which takes the normals)");
+  return param_vjp_tiled(p, W, nl, h, prb, nullptr, w, d_grad, d_out_h, work, (hipStream_t)stream);
 }
 
 // ---- backward of the VJP (the Jacobian regulariser's gradient; kernels and derivation in gather_backward.hip)
@@ -535,8 +550,8 @@ extern "C" int psignn_residual_t(const psignn_plan_t* p, const float* d_a_ij, co
   return PSIGNN_OK;
 }
 
-// Caller-order parameter-VJP for every plan: tiled single-layer dirichlet plans run the tiled kernels (permutation passes
-// around them); mixed and untiled plans run the global-gather kernels in PG mode.  d_normals: mixed only.
+// Caller-order parameter-VJP for every plan: tiled plans of both families run the tiled kernels (permutation passes around
+// them; mixed family since round 3); untiled plans run the global-gather kernels in PG mode.  d_normals: mixed only.
 extern "C" int psignn_f_param_vjp(const psignn_plan_t* p, const float* W, int nl, const float* h, const float* prb,
                                   const float* nrm, const float* w, float* d_grad, float* d_out_h, float* work,
                                   void* stream) {
@@ -546,16 +561,21 @@ extern "C" int psignn_f_param_vjp(const psignn_plan_t* p, const float* W, int nl
   hipStream_t st = (hipStream_t)stream;
   const int64_t N = p->N;
   int rc;
-  if (p->tiled && !p->mixed) {
+  KNOB_INT(mixed_tiled, [] { const char* e = getenv("PSIGNN_MIXED_PGRAD"); return (int)!(e && strcmp(e, "gather") == 0); }());
+  if (p->tiled && (!p->mixed || mixed_tiled)) {
+    const int P = p->mixed ? 3 : 2;
     float* hp = work;
     float* wp = hp + N * D;
     float* op = wp + N * D;
-    float* pp = op + N * D;  // (N, 2)
-    float* rest = pp + N * 2;
+    float* pp = op + N * D;  // (N, 2 | 3)
+    float* np_ = pp + N * P; // (N, 2) unit normals, mixed plans
+    float* rest = np_ + (p->mixed ? N * 2 : 0);
+    rest += (4 - ((rest - work) & 3)) & 3;   // the VJP's B rows are read as float4
     if ((rc = psignn_plan_permute(p, h, D, hp, 1, stream))) return rc;
     if ((rc = psignn_plan_permute(p, w, D, wp, 1, stream))) return rc;
-    if ((rc = psignn_plan_permute(p, prb, 2, pp, 1, stream))) return rc;
-    if ((rc = psignn_f_param_vjp_p(p, W, nl, hp, pp, wp, d_grad, op, rest, stream))) return rc;
+    if ((rc = psignn_plan_permute(p, prb, P, pp, 1, stream))) return rc;
+    if (p->mixed && (rc = psignn_plan_permute(p, nrm, 2, np_, 1, stream))) return rc;
+    if ((rc = param_vjp_tiled(p, W, nl, hp, pp, p->mixed ? np_ : nullptr, wp, d_grad, op, rest, st))) return rc;
     return psignn_plan_permute(p, op, D, d_out_h, 0, stream);
   }
   float* scratch = work;                      // Pj + B: N * 90 floats at most

@@ -121,10 +121,12 @@ __device__ __forceinline__ float pass_fwd(const uint4* __restrict__ slots, int n
 }
 
 // one 16-float group of a parameter-gradient record: v[0..n) then `tail`, then zeros
-__device__ __forceinline__ void rec_group(float* __restrict__ g, const float* v, int n, float t0 = 0.f, float t1 = 0.f) {
+__device__ __forceinline__ void rec_group(float* __restrict__ g, const float* v, int n, float t0 = 0.f, float t1 = 0.f,
+                                          float t2 = 0.f, float t3 = 0.f, float t4 = 0.f) {
   float r[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) r[i] = i < n ? v[i] : (i == n ? t0 : (i == n + 1 ? t1 : 0.f));
+  for (int i = 0; i < 16; ++i)
+    r[i] = i < n ? v[i] : (i == n ? t0 : (i == n + 1 ? t1 : (i == n + 2 ? t2 : (i == n + 3 ? t3 : (i == n + 4 ? t4 : 0.f)))));
   float4* q = reinterpret_cast<float4*>(g);
 #pragma unroll
   for (int i = 0; i < 4; ++i) q[i] = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
@@ -175,8 +177,9 @@ __global__ __launch_bounds__(VT) VJPA_OCC void k_vjp_tile_a(int n_tiles, int chu
                                                    const float* __restrict__ prb, const float* __restrict__ nrm,
                                                    const float* __restrict__ wv, float* __restrict__ B,
                                                    float* __restrict__ out, float* __restrict__ rec) {
-  static_assert(!(MIXED && PG), "parameter-gradient records: dirichlet family only");
   using L = WLayout<P>;
+  // record stride: 20 groups (dirichlet plans) / 30 (mixed plans, P = 3: the Neumann groups 20..29 of fgnn_vjp.hip's PgRec follow)
+  constexpr int REC = P == 3 ? 480 : PGREC;
   constexpr int RS = MIXED ? 32 : 20;   // [Pj_to 10 | Pj_from 10 (| Pj_neu 10 | pad 2)]
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int slot_ = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
@@ -234,10 +237,10 @@ __global__ __launch_bounds__(VT) VJPA_OCC void k_vjp_tile_a(int n_tiles, int chu
     for (int o = 0; o < D; ++o) zero[o] = 0.f;
     store10(out + n * D, zero);
     if (PG) {  // a constant row still acts as a neighbour: its (x, 1) group feeds the W1j products of pass B
-      float* r = rec + n * PGREC;
+      float* r = rec + n * REC;
       rec_group(r, x, D, 1.f);
-      for (int gI = 1; gI < PGREC / 16; ++gI)
-        if (gI != 12 && gI != 13) rec_group(r + 16 * gI, zero, 0);
+      for (int gI = 1; gI < REC / 16; ++gI)
+        if (gI != 12 && gI != 13 && gI != 27) rec_group(r + 16 * gI, zero, 0);   // (12, 13, 27: pass B)
     }
     return;
   }
@@ -250,13 +253,17 @@ __global__ __launch_bounds__(VT) VJPA_OCC void k_vjp_tile_a(int n_tiles, int chu
     // REPLACED, so there is no residual path
     const float* TN = W + tnofs;
     const float* Un = W + L::upd_neu(nl);
-    v2f Pn[5], S_n[5], c_n[5], dummy[1];
+    v2f Pn[5], S_n[5], c_n[5], m_n[PG ? 15 : 1];
+    if (PG) {
+#pragma unroll
+      for (int i = 0; i < 15; ++i) m_n[PG ? i : 0] = splat2(0.f);
+    }
     ldu5(TN + L::N_B1, Pn);
 #pragma unroll
     for (int p = 0; p < 5; ++p) S_n[p] = c_n[p] = splat2(0.f);
     PHASE();
     mvf<D>(TN + L::N_W1I, x, Pn);
-    const float deg_out = pass_fwd<RS, 2 * D, SLOT_OUT, false>(slots, nslots, lds, TN + L::N_A, Pn, S_n, c_n, dummy);
+    const float deg_out = pass_fwd<RS, 2 * D, SLOT_OUT, PG>(slots, nslots, lds, TN + L::N_A, Pn, S_n, c_n, m_n);
     v2f q2[5], gN[5], hid2[5], y2[5];
     ldu5(TN + L::N_NB1, q2);
     ldu5(TN + L::N_gN, gN);
@@ -318,6 +325,49 @@ __global__ __launch_bounds__(VT) VJPA_OCC void k_vjp_tile_a(int n_tiles, int chu
       go[2 * p + 1] = g[p].y;
     }
     store10(out + n * D, go);
+    if (PG) {
+      // ---- parameter-gradient record of a Neumann row (groups as fgnn_vjp.hip's PgRec): the interior branch's factors are zero
+      float* r = rec + n * REC;
+      const float* Wn = W + L::phi_neu(nl);
+      float zero[D], mp[D], t[D];
+#pragma unroll
+      for (int o = 0; o < D; ++o) zero[o] = 0.f;
+      rec_group(r, x, D, 1.f);                                                          // 0: x, 1
+      for (int gI = 1; gI < 12; ++gI) rec_group(r + 16 * gI, zero, 0);
+#pragma unroll
+      for (int o = 0; o < D; ++o) t[o] = w[o] * y[o];
+      rec_group(r + 14 * 16, t, D);                                                     // 14: w * yhat
+      rec_group(r + 15 * 16, w, D);                                                     // 15: w
+      for (int gI = 16; gI < 20; ++gI) rec_group(r + 16 * gI, zero, 0);
+#pragma unroll
+      for (int o = 0; o < D; ++o) mp[o] = deg_out * Wn[L::PHI_B2 + o];
+      matvec10<D, true>(Wn + L::PHI_W2, D, 0, reinterpret_cast<const float*>(S_n), mp);
+      rec_group(r + 20 * 16, mp, D, pq[0], pq[1], pq[2], pq[3], pq[4]);                 // 20: mp_n, prb, normal
+      rec_group(r + 21 * 16, reinterpret_cast<const float*>(S_n), D, deg_out);          // 21: S_n, deg_out
+      rec_group(r + 22 * 16, reinterpret_cast<const float*>(hid2), D, 1.f);             // 22: hid_n, 1
+      rec_group(r + 23 * 16, dq, D);                                                    // 23: dq_n
+      rec_group(r + 24 * 16, gn, D);                                                    // 24: sum of masked cotangents, own out-edges
+      v2f dm[5];
+#pragma unroll
+      for (int p = 0; p < 5; ++p) dm[p] = splat2(0.f);
+      PHASE();
+      mvb<D>(Un + L::NEU_W1, L::NEU_CAT, D, dq, dm);
+      rec_group(r + 25 * 16, reinterpret_cast<const float*>(dm), D);                    // 25: d mp_n
+      rec_group(r + 26 * 16, dy, D);                                                    // 26: dy_n      (27: pass B)
+      float da[32];
+      const float* dsn = reinterpret_cast<const float*>(dS_n);
+      const float* mn = reinterpret_cast<const float*>(m_n);
+#pragma unroll
+      for (int o = 0; o < D; ++o) {
+        da[o * 3] = dsn[o] * mn[PG ? o : 0];
+        da[o * 3 + 1] = dsn[o] * mn[PG ? 10 + o : 0];
+        da[o * 3 + 2] = dsn[o] * mn[PG ? 20 + o : 0];
+      }
+      da[30] = da[31] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)                                                       // 28..29: dS_n (.) attr moments
+        reinterpret_cast<float4*>(r + 28 * 16)[i] = make_float4(da[4 * i], da[4 * i + 1], da[4 * i + 2], da[4 * i + 3]);
+    }
     return;
   }
   // ---- forward with activity counts
@@ -452,13 +502,13 @@ __global__ __launch_bounds__(VT) VJPA_OCC void k_vjp_tile_a(int n_tiles, int chu
   store10(out + n * D, go);
   if (PG) {
     // ---- parameter-gradient record (fgnn_pgrad.hip reduces sum_n A_n (x) B_n over these 16-float groups)
-    float* r = rec + n * PGREC;
+    float* r = rec + n * REC;
     float mp[D], t[D];
     rec_group(r, x, D, 1.f);                                                   // 0: x, 1
 #pragma unroll
     for (int o = 0; o < D; ++o) mp[o] = deg_in * Wto[L::PHI_B2 + o];
     matvec10<D, true>(Wto + L::PHI_W2, D, 0, sto, mp);
-    rec_group(r + 16, mp, D, pq[0], pq[1]);                                    // 1: mp_to, prb
+    rec_group(r + 16, mp, D, pq[0], pq[1], P == 3 ? pq[P - 1] : 0.f);         // 1: mp_to, prb
 #pragma unroll
     for (int o = 0; o < D; ++o) mp[o] = deg_out * Wfr[L::PHI_B2 + o];
     matvec10<D, true>(Wfr + L::PHI_W2, D, 0, sfr, mp);
@@ -504,6 +554,12 @@ __global__ __launch_bounds__(VT) VJPA_OCC void k_vjp_tile_a(int n_tiles, int chu
 #pragma unroll
     for (int i = 0; i < 16; ++i)
       reinterpret_cast<float4*>(r + 256)[i] = make_float4(da[4 * i], da[4 * i + 1], da[4 * i + 2], da[4 * i + 3]);
+    if (P == 3) {   // mixed plan, interior row: no Neumann factors (27: pass B)
+#pragma unroll
+      for (int o = 0; o < D; ++o) t[o] = 0.f;
+      for (int gI = 20; gI < 30; ++gI)
+        if (gI != 27) rec_group(r + 16 * gI, t, 0);
+    }
   }
 }
 
@@ -602,6 +658,7 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const
                                                    const float* __restrict__ B, float* __restrict__ out,
                                                    float* __restrict__ rec) {
   using L = WLayout<P>;
+  constexpr int REC = P == 3 ? 480 : PGREC;
   // B row in memory: [Pt 10 | dS_to 10 | Pf 10 | dS_fr 10].  The OUT slots need the first half of the senders' rows, the IN slots the
   // second: the halves are staged one after the other into 80-byte LDS rows -- 26 KB per workgroup instead of 52, so six workgroups
   // fit a CU where three did (the kernel needs < 96 VGPRs: LDS was what held it at three waves per SIMD); same bytes from memory.
@@ -673,8 +730,9 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const
   }
   if (!active) return;
   if (PG) {  // neighbour-side cotangent sums: W1j gradients are sum_u acc[u] (x) x[u]
-    rec_group(rec + u * PGREC + 192, reinterpret_cast<const float*>(at), D);
-    rec_group(rec + u * PGREC + 208, reinterpret_cast<const float*>(af), D);
+    rec_group(rec + u * REC + 192, reinterpret_cast<const float*>(at), D);
+    rec_group(rec + u * REC + 208, reinterpret_cast<const float*>(af), D);
+    if (P == 3) rec_group(rec + u * REC + 27 * 16, reinterpret_cast<const float*>(an), D);   // 27: neighbour-side sums through Phi_neumann
   }
   float go[D];
   load10(out + u * D, go);
@@ -703,7 +761,8 @@ __global__ __launch_bounds__(VT) void k_vjp_tile_b(int n_tiles, int chunk, const
 static int tile_vjp_launch(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* nrm,
                            const float* w, float* out, float* work, float* rec, hipStream_t st) {
   ARG_CHECK(p && p->tiled && (p->mixed || nl == 1), "tiled VJP: single-layer dirichlet plans, mixed plans");
-  ARG_CHECK(!p->mixed || (nrm && !rec), "mixed plan: needs unit normals; no parameter-gradient records");
+  ARG_CHECK(!p->mixed || nrm, "mixed plan: needs unit normals");
+  ARG_CHECK(!(p->mixed && rec) || nl == 1, "parameter-gradient records: single-layer blocks");
   const int chunk = (int)cdiv(p->n_tiles, 8);
   const unsigned grid = (unsigned)(chunk * 8);
   const size_t lds_b = (size_t)p->max_rows * (20 + (p->mixed ? 1 : 0)) * 4;
@@ -715,16 +774,28 @@ static int tile_vjp_launch(const psignn_plan* p, const float* W, int nl, const f
     const int na = (int)p->n_tiles_plain, nb = (int)(p->n_tiles - p->n_tiles_plain);
     if (na > 0) {   // tiles without Neumann nodes of their own
       const int ch = (int)cdiv(na, 8);
-      LAUNCH("k_vjp_tile_a", st, (k_vjp_tile_a<3, false, false><<<(unsigned)(ch * 8), VT, (size_t)p->max_rows * 20 * 4, st>>>(
-          na, ch, p->tile_order, VJP_PLAN, W, nl, lofs, tofs, tnofs, h, prb, nrm, w, work, out, rec)));
+      if (rec)
+        LAUNCH("k_pgrad_tile_a", st, (k_vjp_tile_a<3, false, true><<<(unsigned)(ch * 8), VT, (size_t)p->max_rows * 20 * 4, st>>>(
+            na, ch, p->tile_order, VJP_PLAN, W, nl, lofs, tofs, tnofs, h, prb, nrm, w, work, out, rec)));
+      else
+        LAUNCH("k_vjp_tile_a", st, (k_vjp_tile_a<3, false, false><<<(unsigned)(ch * 8), VT, (size_t)p->max_rows * 20 * 4, st>>>(
+            na, ch, p->tile_order, VJP_PLAN, W, nl, lofs, tofs, tnofs, h, prb, nrm, w, work, out, rec)));
     }
     if (nb > 0) {
       const int ch = (int)cdiv(nb, 8);
-      LAUNCH("k_vjp_tile_a", st, (k_vjp_tile_a<3, true, false><<<(unsigned)(ch * 8), VT, (size_t)p->max_rows * 32 * 4, st>>>(
-          nb, ch, p->tile_order + na, VJP_PLAN, W, nl, lofs, tofs, tnofs, h, prb, nrm, w, work, out, rec)));
+      if (rec)
+        LAUNCH("k_pgrad_tile_a", st, (k_vjp_tile_a<3, true, true><<<(unsigned)(ch * 8), VT, (size_t)p->max_rows * 32 * 4, st>>>(
+            nb, ch, p->tile_order + na, VJP_PLAN, W, nl, lofs, tofs, tnofs, h, prb, nrm, w, work, out, rec)));
+      else
+        LAUNCH("k_vjp_tile_a", st, (k_vjp_tile_a<3, true, false><<<(unsigned)(ch * 8), VT, (size_t)p->max_rows * 32 * 4, st>>>(
+            nb, ch, p->tile_order + na, VJP_PLAN, W, nl, lofs, tofs, tnofs, h, prb, nrm, w, work, out, rec)));
     }
-    LAUNCH("k_vjp_tile_b", st, (k_vjp_tile_b<3, true, false><<<grid, VT, lds_b, st>>>(
-        (int)p->n_tiles, chunk, VJP_PLAN, W, nl, lofs, tofs, tnofs, h, work, out, rec)));
+    if (rec)
+      LAUNCH("k_pgrad_tile_b", st, (k_vjp_tile_b<3, true, true><<<grid, VT, lds_b, st>>>(
+          (int)p->n_tiles, chunk, VJP_PLAN, W, nl, lofs, tofs, tnofs, h, work, out, rec)));
+    else
+      LAUNCH("k_vjp_tile_b", st, (k_vjp_tile_b<3, true, false><<<grid, VT, lds_b, st>>>(
+          (int)p->n_tiles, chunk, VJP_PLAN, W, nl, lofs, tofs, tnofs, h, work, out, rec)));
     HIP_TRY(hipGetLastError());
     return PSIGNN_OK;
   }
@@ -748,9 +819,9 @@ int psignn_f_tile_vjp(const psignn_plan* p, const float* W, int nl, const float*
                       const float* w, float* out, float* work, hipStream_t st) {
   return tile_vjp_launch(p, W, nl, h, prb, nrm, w, out, work, nullptr, st);
 }
-// same, additionally filling the parameter-gradient records rec: (N, PGREC) floats (fgnn_pgrad.hip; dirichlet family)
-int psignn_f_tile_vjp_rec(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* w,
-                          float* out, float* work, float* rec, hipStream_t st) {
+// same, additionally filling the parameter-gradient records rec: (N, 320) floats, mixed plans (N, 480) (fgnn_pgrad.hip)
+int psignn_f_tile_vjp_rec(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* nrm,
+                          const float* w, float* out, float* work, float* rec, hipStream_t st) {
   ARG_CHECK(rec, "NULL record buffer");
-  return tile_vjp_launch(p, W, nl, h, prb, nullptr, w, out, work, rec, st);
+  return tile_vjp_launch(p, W, nl, h, prb, nrm, w, out, work, rec, st);
 }

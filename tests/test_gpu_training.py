@@ -131,6 +131,47 @@ def test_param_vjp_other_tile_sizes(dev):
         flat.param_vjp_p(h, v)   # the plan-order entry point is the tiled path only
 
 
+def test_mixed_param_vjp_on_tiles_equals_gather_records(dev, knobs):
+    """Mixed-family parameter gradients from the tiled VJP kernels in record mode (round 3: 30-group records incl. the Neumann
+    factors, csrc/fgnn_tile_vjp.hip) against the global-gather record kernels (PSIGNN_MIXED_PGRAD=gather) on a mesh of many
+    tiles with Neumann nodes on three sides; several tile sizes; bitwise reproducible."""
+    data, eng = pkg("data"), pkg("engine")
+    sd = load_weights("mixed")
+    mesh = data.make_hex_problem(data.hex_n_for_nodes(20000), seed=3, mixed=True, compute_sol=False)
+    md = mesh.to(dev)
+    with torch.no_grad():
+        h0 = orc.encoder(sd, mesh.x).to(dev)
+    w = eng.PackedWeights(sd, dev)
+    gen = torch.Generator().manual_seed(23)
+    h = (h0 + 0.1 * torch.randn(h0.shape, generator=gen).to(dev)).contiguous()
+    v = torch.randn(h0.shape, generator=gen).to(dev)
+    fm = eng.FixedPointMap(eng.MeshPlan(md), w, h0, md.prb_data, md.unit_normal_vector)
+    assert fm.plan.tiled and fm.plan.mixed and fm.plan.n_tiles > 50
+    nat = pkg("_native")
+    nat.prof_enable(True)
+    nat.prof_collect()
+    tiled, oh = fm.param_vjp(h, v)
+    ran = nat.prof_collect()
+    assert "k_pgrad_tile_a" in ran and "k_pgrad_tile_b" in ran and "k_pgrad_local" not in ran, ran   # the tile kernels in record mode
+    again, _ = fm.param_vjp(h, v)
+    assert all(torch.equal(tiled[k], again[k]) for k in tiled)
+    knobs(PSIGNN_MIXED_PGRAD="gather")
+    nat.prof_collect()
+    gath, oh_g = fm.param_vjp(h, v)
+    ran = nat.prof_collect()
+    nat.prof_enable(False)
+    assert "k_pgrad_local" in ran and "k_pgrad_tile_a" not in ran, ran
+    knobs(PSIGNN_MIXED_PGRAD=None)
+    scale = max(float(t.norm()) for t in gath.values())
+    assert set(tiled) == set(gath) and any("neumann" in k for k in tiled)
+    _cmp(tiled, {k: t.cpu() for k, t in gath.items()}, 1e-5, scale)
+    assert rel_l2(oh, oh_g) < 2e-6
+    for tt in (64, 160):
+        fm2 = eng.FixedPointMap(eng.MeshPlan(md, tile_target=tt), w, h0, md.prb_data, md.unit_normal_vector)
+        got, _ = fm2.param_vjp(h, v)
+        _cmp(got, {k: t.cpu() for k, t in gath.items()}, 1e-5, scale)
+
+
 @pytest.mark.parametrize("dims", [(1, 10, 10), (10, 10, 1), (3, 7, 5)])
 def test_mlp2_backward(dims, dev):
     eng = pkg("engine")
