@@ -193,38 +193,45 @@ __global__ __launch_bounds__(TB) void k_resid(int64_t M, const Status* __restric
 
 // One block: finish the norms, append to the traces, track the lowest iterate, run the stop tests
 // (solver.py:160-183) and rotate the iterate buffers.
+// The bookkeeping block of an iteration.  Its time is latency, not work: round 2's form read and wrote the status fields one by
+// one (a dozen dependent global round trips on thread 0) and ran the two norm reductions one after the other -- 7.7 us for a
+// kernel whose empty launch costs 4.5.  Now the whole status block is read in one go BEFORE the reductions, both norms are summed in
+// one pass (same thread-strided shape and tree per column as block_sum_col), everything is decided in registers and the block is
+// written back once.
 __device__ void check_block(Status* st, const float* __restrict__ part, int npart, double* __restrict__ rel_trace,
                             double* __restrict__ abs_trace, double eps, int thr, int seq_len, int keep_trace, double* sh) {
-  if (st->done) return;
-  double sg = block_sum_col(part, npart, 1, sh);
-  double sf = block_sum_col(part + npart, npart, 1, sh);
+  __shared__ double sh2[RB];
+  Status s = *st;   // (every thread: uniform address, one request; thread 0 is the only writer)
+  if (s.done) return;
+  double sg, sf;
+  block_sum_col2(part, part + npart, npart, sh, sh2, sg, sf);
   if (threadIdx.x != 0) return;
   // torch.norm(...) is an fp32 value read back with .item(); the division is done in Python doubles
   double abs_diff = (double)(float)sqrt(sg);
   double rel_diff = abs_diff / ((double)(float)sqrt(sf) + 1e-9);
-  int n = st->n_iter + 1;
-  st->n_iter = n;
+  const int n = s.n_iter + 1;
+  s.n_iter = n;
   rel_trace[n - 1] = rel_diff;
   abs_trace[n - 1] = abs_diff;
   if (n == 1) {
-    st->rel0 = rel_diff;
-    st->abs0 = abs_diff;
+    s.rel0 = rel_diff;
+    s.abs0 = abs_diff;
   }
   // both modes keep their own lowest value / step; the lowest ITERATE follows stop_mode (solver.py:167-172)
-  const bool stop_abs = st->stop_abs != 0;
-  const bool low_rel = rel_diff < st->lowest_rel, low_abs = abs_diff < st->lowest_abs_at;
+  const bool stop_abs = s.stop_abs != 0;
+  const bool low_rel = rel_diff < s.lowest_rel, low_abs = abs_diff < s.lowest_abs_at;
   if (low_rel) {
-    st->lowest_rel = rel_diff;
-    st->lowest_step = n;
+    s.lowest_rel = rel_diff;
+    s.lowest_step = n;
   }
   if (low_abs) {
-    st->lowest_abs_at = abs_diff;
-    st->lowest_step_abs = n;
+    s.lowest_abs_at = abs_diff;
+    s.lowest_step_abs = n;
   }
   const bool new_low = stop_abs ? low_abs : low_rel;
   // buffer rotation: the iterate just evaluated lives in nxt
-  int cur = st->nxt;
-  int low = new_low ? cur : st->low;
+  const int cur = s.nxt;
+  const int low = new_low ? cur : s.low;
   int nxt;
   if (keep_trace) {
     nxt = cur + 1;
@@ -232,9 +239,9 @@ __device__ void check_block(Status* st, const float* __restrict__ part, int npar
     nxt = 0;
     while (nxt == cur || nxt == low) ++nxt;
   }
-  st->cur = cur;
-  st->low = low;
-  st->nxt = nxt;
+  s.cur = cur;
+  s.low = low;
+  s.nxt = nxt;
   // stop tests on the objective of stop_mode (solver.py:174-181); protect_thres = 1e6 (abs) / 1e3 (rel) * seq_len
   const double obj = stop_abs ? abs_diff : rel_diff;
   const double* tr = stop_abs ? abs_trace : rel_trace;
@@ -242,23 +249,24 @@ __device__ void check_block(Status* st, const float* __restrict__ part, int npar
   if (obj < eps) {
     reason = 1;
   } else if (obj < 3 * eps && n > 30) {
-    double mx = -1e300, mn = 1e300;
-    for (int i = n - 30; i < n; ++i) {
+    double mx = obj, mn = obj;   // (entry n - 1 of the trace is this iteration's value)
+    for (int i = n - 30; i < n - 1; ++i) {
       double r = tr[i];
       mx = r > mx ? r : mx;
       mn = r < mn ? r : mn;
     }
     if (mx / mn < 1.3) reason = 2;
   }
-  if (reason < 0 && obj > (stop_abs ? st->abs0 * 1e6 : st->rel0 * 1e3) * seq_len) {
+  if (reason < 0 && obj > (stop_abs ? s.abs0 * 1e6 : s.rel0 * 1e3) * seq_len) {
     reason = 3;
-    st->prot_break = 1;
+    s.prot_break = 1;
   }
   if (reason < 0 && n >= thr) reason = 0;
   if (reason >= 0) {
-    st->done = 1;
-    st->stop_reason = reason;
+    s.done = 1;
+    s.stop_reason = reason;
   }
+  *st = s;
 }
 
 #define DOTS_PART4 1   // (historic switch of the partials layout; the three-sweep forms below assume the current one)
@@ -422,7 +430,7 @@ __device__ __forceinline__ void reduce_a_check_body(Status* st, const float* __r
     if (blockIdx.x == 0) check_block(st, nrm_part, nn, rel_trace, abs_trace, eps, thr, seq_len, keep_trace, sh);
     return;
   }
-  if (st->done) return;
+  const int done = st->done;   // (requested first, looked at last)
   const int j = blockIdx.x, r = blockIdx.y;
   if (j >= k) return;
   // pairs from a_from on: per-block partials of the folded sweep 3 of the last iteration (entry j - a_from of its rows); the older
@@ -433,7 +441,7 @@ __device__ __forceinline__ void reduce_a_check_body(Status* st, const float* __r
   const int64_t stride = j >= a_from ? PARTA_LD : ldp;
   const int lo = (int)((int64_t)n * r / RA), hi = (int)((int64_t)n * (r + 1) / RA);
   const double s = block_sum_col(col + (int64_t)lo * stride, hi - lo, stride, sh);
-  if (threadIdx.x == 0) coef[(3 + r) * thr + j] = (float)s;
+  if (threadIdx.x == 0 && !done) coef[(3 + r) * thr + j] = (float)s;
 }
 __global__ __launch_bounds__(RB) void k_reduce_a_check(Status* st, const float* __restrict__ part, int nrows, int ldp, int thr, int k,
                                                        float* __restrict__ coef, const float* __restrict__ nrm_part, int nn,
@@ -534,21 +542,23 @@ __global__ __launch_bounds__(TB) void k_sweep_v(int64_t M, int k, const Status* 
 // (fixed order, fp64, rounded to fp32 like the reference's .item() values -- what every block of k_final used to repeat)
 __device__ __forceinline__ void reduce_cb_body(Status* __restrict__ st, const float* __restrict__ part, int nrows, int64_t pstride, int ldp, int thr, int k,
                                                float* __restrict__ coef, const float* __restrict__ part2, int nblk, double* sh) {
-  if (st->done) return;
+  // (the done flag is requested first and looked at last: its round trip overlaps the partial loads of the reduction)
+  const int done = st->done;
   if (blockIdx.y == 2) {
     if (blockIdx.x != 0) return;
-    const float sv = (float)block_sum_col(part2, nblk, 1, sh);
-    const float beta = (float)block_sum_col(part2 + nblk, nblk, 1, sh);
-    if (threadIdx.x == 0) {
-      st->s = (double)sv;
-      st->beta = (double)beta;
+    __shared__ double sh2[RB];
+    double sv, beta;
+    block_sum_col2(part2, part2 + nblk, nblk, sh, sh2, sv, beta);
+    if (threadIdx.x == 0 && !done) {
+      st->s = (double)(float)sv;
+      st->beta = (double)(float)beta;
     }
     return;
   }
   const int j = blockIdx.x, c = 1 + blockIdx.y;
   if (j >= k) return;
   const double s = block_sum_col(part + (int64_t)c * pstride + j, nrows, ldp, sh);
-  if (threadIdx.x == 0) coef[c * thr + j] = (float)s;
+  if (threadIdx.x == 0 && !done) coef[c * thr + j] = (float)s;
 }
 __global__ __launch_bounds__(RB) void k_reduce_cb(Status* __restrict__ st, const float* __restrict__ part, int nrows, int64_t pstride, int ldp, int thr, int k,
                                                   float* __restrict__ coef, const float* __restrict__ part2, int nblk) {

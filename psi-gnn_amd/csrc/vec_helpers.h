@@ -206,6 +206,38 @@ __device__ inline double block_sum_col(const float* __restrict__ p, int n, int64
   return r;
 }
 
+// two contiguous lists of n values at once (p and q), each summed in exactly block_sum_col's shape (thread-strided, four partial
+// sums per thread, the same tree): one set of barriers for both
+__device__ inline void block_sum_col2(const float* __restrict__ p, const float* __restrict__ q, int n, double* sh, double* sh2,
+                                      double& sp, double& sq) {
+  const int T = blockDim.x;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * T < n; i += 4 * T) {
+    const float x0 = p[i], x1 = p[i + T], x2 = p[i + 2 * T], x3 = p[i + 3 * T];
+    const float y0 = q[i], y1 = q[i + T], y2 = q[i + 2 * T], y3 = q[i + 3 * T];
+    a0 += (double)x0; a1 += (double)x1; a2 += (double)x2; a3 += (double)x3;
+    b0 += (double)y0; b1 += (double)y1; b2 += (double)y2; b3 += (double)y3;
+  }
+  for (; i < n; i += T) {
+    a0 += (double)p[i];
+    b0 += (double)q[i];
+  }
+  sh[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  sh2[threadIdx.x] = (b0 + b1) + (b2 + b3);
+  __syncthreads();
+  for (int o = T / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      sh[threadIdx.x] += sh[threadIdx.x + o];
+      sh2[threadIdx.x] += sh2[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  sp = sh[0];
+  sq = sh2[0];
+  __syncthreads();
+}
+
 // launch a VEC-templated kernel with the solver's vector width
 #define VPLAIN(vec, kern, cfg, ...)                                     \
   do {                                                                  \
