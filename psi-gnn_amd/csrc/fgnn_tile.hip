@@ -118,6 +118,14 @@ struct FuseArgs {
   long long* stamps;  // diagnostics (psignn_prof_tile_stamps): per tile and wave 8 constant-rate (100 MHz) clock stamps, else NULL
 };
 
+// Wave priority per phase: TILE_PRIO = p0 + 4 p1 + 16 p2 + 64 p3 sets s_setprio(p) at the start of stage 1 / after the barrier (slot
+// walk) / at the node update / at the epilogue; 0 = never touched.  15: the phases that ISSUE memory requests (stage 1, slot walk)
+// go ahead of the purely arithmetic node update of other waves -- plain f 52.0 -> 50.4 us over four interleaved runs each, fused
+// step unchanged (profiles/r3_ab_prio.txt); the other placements measured there are within noise.
+#ifndef TILE_PRIO
+#define TILE_PRIO 15
+#endif
+#define PRIO_AT(ph) do { if (TILE_PRIO) __builtin_amdgcn_s_setprio((TILE_PRIO >> (2 * (ph))) & 3); } while (0)
 // In-kernel phase stamps (diagnostics only; one lane per wave writes s_memtime values)
 #ifndef TILE_STAMPS
 #define TILE_STAMPS 0   // build with -DTILE_STAMPS=1 for scripts/tile_phases.py (the stamps cost registers and issue slots)
@@ -165,6 +173,7 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
   constexpr int RS = TileRow<MIXED>::RS;
   const int tile = tile_list ? tile_list[slot] : slot;   // mixed plans: a sub-list of the tiles (see launch_mixed)
   STAMP(0);
+  PRIO_AT(0);
   const int tid = threadIdx.x;
   // tile -> node range: arithmetic when the plan's tiles are uniform chunks (always, since round 2; the table stays for
   // tile sizes that are not a multiple of 64)
@@ -451,6 +460,7 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
   STAMP(1);
   __syncthreads();
   STAMP(2);
+  PRIO_AT(1);
   if (!FUSED && tid >= n_t) return;
 
   // ---- stage 2: one tile node per lane
@@ -508,6 +518,7 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
     PHASE();
   }
   STAMP(3);
+  PRIO_AT(2);
 #if X_RELOAD
   load10(xsrc, x);
 #endif
@@ -617,6 +628,7 @@ __device__ __forceinline__ void f_tile_body(const FuseArgs& fa, const int slot, 
   }
   }  // !dirichlet && active
   STAMP(4);
+  PRIO_AT(3);
   if (!FUSED) {
     store10(out + n * D, y);
     STAMP(5);
