@@ -83,6 +83,9 @@ __device__ __forceinline__ float edge_pass_jvp(const uint4* __restrict__ slots, 
 #else
 #define JVP_OCC
 #endif
+#ifndef JVP_PRIO
+#define JVP_PRIO 1   // 1: s_setprio(3) through stage 1 and the slot walk, 0 from the node update on (86.4 -> 83.6 us; k_jvp_lin: 49.2 -> 50.7, left off; profiles/r3_ab_prio_jvp.txt)
+#endif
 #ifndef JVP_XRELOAD
 #define JVP_XRELOAD 1
 #endif
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(TILE_THREADS) JVP_OCC void k_jvp_tile(int n_tiles, 
   const float* T = W + tofs;
   const int doff = MIXED ? 2 * D : (n_t + n_h) * RS;   // floats from a node's value row to its tangent row
   // ---- stage 1
+  if (JVP_PRIO) __builtin_amdgcn_s_setprio(3);
   float x[D], dx[D];
   if constexpr (MFMA1) {
     // Both dense products of stage 1 -- state rows and tangent rows times the neighbour-side weights -- on the matrix
@@ -391,6 +395,7 @@ __global__ __launch_bounds__(TILE_THREADS) JVP_OCC void k_jvp_tile(int n_tiles, 
   load10(tv + n * D, dx);
 #endif
   // ---- gate and update MLP (second Phi layer folded), values and tangents
+  if (JVP_PRIO) __builtin_amdgcn_s_setprio(0);
   const float* Wf = W + lofs + L::L_FOLD;
   const float* Wa = W + L::AL_W;
   const float* sto = reinterpret_cast<const float*>(S_to);

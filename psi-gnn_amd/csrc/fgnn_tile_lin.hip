@@ -292,6 +292,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_lin_build(int n_tiles, int chu
 // ------------------------------------------------------------------------------------------------------------------
 // Product: out = J_f(h) v from the stored linearisation
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef LIN_PRIO
+#define LIN_PRIO 0   // 1: s_setprio(3) through stage 1 and the slot walk, 0 from the node update on (as k_f_tile's TILE_PRIO = 15)
+#endif
 #ifndef LIN_REC_EARLY
 #define LIN_REC_EARLY 0   // 1: node record requested before the slot walk (127 VGPRs, four waves per SIMD)
 #endif
@@ -321,6 +324,7 @@ __global__ __launch_bounds__(TILE_THREADS) LIN_OCC void k_jvp_lin(int n_tiles, i
   const int32_t* hl = C.halo + (int64_t)tile * HALO_CAP;
   const float* T = W + tofs;
   float dx[D];
+  if (LIN_PRIO) __builtin_amdgcn_s_setprio(3);
   lin_stage1<P>(T, tv, t0, n_t, n_h, hl, lds, dx);
   __syncthreads();
   if (tid >= n_t) return;
@@ -384,6 +388,7 @@ __global__ __launch_bounds__(TILE_THREADS) LIN_OCC void k_jvp_lin(int n_tiles, i
     }
   }
   // ---- tangent of the gate, the update MLP and LayerNorm
+  if (LIN_PRIO) __builtin_amdgcn_s_setprio(0);
 #if !LIN_REC_EARLY
   PHASE();   // the node record and v's own row are not needed during the walk: read them here instead of holding 34 VGPRs across it
   const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3], r4 = rp[4], r5 = rp[5];
