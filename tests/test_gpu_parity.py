@@ -90,6 +90,14 @@ def test_plan_degenerate_graphs(dev):
         with torch.no_grad():
             want = orc.function_forward(sd, h0.clone(), h0, m)
         assert rel_l2(got, want) < 2e-6
+        # the adjoint products on the same degenerate graphs: direct JVP vs the stored linearisation (slices without a slot row)
+        v = torch.randn(N, 10, generator=torch.Generator().manual_seed(1)).to(dev)
+        jv = fm.jvp(h0.to(dev), v)
+        assert bool(torch.isfinite(jv).all()) and float(jv[[0, 4]].abs().max()) == 0.0     # Dirichlet rows
+        if fm.can_linearize():
+            lin = fm.linearize_p(fm.to_plan(h0.to(dev)))
+            assert rel_l2(fm.from_plan(lin.jvp_p(fm.to_plan(v))), jv) < 2e-6 or float(jv.abs().max()) == 0.0
+            lin.close()
 
 
 # ------------------------------------------------------------------------------------------ f
