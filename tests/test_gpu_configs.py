@@ -228,6 +228,13 @@ def test_config4_1m_f_vs_oracle(dev):
     v = torch.randn(mesh.num_nodes, 10, generator=torch.Generator().manual_seed(7))
     jv_ref = orc.function_jvp(sd, want, h0, mesh, v)
     assert rel_l2(fm.jvp(want.to(dev), v.to(dev)), jv_ref) < 1e-5
+    # the stored linearisation at the same state (what Newton-Krylov applies at this size): same product, exactly linear
+    xp, vp = fm.to_plan(want.to(dev)), fm.to_plan(v.to(dev))
+    lin = fm.linearize_p(xp)
+    jl = lin.jvp_p(vp)
+    assert rel_l2(fm.from_plan(jl), jv_ref) < 1e-5 and rel_l2(jl, fm.jvp_p(xp, vp)) < 2e-6
+    assert torch.equal(lin.jvp_p(-2.0 * vp), -2.0 * jl)      # (scaling by a power of two commutes with every rounding)
+    lin.close()
 
 
 def test_batched_solver_ragged_shard_and_fallbacks(dev):
