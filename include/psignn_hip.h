@@ -142,7 +142,8 @@ int psignn_f_jvp(const psignn_plan_t* plan, const float* d_weights, int n_layers
 /* Linearisation of f at a fixed state h, for Krylov solvers that apply J_f(h) to many vectors (Newton-Krylov, BASELINE config 5):
  * psignn_lin_build evaluates the value path of f once and stores what the Jacobian needs (relu masks of every edge direction as
  * wave-level bit masks, per-node gate / update / LayerNorm quantities); psignn_lin_jvp then applies J_f(h) as a linear operator,
- * at about half the cost of psignn_f_jvp.  Tiled dirichlet plans, single-layer blocks; h, prb, v, out in PLAN order
+ * at about half the cost of psignn_f_jvp.  Tiled plans; dirichlet: single-layer blocks; mixed (d_normals_plan required; the tiles
+ * holding Neumann nodes run the direct kernel at a copy of the state kept by the build).  h, prb, normals, v, out in PLAN order
  * (psignn_plan_permute).  The handle keeps a pointer to the plan: destroy it before the plan.
  * replaces: nothing executable in the reference (see psignn_f_jvp); same product as psignn_f_jvp up to fp32 summation order. */
 typedef struct psignn_lin psignn_lin_t;
@@ -150,7 +151,7 @@ int psignn_lin_create(psignn_lin_t** out, const psignn_plan_t* plan);
 void psignn_lin_destroy(psignn_lin_t* lin);
 size_t psignn_lin_bytes(const psignn_lin_t* lin);
 int psignn_lin_build(psignn_lin_t* lin, const float* d_weights, int n_layers, const float* d_h_plan, const float* d_prb_plan,
-                     void* stream);
+                     const float* d_normals_plan, void* stream);
 int psignn_lin_jvp(const psignn_lin_t* lin, const float* d_weights, int n_layers, const float* d_v_plan, float* d_out_plan,
                    void* stream);
 

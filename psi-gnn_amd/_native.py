@@ -56,7 +56,7 @@ SIGNATURES = {
     "psignn_lin_create": (_INT, [_P, _P]),
     "psignn_lin_destroy": (None, [_P]),
     "psignn_lin_bytes": (C.c_size_t, [_P]),
-    "psignn_lin_build": (_INT, [_P, _P, _INT, _P, _P, _P]),
+    "psignn_lin_build": (_INT, [_P, _P, _INT, _P, _P, _P, _P]),
     "psignn_lin_jvp": (_INT, [_P, _P, _INT, _P, _P, _P]),
     "psignn_f_vjp": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P]),
     "psignn_f_vjp_p": (_INT, [_P, _P, _INT, _P, _P, _P, _P, _P, _P, _P]),

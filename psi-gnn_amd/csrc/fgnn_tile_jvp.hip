@@ -488,8 +488,16 @@ __global__ __launch_bounds__(TILE_THREADS) JVP_OCC void k_jvp_tile(int n_tiles, 
 }
 
 // h, prb, nrm (mixed plans), v, out in PLAN order.
+// groups (mixed plans): bit 0 = tiles without Neumann nodes, bit 1 = tiles holding Neumann nodes (fgnn_tile_lin.hip applies the
+// stored linearisation on the first group and this kernel on the second)
+int psignn_f_tile_jvp_groups(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* nrm,
+                             const float* v, float* out, int groups, hipStream_t st);
 int psignn_f_tile_jvp(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* nrm,
                       const float* v, float* out, hipStream_t st) {
+  return psignn_f_tile_jvp_groups(p, W, nl, h, prb, nrm, v, out, 3, st);
+}
+int psignn_f_tile_jvp_groups(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* nrm,
+                             const float* v, float* out, int groups, hipStream_t st) {
   ARG_CHECK(p && p->tiled && (nl == 1 || p->mixed), "tiled JVP: tiled plans, single-layer blocks (mixed: any depth, last layer)");
   ARG_CHECK(!p->mixed || nrm, "mixed plan needs unit normals");
 #define JVP_TILE_ARGS p->tile_ptr, p->tile_slice, p->halo, p->halo_cnt, p->slice_off, p->slice_deg, p->ell, p->flags_p
@@ -498,12 +506,12 @@ int psignn_f_tile_jvp(const psignn_plan* p, const float* W, int nl, const float*
     const int lofs = L::layer(nl - 1), tofs = L::tp_layer(nl, true, nl - 1), tnofs = L::tp_neu(nl);
     const int na = (int)p->n_tiles_plain, nb = (int)(p->n_tiles - p->n_tiles_plain);
     ARG_CHECK((size_t)p->max_rows * 60 * 4 <= 160 * 1024, "tile + halo rows exceed the LDS budget of the tiled JVP");
-    if (na > 0) {   // tiles without Neumann nodes: 160-byte LDS rows, no Neumann branch
+    if (na > 0 && (groups & 1)) {   // tiles without Neumann nodes: 160-byte LDS rows, no Neumann branch
       const int chunk = (int)cdiv(na, 8);
       LAUNCH("k_jvp_tile", st, (k_jvp_tile<3, false, false><<<(unsigned)(chunk * 8), TILE_THREADS, (size_t)p->max_rows * 40 * 4, st>>>(
           na, chunk, p->tile_order, JVP_TILE_ARGS, W, lofs, tofs, tnofs, h, prb, nrm, v, out)));
     }
-    if (nb > 0) {
+    if (nb > 0 && (groups & 2)) {
       const int chunk = (int)cdiv(nb, 8);
       LAUNCH("k_jvp_tile", st, (k_jvp_tile<3, true, false><<<(unsigned)(chunk * 8), TILE_THREADS, (size_t)p->max_rows * 60 * 4, st>>>(
           nb, chunk, p->tile_order + na, JVP_TILE_ARGS, W, lofs, tofs, tnofs, h, prb, nrm, v, out)));

@@ -16,7 +16,9 @@
 //
 // Against k_jvp_tile at 1M nodes: ~0.4 x the VALU instructions per wave, 80-byte LDS rows (tangent projections only: six
 // workgroups per CU instead of three), about the same bytes (the 96-byte node record replaces the h row, the 16-byte slot records
-// shrink to 4 bytes).  Dirichlet plans with a single-layer block; other plans keep k_jvp_tile (psignn_lin_create refuses them).
+// shrink to 4 bytes).  Dirichlet plans with a single-layer block; mixed plans: the tiles WITHOUT Neumann nodes (all but the boundary
+// tiles) go through the stored linearisation, the few tiles holding Neumann nodes through k_jvp_tile at the state kept from the build
+// (a Neumann row needs a third mask set per slot; not worth a second record format for ~2 % of the tiles).
 // weight loads of mv2 pinned chunk by chunk (tile_helpers.h; A/B in profiles/r3_ab_mv2.txt: k_jvp_lin 53 -> 48.5 us)
 #ifndef MV2_LAUNDER
 #define MV2_LAUNDER 2
@@ -33,6 +35,7 @@ struct psignn_lin {
   const psignn_plan* plan = nullptr;
   uint32_t* slot = nullptr;     // (ell_rows, 64)
   float* rec = nullptr;         // (N, LIN_REC)
+  float *h = nullptr, *prb = nullptr, *nrm = nullptr;   // mixed plans: the state of the last build (k_jvp_tile on the Neumann tiles)
   size_t bytes = 0;
   int built = 0;
 };
@@ -106,15 +109,17 @@ __device__ __forceinline__ void lin_stage1(const float* __restrict__ T, const fl
 // Build: the value path of f at h (same formulas and operation order as k_jvp_tile's value half), storing what J_f(h) needs.
 // ------------------------------------------------------------------------------------------------------------------
 template <int P>
-__global__ __launch_bounds__(TILE_THREADS) void k_lin_build(int n_tiles, int chunk, const TileCtx C, const float* __restrict__ W,
+__global__ __launch_bounds__(TILE_THREADS) void k_lin_build(int n_tiles, int chunk, const int32_t* __restrict__ tile_list, const TileCtx C,
+                                                            const float* __restrict__ W,
                                                             int lofs, int tofs, const float* __restrict__ h,
                                                             const float* __restrict__ prb, uint32_t* __restrict__ slot,
                                                             float* __restrict__ rec) {
   using L = WLayout<P>;
   constexpr int RS = 20;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (tile >= n_tiles) return;
+  const int slot_ = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (slot_ >= n_tiles) return;
+  const int tile = tile_list ? tile_list[slot_] : slot_;   // mixed plans: the tiles without Neumann nodes
   const int tid = threadIdx.x;
   const int tn = C.tile_nodes;
   const int32_t t0 = tn ? tile * tn : C.tile_ptr[tile];
@@ -307,15 +312,17 @@ __global__ __launch_bounds__(TILE_THREADS) void k_lin_build(int n_tiles, int chu
 #define LIN_OCC
 #endif
 template <int P>
-__global__ __launch_bounds__(TILE_THREADS) LIN_OCC void k_jvp_lin(int n_tiles, int chunk, const TileCtx C, const float* __restrict__ W,
+__global__ __launch_bounds__(TILE_THREADS) LIN_OCC void k_jvp_lin(int n_tiles, int chunk, const int32_t* __restrict__ tile_list,
+                                                                  const TileCtx C, const float* __restrict__ W,
                                                                   int lofs, int tofs, const uint32_t* __restrict__ slot,
                                                                   const float* __restrict__ rec,
                                                                   const float* __restrict__ tv, float* __restrict__ out) {
   using L = WLayout<P>;
   constexpr int RS = 20;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (tile >= n_tiles) return;
+  const int slot_ = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (slot_ >= n_tiles) return;
+  const int tile = tile_list ? tile_list[slot_] : slot_;
   const int tid = threadIdx.x;
   const int tn = C.tile_nodes;
   const int32_t t0 = tn ? tile * tn : C.tile_ptr[tile];
@@ -442,46 +449,71 @@ __global__ __launch_bounds__(TILE_THREADS) LIN_OCC void k_jvp_lin(int n_tiles, i
 }
 
 // ------------------------------------------------------------------------------------------------------------------ host
+int psignn_f_tile_jvp_groups(const psignn_plan* p, const float* W, int nl, const float* h, const float* prb, const float* nrm,
+                             const float* v, float* out, int groups, hipStream_t st);
+
 extern "C" int psignn_lin_create(psignn_lin_t** out, const psignn_plan_t* p) {
   ARG_CHECK(out && p, "NULL argument");
-  ARG_CHECK(p->tiled && !p->mixed, "linearised JVP: tiled dirichlet plans (other plans use psignn_f_jvp)");
+  ARG_CHECK(p->tiled, "linearised JVP: tiled plans (other plans use psignn_f_jvp)");
+  ARG_CHECK(p->max_rows <= 1024, "tile + halo rows exceed the 10-bit row field of the stored slots");
   psignn_lin* s = new psignn_lin();
   s->plan = p;
-  ARG_CHECK(p->max_rows <= 1024, "tile + halo rows exceed the 10-bit row field of the stored slots");
   const size_t b_slot = (size_t)(p->ell_rows + 1) * 64 * 4, b_rec = (size_t)p->N * LIN_REC * 4;
-  if (hipMalloc((void**)&s->slot, b_slot) != hipSuccess || hipMalloc((void**)&s->rec, b_rec) != hipSuccess) {
+  const size_t b_state = p->mixed ? (size_t)p->N * (D + 3 + 2) * 4 : 0;
+  bool ok = hipMalloc((void**)&s->slot, b_slot) == hipSuccess && hipMalloc((void**)&s->rec, b_rec) == hipSuccess;
+  if (ok && p->mixed)
+    ok = hipMalloc((void**)&s->h, (size_t)p->N * D * 4) == hipSuccess && hipMalloc((void**)&s->prb, (size_t)p->N * 3 * 4) == hipSuccess &&
+         hipMalloc((void**)&s->nrm, (size_t)p->N * 2 * 4) == hipSuccess;
+  if (!ok) {
     (void)hipGetLastError();
     psignn_lin_destroy(s);
-    psignn_set_error("psignn_lin_create: out of device memory (%zu bytes)", b_slot + b_rec);
+    psignn_set_error("psignn_lin_create: out of device memory (%zu bytes)", b_slot + b_rec + b_state);
     return PSIGNN_ENOMEM;
   }
-  s->bytes = b_slot + b_rec;
+  s->bytes = b_slot + b_rec + b_state;
   *out = s;
   return PSIGNN_OK;
 }
 
 extern "C" void psignn_lin_destroy(psignn_lin_t* s) {
   if (!s) return;
-  for (void* q : {(void*)s->slot, (void*)s->rec})
+  for (void* q : {(void*)s->slot, (void*)s->rec, (void*)s->h, (void*)s->prb, (void*)s->nrm})
     if (q) (void)hipFree(q);
   delete s;
 }
 
 extern "C" size_t psignn_lin_bytes(const psignn_lin_t* s) { return s ? s->bytes : 0; }
 
-// h, prb in PLAN order; single-layer block (nl = 1)
-extern "C" int psignn_lin_build(psignn_lin_t* s, const float* W, int nl, const float* h, const float* prb, void* stream) {
+// h, prb (and, mixed plans, the unit normals) in PLAN order; dirichlet: single-layer block; mixed: any depth (the iterated layer is
+// the last one, as in psignn_f_jvp)
+extern "C" int psignn_lin_build(psignn_lin_t* s, const float* W, int nl, const float* h, const float* prb, const float* nrm,
+                                void* stream) {
   ARG_CHECK(s && W && h && prb, "NULL argument");
-  ARG_CHECK(nl == 1, "linearised JVP: single-layer blocks");
   const psignn_plan* p = s->plan;
+  ARG_CHECK(p->mixed ? nl >= 1 : nl == 1, "linearised JVP: single-layer blocks (mixed plans: the last layer)");
+  ARG_CHECK(!p->mixed || nrm, "mixed plan needs unit normals");
   hipStream_t st = (hipStream_t)stream;
-  using L = WLayout<2>;
-  const int chunk = (int)cdiv(p->n_tiles, 8);
   const size_t lds = (size_t)p->max_rows * 20 * 4;
-  // B_f's reads (h, prb, flags, slot records) + the stored linearisation
-  PROF_BYTES((49 * p->N + 20 * p->Ep) + (int64_t)p->N * LIN_REC * 4 + (int64_t)p->ell_rows * 64 * 4);
-  LAUNCH("k_lin_build", st, (k_lin_build<2><<<(unsigned)(chunk * 8), TILE_THREADS, lds, st>>>(
-      (int)p->n_tiles, chunk, p->h_ctx, W, L::layer(0), L::tp_layer(nl, false, 0), h, prb, s->slot, s->rec)));
+  if (p->mixed) {
+    using L = WLayout<3>;
+    const int na = (int)p->n_tiles_plain;
+    HIP_TRY(hipMemcpyAsync(s->h, h, (size_t)p->N * D * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->prb, prb, (size_t)p->N * 3 * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->nrm, nrm, (size_t)p->N * 2 * 4, hipMemcpyDeviceToDevice, st));
+    if (na > 0) {
+      const int chunk = (int)cdiv(na, 8);
+      PROF_BYTES((62 * p->N + 20 * p->Ep) + (int64_t)p->N * LIN_REC * 4 + (int64_t)p->ell_rows * 64 * 4);
+      LAUNCH("k_lin_build", st, (k_lin_build<3><<<(unsigned)(chunk * 8), TILE_THREADS, lds, st>>>(
+          na, chunk, p->tile_order, p->h_ctx, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), h, prb, s->slot, s->rec)));
+    }
+  } else {
+    using L = WLayout<2>;
+    const int chunk = (int)cdiv(p->n_tiles, 8);
+    // B_f's reads (h, prb, flags, slot records) + the stored linearisation
+    PROF_BYTES((49 * p->N + 20 * p->Ep) + (int64_t)p->N * LIN_REC * 4 + (int64_t)p->ell_rows * 64 * 4);
+    LAUNCH("k_lin_build", st, (k_lin_build<2><<<(unsigned)(chunk * 8), TILE_THREADS, lds, st>>>(
+        (int)p->n_tiles, chunk, nullptr, p->h_ctx, W, L::layer(0), L::tp_layer(nl, false, 0), h, prb, s->slot, s->rec)));
+  }
   HIP_TRY(hipGetLastError());
   s->built = 1;
   return PSIGNN_OK;
@@ -491,17 +523,30 @@ extern "C" int psignn_lin_build(psignn_lin_t* s, const float* W, int nl, const f
 extern "C" int psignn_lin_jvp(const psignn_lin_t* s, const float* W, int nl, const float* v, float* out, void* stream) {
   ARG_CHECK(s && W && v && out, "NULL argument");
   ARG_CHECK(s->built, "psignn_lin_build has not run");
-  ARG_CHECK(nl == 1, "linearised JVP: single-layer blocks");
   ARG_CHECK(v != out, "in-place product is not supported");
   const psignn_plan* p = s->plan;
+  ARG_CHECK(p->mixed ? nl >= 1 : nl == 1, "linearised JVP: single-layer blocks (mixed plans: the last layer)");
   hipStream_t st = (hipStream_t)stream;
-  using L = WLayout<2>;
-  const int chunk = (int)cdiv(p->n_tiles, 8);
   const size_t lds = std::max((size_t)p->max_rows * 20 * 4, tile_lds_min());
-  // v, out (40 N each), flags (N), node records, slot dwords
-  PROF_BYTES((int64_t)p->N * (81 + LIN_REC * 4) + (int64_t)p->ell_rows * 64 * 4);
-  LAUNCH("k_jvp_lin", st, (k_jvp_lin<2><<<(unsigned)(chunk * 8), TILE_THREADS, lds, st>>>(
-      (int)p->n_tiles, chunk, p->h_ctx, W, L::layer(0), L::tp_layer(nl, false, 0), s->slot, s->rec, v, out)));
+  if (p->mixed) {
+    using L = WLayout<3>;
+    const int na = (int)p->n_tiles_plain;
+    if (na > 0) {
+      const int chunk = (int)cdiv(na, 8);
+      PROF_BYTES((int64_t)p->N * (81 + LIN_REC * 4) + (int64_t)p->ell_rows * 64 * 4);
+      LAUNCH("k_jvp_lin", st, (k_jvp_lin<3><<<(unsigned)(chunk * 8), TILE_THREADS, lds, st>>>(
+          na, chunk, p->tile_order, p->h_ctx, W, L::layer(nl - 1), L::tp_layer(nl, true, nl - 1), s->slot, s->rec, v, out)));
+    }
+    int rc = psignn_f_tile_jvp_groups(p, W, nl, s->h, s->prb, s->nrm, v, out, 2, st);   // the tiles holding Neumann nodes
+    if (rc) return rc;
+  } else {
+    using L = WLayout<2>;
+    const int chunk = (int)cdiv(p->n_tiles, 8);
+    // v, out (40 N each), flags (N), node records, slot dwords
+    PROF_BYTES((int64_t)p->N * (81 + LIN_REC * 4) + (int64_t)p->ell_rows * 64 * 4);
+    LAUNCH("k_jvp_lin", st, (k_jvp_lin<2><<<(unsigned)(chunk * 8), TILE_THREADS, lds, st>>>(
+        (int)p->n_tiles, chunk, nullptr, p->h_ctx, W, L::layer(0), L::tp_layer(nl, false, 0), s->slot, s->rec, v, out)));
+  }
   HIP_TRY(hipGetLastError());
   return PSIGNN_OK;
 }

@@ -353,8 +353,8 @@ class FixedPointMap:
         return out
 
     def can_linearize(self):
-        """True when ``linearize_p`` applies: tiled dirichlet plan, single-layer block (csrc/fgnn_tile_lin.hip)."""
-        return bool(self.plan.tiled) and not self.plan.mixed and self.weights.n_layers == 1
+        """True when ``linearize_p`` applies: tiled plan; dirichlet family: single-layer block (csrc/fgnn_tile_lin.hip)."""
+        return bool(self.plan.tiled) and (bool(self.plan.mixed) or self.weights.n_layers == 1)
 
     def linearize_p(self, Hp, lin=None):
         """Linearisation of f at ``Hp`` (plan order) for solvers that apply J_f(Hp) to many vectors: one pass stores the relu
@@ -823,7 +823,7 @@ class Linearization:
 
     def __init__(self, fmap):
         if not fmap.can_linearize():
-            raise nat.NativeError("linearize_p: tiled dirichlet plans with a single-layer block (use jvp_p otherwise)")
+            raise nat.NativeError("linearize_p: tiled plans (dirichlet family: single-layer blocks); use jvp_p otherwise")
         self.fmap = fmap
         h = C.c_void_p()
         with torch.cuda.device(fmap.weights.flat.device):
@@ -833,11 +833,11 @@ class Linearization:
 
     def build(self, Hp):
         fm = self.fmap
-        _, prbp, _ = fm._p
+        _, prbp, nrmp = fm._p
         Hc = _f32c(Hp)
         with torch.cuda.device(Hc.device):
             nat.check(nat.lib().psignn_lin_build(self.handle, nat.ptr(fm.weights.flat), fm.weights.n_layers, nat.ptr(Hc),
-                                                 nat.ptr(prbp), nat.stream_ptr(Hc.device)), "psignn_lin_build")
+                                                 nat.ptr(prbp), nat.ptr(nrmp), nat.stream_ptr(Hc.device)), "psignn_lin_build")
         return self
 
     def jvp_p(self, Vp, out=None):

@@ -460,6 +460,22 @@ def test_linearised_jvp_on_many_tiles_and_in_newton_krylov(dev, monkeypatch):
     assert rel_l2(a, b) < 2e-6, rel_l2(a, b)
     assert float((a - b).abs().max()) < 1e-5 * float(b.abs().max())
     lin.close()
+    # mixed family at 100k nodes: stored form on the tiles without Neumann nodes + direct kernel on the boundary tiles
+    sdm = load_weights("mixed")
+    mm = data.make_hex_problem(data.hex_n_for_nodes(100000), seed=2, mixed=True, compute_sol=False)
+    mdm, h0m, planm, fmm = _fmap(mm, sdm, dev)
+    assert planm.mixed and fmm.can_linearize()
+    xm = fmm.to_plan(fmm.h0)
+    for _ in range(6):
+        xm = fmm.fp(xm)
+    Vm = fmm.to_plan(torch.randn(h0m.shape, generator=gen).to(dev))
+    linm = fmm.linearize_p(xm)
+    am, bm = linm.jvp_p(Vm), fmm.jvp_p(xm, Vm)
+    assert rel_l2(am, bm) < 2e-6, rel_l2(am, bm)
+    xm2 = fmm.fp(xm)                         # rebuild at another state: the kept copy of the state moves with it
+    linm.build(xm2)
+    assert rel_l2(linm.jvp_p(Vm), fmm.jvp_p(xm2, Vm)) < 2e-6
+    linm.close()
     # Newton-Krylov on a mesh inside the range where it converges (20 tiles): the first outer steps follow each other closely
     # (same Newton systems up to rounding), the final residuals are of one order
     mesh = data.make_hex_problem(data.hex_n_for_nodes(5000), seed=2, compute_sol=False)
