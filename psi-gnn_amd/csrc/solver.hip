@@ -49,6 +49,9 @@ struct Status {
 // (block_sum_col, vec_helpers.h: RB = 1 024 threads per reduce block was tried for the column reads:
 // k_reduce_cb 9.7 vs 8.3 us, k_reduce_a_check unchanged -- a block's time is the 64-byte sectors it pulls through ONE CU, not
 // its load rounds; what helps is more blocks per column, RA below.)
+#ifndef SWEEP_V_AHEAD
+#define SWEEP_V_AHEAD 0   // 1: sweep 2 (16 floats per lane) requests the next pair's row before it works on the current one (A/B: slower)
+#endif
 #define RB 256
 #define RA 8     // row chunks per column of the a-reduction: coef_a arrives as RA partial sums that sweep 2 adds up itself
 struct psignn_broyden {
@@ -482,7 +485,8 @@ __device__ __forceinline__ void sweep_v_body(int64_t M, int k, const Status* __r
   const bool lead = lane == 0;
   float* rowb = part + (int64_t)blockIdx.x * ldp;      // planes 1 (c) and 2 (b)
   float cw = 0.f;                                       // coef_a of the current chunk of 64 pairs: lane q holds a_{jc + q}
-  for (int j = 0; j < k; ++j) {
+  // One stored pair: the dot products and vT's term of V_j, whose values `v` the caller has requested already.
+  auto step = [&](const int j, const float* v) {
     const int q = j & 63;
     // one vector load of 64 coefficients per chunk, handed out by v_readlane: in the batched kernels the table hangs off a
     // descriptor in memory, where a scalar per-pair read is a vector load with its full latency inside the loop
@@ -494,11 +498,9 @@ __device__ __forceinline__ void sweep_v_body(int64_t M, int k, const Status* __r
       }
       cw = (float)acc;
     }
-    float v[VEC];
     float sc = 0.f, sb = 0.f;
     const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cw), q));
     if (act) {
-      ldv_stream<VEC>(V + (int64_t)j * ld, e0, M, v);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         sc = fmaf(v[i], dg[i], sc);
@@ -515,6 +517,32 @@ __device__ __forceinline__ void sweep_v_body(int64_t M, int k, const Status* __r
     if (q == 63 || j == k - 1) {
       float* const rows[2] = {rowb + pstride + (j - q), rowb + 2 * pstride + (j - q)};
       stash_flush<2>(sh, q + 1, rows);
+    }
+  };
+  if (SWEEP_V_AHEAD && VEC == 16) {
+    // (experiment, off) Two pairs' rows in flight per wave: the sweep holds 96 VGPRs = five waves per SIMD with ONE 4 KB row per wave
+    // in flight; requesting the row of pair j + 1 before pair j is worked on (two register buffers, loop unrolled by two) doubles the
+    // bytes in flight per wave but costs a wave per SIMD (128 VGPRs).  Measured, interleaved on one box (profiles/r3_ab_sweepv.txt):
+    // K = 20 94.4 -> 99.5 us (0.69 -> 0.65), K = 100 361 -> 384 us -- the fifth wave is worth more than the second row.
+    float va[VEC], vb[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) va[i] = vb[i] = 0.f;
+    if (act && k > 0) ldv_stream<VEC>(V, e0, M, va);
+    int j = 0;
+    for (; j + 1 < k; j += 2) {
+      if (act) ldv_stream<VEC>(V + (int64_t)(j + 1) * ld, e0, M, vb);
+      step(j, va);
+      if (act && j + 2 < k) ldv_stream<VEC>(V + (int64_t)(j + 2) * ld, e0, M, va);
+      step(j + 1, vb);
+    }
+    if (j < k) step(j, va);
+  } else {
+    for (int j = 0; j < k; ++j) {
+      float v[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[i] = 0.f;
+      if (act) ldv_stream<VEC>(V + (int64_t)j * ld, e0, M, v);
+      step(j, v);
     }
   }
   float p1 = 0.f, p2 = 0.f;
