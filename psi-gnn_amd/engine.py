@@ -352,6 +352,30 @@ class FixedPointMap:
                                                nat.stream_ptr(Hc.device)), "psignn_f_jvp_p")
         return out
 
+    # ---- one idle Broyden solver kept between solves of this map (utilities.solver.broyden without keep_trace / solver_obj):
+    # creating and destroying the 2 * threshold state vectors costs 2.2 ms per call at 1M nodes and threshold 20 -- a quarter of
+    # such a solve (profiles/r3_cold_solve_probe.txt).  Bounded by PSIGNN_SOLVER_CACHE_GB (default 16; 0 disables).
+    def borrow_broyden(self, threshold):
+        sv = getattr(self, "_idle_broyden", None)
+        self._idle_broyden = None
+        if sv is not None and sv.threshold == int(threshold) and not sv.keep_trace:
+            return sv
+        if sv is not None:
+            sv.close()
+        return DeviceBroyden(plan=self.plan, threshold=threshold, keep_trace=False)
+
+    def return_broyden(self, sv):
+        import os
+        limit = float(os.environ.get("PSIGNN_SOLVER_CACHE_GB", "16")) * 1e9
+        old = getattr(self, "_idle_broyden", None)
+        if old is not None and old is not sv:
+            old.close()
+        if sv.nbytes <= limit:
+            self._idle_broyden = sv
+        else:
+            self._idle_broyden = None
+            sv.close()
+
     def can_linearize(self):
         """True when ``linearize_p`` applies: tiled plan; dirichlet family: single-layer block (csrc/fgnn_tile_lin.hip)."""
         return bool(self.plan.tiled) and (bool(self.plan.mixed) or self.weights.n_layers == 1)

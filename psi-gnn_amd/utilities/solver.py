@@ -21,6 +21,13 @@ from .. import _native as nat
 from ..engine import D, TRACE_BUDGET_BYTES, DeviceBroyden, DeviceFixedPointIter, FixedPointMap
 
 
+class _NoTrace:
+    keep_trace = False
+
+
+_NO_TRACE = _NoTrace()
+
+
 class _LazyTrace:
     """``xest_trace`` of a device solve: list-like, iterates are copied out on demand."""
 
@@ -74,9 +81,21 @@ def broyden(f, x0, threshold, eps=1e-3, stop_mode="rel", ls=False, name="unknown
         # solver_obj: a DeviceBroyden of the same plan / threshold kept by the caller between solves (a training loop
         # would otherwise allocate and free 2 * threshold * N * d floats per step); its iterates are overwritten by the
         # next solve, so it is only meant for callers that do not keep xest_trace
-        solver = solver_obj if solver_obj is not None else DeviceBroyden(plan=f.plan, threshold=threshold, keep_trace=keep_trace)
+        # without solver_obj and without a kept trace the map lends its idle solver (FixedPointMap.borrow_broyden): repeated solves
+        # on one map do not re-allocate their state
+        pooled = solver_obj is None and not keep_trace
+        if pooled:
+            solver = f.borrow_broyden(threshold)
+        else:
+            solver = solver_obj if solver_obj is not None else DeviceBroyden(plan=f.plan, threshold=threshold, keep_trace=keep_trace)
         solver.set_stop_mode(stop_mode)
-        out = solver.solve(f, eps, poll_every=poll_every)
+        try:
+            out = solver.solve(f, eps, poll_every=poll_every)
+        finally:
+            if pooled:
+                f.return_broyden(solver)
+        if pooled:
+            solver = _NO_TRACE          # (the result holds no reference to the lent solver: its buffers belong to the next solve)
         x_init = f.h0
     else:
         solver = DeviceBroyden(threshold=threshold, keep_trace=keep_trace, n_elems=M, seq_len=x0.shape[1],

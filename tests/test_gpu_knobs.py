@@ -124,3 +124,31 @@ def test_gmres_unconditional_reorthogonalisation(dev, knobs):
     knobs(PSIGNN_GMRES_REORTH=None)
     np.testing.assert_allclose(a["rel_trace"][:2], b["rel_trace"][:2], rtol=5e-2)
     assert 0.2 < a["lowest"] / b["lowest"] < 5.0
+
+
+def test_idle_solver_is_lent_between_solves_of_one_map(dev, monkeypatch):
+    """utilities.solver.broyden without keep_trace / solver_obj borrows the map's idle DeviceBroyden and returns it: the second solve
+    runs on the same state buffers (no 2 * threshold vectors re-allocated) and gives the same bits; another threshold replaces the
+    idle solver; PSIGNN_SOLVER_CACHE_GB=0 keeps nothing; a kept trace never shares a solver."""
+    data, solver = pkg("data"), pkg("utilities.solver")
+    sd = load_weights("dirichlet")
+    mesh = data.make_hex_problem(data.hex_n_for_nodes(20000), seed=10, compute_sol=False)
+    md, h0, plan, fm = _fmap(mesh, sd, dev)
+    a = solver.broyden(fm, fm.h0, threshold=12, eps=0.0, keep_trace=False)
+    sv = fm._idle_broyden
+    assert sv is not None and sv.threshold == 12
+    b = solver.broyden(fm, fm.h0, threshold=12, eps=0.0, keep_trace=False)
+    assert fm._idle_broyden is sv
+    assert torch.equal(a["result"], b["result"]) and a["rel_trace"] == b["rel_trace"]
+    assert torch.equal(a["xest_trace"][0], fm.h0) and torch.equal(a["xest_trace"][a["nstep"]], a["result"])
+    with pytest.raises(RuntimeError):
+        a["xest_trace"][3]
+    c = solver.broyden(fm, fm.h0, threshold=7, eps=0.0, keep_trace=False)
+    assert fm._idle_broyden is not sv and fm._idle_broyden.threshold == 7
+    np.testing.assert_allclose(c["rel_trace"][:7], a["rel_trace"][:7], rtol=1e-4)
+    kept = solver.broyden(fm, fm.h0, threshold=7, eps=0.0, keep_trace=True)
+    assert fm._idle_broyden.threshold == 7 and torch.equal(kept["xest_trace"][7], kept["xest_trace"][7])
+    assert rel_l2(kept["xest_trace"][kept["nstep"]], kept["result"]) == 0.0
+    monkeypatch.setenv("PSIGNN_SOLVER_CACHE_GB", "0")
+    solver.broyden(fm, fm.h0, threshold=7, eps=0.0, keep_trace=False)
+    assert fm._idle_broyden is None
