@@ -457,6 +457,7 @@ def main():
                                        "achieved": nk_hi / us_nk * 1e-3, "unit": "GB/s", "frac": nk_hi / us_nk * 1e-3 / HBM_PEAK_GBS,
                                        "frac_lower": nk_lo / us_nk * 1e-3 / HBM_PEAK_GBS,
                                        "linear_residual_after_m": float(hist[-1]) if len(hist) else None,
+                                       "linear_residual_first": float(hist[0]) if len(hist) else None,
                                        "note": "one linearisation + device GMRES without restarts around its JVP, Hessenberg / Givens on the "
                                                "device, no host synchronisation inside the m steps; bytes priced with the number of "
                                                "steps whose second Gram-Schmidt pass ran (psignn_gmres_reorth_count)"}

@@ -58,6 +58,10 @@ def test_bench_kernel_records_come_from_the_library():
     sweep_bytes = sum(r["alg_bytes_per_launch"] * r["work_launches"] for r in d["kernels"] if "alg_bytes_per_launch" in r)
     assert abs(sweep_bytes - d["roofline_iter"]["alg_bytes"]) < 1e-6 * sweep_bytes
     assert d["roofline"]["kernel"] in rows and d["roofline"]["alg_bytes_per_launch"] > 0
+    # the Newton-Krylov leg: the stored linearisation is what it applies, and its 30 Arnoldi steps do reduce the linear residual
+    nk, rj = d["newton_krylov"], d["roofline_jvp"]
+    assert rj["kernel"] == "k_jvp_lin" and rj["avg_launch_us"] < d["roofline_jvp_direct"]["avg_launch_us"]
+    assert nk["arnoldi_steps"] == 30 and 0.0 < nk["linear_residual_after_m"] < nk["linear_residual_first"] <= 1.0 + 1e-6
     assert d["ms_per_step_first"] > 0 and "warmup_extra" in d and d["ranks"]["world_size"] == 1
 
 
